@@ -1,0 +1,78 @@
+"""Pin the oracle (oracle/videoitg_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from /root/reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import videoitg_oracle as O
+from videoitg_amd import synth
+from videoitg_amd.config import ITGConfig
+
+CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520"]
+TOL = 2e-5
+
+
+def load_case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    cfg = ITGConfig.from_dict(json.loads(str(z["cfg"])))
+    seed = int(z["seed"])
+    T = z["T"].tolist()
+    images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i) for i, t in enumerate(T)]
+    return z, cfg, seed, T, images
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference(golden_dir, name):
+    z, cfg, seed, T, images = load_case(golden_dir, name)
+    sd = synth.synth_llm_state_dict(cfg, seed)
+    vsd = synth.synth_vision_state_dict(cfg, seed)
+    ids = torch.from_numpy(z["input_ids"])
+    mask = torch.from_numpy(z["attention_mask"])
+    logits, im = O.forward(cfg, sd, vsd, ids, mask, images, return_intermediates=True)
+    # A7: tower output (hidden_states[-2])
+    assert (im["vit"][0] - torch.from_numpy(z["vit_first"])).abs().max() < TOL
+    assert (im["vit"][-1] - torch.from_numpy(z["vit_last"])).abs().max() < TOL
+    assert abs(im["vit"].double().abs().sum().item() - z["vit_sum"][1]) < 1e-6 * z["vit_sum"][1] + 1e-3
+    # A9: projector shapes and values
+    assert [list(v.shape) for v in im["visual"]] == z["visual_shapes"].tolist()
+    assert (im["visual"][0][:32] - torch.from_numpy(z["visual0_head"])).abs().max() < TOL
+    for v, (s, a) in zip(im["visual"], z["visual_sums"]):
+        assert abs(v.double().abs().sum().item() - a) < 1e-6 * a + 1e-3
+    # A10: splice
+    assert list(im["inputs_embeds"].shape) == z["embeds_shape"].tolist()
+    assert np.array_equal(im["token_types"].numpy(), z["token_types"])
+    assert abs(im["inputs_embeds"].double().abs().sum().item() - z["embeds_sum"][1]) < 1e-6 * z["embeds_sum"][1] + 1e-3
+    # A11: hidden after layer 1 and after the final norm (reference hidden_states = embeds, layer outs.., normed)
+    ls = z["layer_sums"]
+    assert abs(im["layers"][0].double().abs().sum().item() - ls[1][1]) < 2e-6 * ls[1][1]
+    assert abs(im["final"].double().abs().sum().item() - ls[-1][1]) < 2e-6 * ls[-1][1]
+    # A12: logits
+    for b in range(len(T)):
+        ref = torch.from_numpy(z[f"logits{b}"])
+        assert logits[b].shape == ref.shape == (T[b], 1)
+        assert (logits[b] - ref).abs().max() < TOL
+
+
+def test_padded_batch_equals_single(golden_dir):
+    """Row of a right-padded batch == the same video alone (key padding masked out)."""
+    a = np.load(os.path.join(golden_dir, "pool_post.npz"))
+    b = np.load(os.path.join(golden_dir, "batch2_pad.npz"))
+    assert np.abs(a["logits0"] - b["logits0"]).max() < 1e-6
+
+
+def test_rank_frames_stable_ties():
+    lg = torch.tensor([0.0, 2.0, 2.0, -1.0, 2.0])
+    s, order = O.rank_frames(lg)
+    assert order.tolist() == [1, 2, 4, 0, 3]
+    assert O.topk_selection(lg, [10, 20, 30, 40, 50], 2) == [20, 30]
+
+
+def test_pooled_grid_table():
+    # SURVEY.md Appendix A table (mlp_proj.py:48,54)
+    want = {16: 27, 22: 27, 23: 26, 32: 22, 64: 16, 128: 11, 200: 9, 256: 8, 512: 5, 1024: 4}
+    for T, hw in want.items():
+        assert O.pooled_grid(T, 27, 16384) == hw
+        assert ITGConfig().pooled_grid(T) == hw

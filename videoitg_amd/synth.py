@@ -1,0 +1,127 @@
+"""Seeded synthetic weights / inputs in the reference's checkpoint key layout.
+
+Real weights (``nvidia/VideoITG-8B``, ``google/siglip-so400m-patch14-384``) are unreachable offline
+(SURVEY.md §8c), so parity and the benchmark run on random-init weights of the same architecture.
+Every tensor is generated from its own ``torch.Generator`` seeded by (seed, crc32(key)), so tensors can
+be produced one at a time, in any order, and are bit-identical wherever torch's CPU generator is.
+
+Values are rounded so that they are exactly representable in BOTH bf16 and fp16 (bf16 rounding, then
+anything below fp16's normal range is flushed to zero): the fp32 oracle, a bf16 device run and an fp16
+device run all see the same weight values.
+
+Key names follow SURVEY.md §8(b) "Checkpoint layout the loader must accept":
+LLM/projector/head keys as in the ITG checkpoint, SigLIP keys as in the separate Hub repo
+(``vision_model.*``; /root/reference/eagle/model/builder.py:163-165 loads it separately).
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Iterator, Tuple
+
+import torch
+
+from .config import ITGConfig
+
+_FP16_MIN_NORMAL = 2.0 ** -14
+
+
+def round_16(t: torch.Tensor) -> torch.Tensor:
+    """fp32 values exactly representable in bf16 and fp16."""
+    t = t.to(torch.bfloat16).to(torch.float32)
+    t = torch.where(t.abs() < _FP16_MIN_NORMAL, torch.zeros_like(t), t)
+    return t.clamp_(-60000.0, 60000.0)
+
+
+def _gen(seed: int, key: str) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((seed * 1_000_003 + zlib.crc32(key.encode())) % (2 ** 63 - 1))
+    return g
+
+
+def _normal(seed, key, shape, std, mean=0.0) -> torch.Tensor:
+    t = torch.empty(shape, dtype=torch.float32)
+    t.normal_(mean, std, generator=_gen(seed, key))
+    return round_16(t)
+
+
+def llm_param_specs(cfg: ITGConfig) -> Iterator[Tuple[str, tuple, float, float]]:
+    """(key, shape, mean, std) for every LLM / projector / head tensor."""
+    D, F = cfg.hidden_size, cfg.intermediate_size
+    hd = cfg.head_dim
+    nq, nkv = cfg.num_attention_heads * hd, cfg.num_key_value_heads * hd
+    yield "model.embed_tokens.weight", (cfg.vocab_size, D), 0.0, 1.0
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        yield p + "input_layernorm.weight", (D,), 1.0, 0.02
+        yield p + "self_attn.q_proj.weight", (nq, D), 0.0, D ** -0.5
+        yield p + "self_attn.q_proj.bias", (nq,), 0.0, 0.02
+        yield p + "self_attn.k_proj.weight", (nkv, D), 0.0, D ** -0.5
+        yield p + "self_attn.k_proj.bias", (nkv,), 0.0, 0.02
+        yield p + "self_attn.v_proj.weight", (nkv, D), 0.0, D ** -0.5
+        yield p + "self_attn.v_proj.bias", (nkv,), 0.0, 0.02
+        yield p + "self_attn.o_proj.weight", (D, nq), 0.0, nq ** -0.5
+        yield p + "post_attention_layernorm.weight", (D,), 1.0, 0.02
+        yield p + "mlp.gate_proj.weight", (F, D), 0.0, D ** -0.5
+        yield p + "mlp.up_proj.weight", (F, D), 0.0, D ** -0.5
+        yield p + "mlp.down_proj.weight", (D, F), 0.0, F ** -0.5
+    yield "model.norm.weight", (D,), 1.0, 0.02
+    Dv = cfg.mm_hidden_size
+    yield "model.mm_projector.out_projection.0.weight", (D, Dv), 0.0, Dv ** -0.5
+    yield "model.mm_projector.out_projection.0.bias", (D,), 0.0, 0.02
+    yield "model.mm_projector.out_projection.2.weight", (D, D), 0.0, D ** -0.5
+    yield "model.mm_projector.out_projection.2.bias", (D,), 0.0, 0.02
+    # score head: scaled up so that the logits are spread out (SURVEY.md §7 hard-part 2)
+    yield "out_proj.weight", (1, D), 0.0, 4.0 * D ** -0.5
+    yield "out_proj.bias", (1,), 0.0, 0.02
+
+
+def vision_param_specs(cfg: ITGConfig) -> Iterator[Tuple[str, tuple, float, float]]:
+    v = cfg.vision
+    Dv, Fv, ps, C = v.hidden_size, v.intermediate_size, v.patch_size, v.num_channels
+    e = "vision_model.embeddings."
+    yield e + "patch_embedding.weight", (Dv, C, ps, ps), 0.0, (C * ps * ps) ** -0.5
+    yield e + "patch_embedding.bias", (Dv,), 0.0, 0.02
+    yield e + "position_embedding.weight", (v.num_patches, Dv), 0.0, 0.02
+    for i in range(v.num_hidden_layers):
+        p = f"vision_model.encoder.layers.{i}."
+        yield p + "layer_norm1.weight", (Dv,), 1.0, 0.02
+        yield p + "layer_norm1.bias", (Dv,), 0.0, 0.02
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            yield p + f"self_attn.{n}.weight", (Dv, Dv), 0.0, Dv ** -0.5
+            yield p + f"self_attn.{n}.bias", (Dv,), 0.0, 0.02
+        yield p + "layer_norm2.weight", (Dv,), 1.0, 0.02
+        yield p + "layer_norm2.bias", (Dv,), 0.0, 0.02
+        yield p + "mlp.fc1.weight", (Fv, Dv), 0.0, Dv ** -0.5
+        yield p + "mlp.fc1.bias", (Fv,), 0.0, 0.02
+        yield p + "mlp.fc2.weight", (Dv, Fv), 0.0, Fv ** -0.5
+        yield p + "mlp.fc2.bias", (Dv,), 0.0, 0.02
+
+
+def synth_tensor(seed: int, key: str, shape, mean: float, std: float) -> torch.Tensor:
+    return _normal(seed, key, shape, std, mean)
+
+
+def synth_llm_state_dict(cfg: ITGConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    return {k: _normal(seed, k, s, sd, m) for k, s, m, sd in llm_param_specs(cfg)}
+
+
+def synth_vision_state_dict(cfg: ITGConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    return {k: _normal(seed, k, s, sd, m) for k, s, m, sd in vision_param_specs(cfg)}
+
+
+def synth_pixel_values(num_frames: int, image_size: int, seed: int = 1234) -> torch.Tensor:
+    """``fp32 [T,3,R,R]`` in [-1,1] (what SiglipImageProcessor emits), low-pass
+    filtered so patches are not white noise, 16-bit exact."""
+    g = _gen(seed, f"pixels{num_frames}x{image_size}")
+    coarse = torch.rand((num_frames, 3, (image_size + 7) // 8, (image_size + 7) // 8), generator=g)
+    x = torch.nn.functional.interpolate(coarse, size=(image_size, image_size), mode="bilinear",
+                                        align_corners=False)
+    x = x + 0.1 * torch.rand(x.shape, generator=g)
+    x = (x / 1.1) * 2.0 - 1.0
+    return round_16(x)
+
+
+def synth_prompt_ids(length: int, vocab_size: int, seed: int = 4321) -> torch.Tensor:
+    g = _gen(seed, f"prompt{length}")
+    hi = min(vocab_size, 151_643)
+    return torch.randint(0, hi, (length,), generator=g, dtype=torch.long)
