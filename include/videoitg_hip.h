@@ -1,0 +1,108 @@
+/* videoitg_hip.h — C ABI of libvideoitg_hip.so, the gfx950 (MI355X) kernels under the VideoITG frame-selector
+ * forward.
+ *
+ * The reference (NVlabs/VideoITG) has no native/FFI boundary of its own: it is pure Python and every arithmetic
+ * op on this path executes inside third-party CUDA wheels.  Each entry point below therefore
+ * cites the reference call site whose third-party kernel(s) it replaces.  All pointers are DEVICE pointers
+ * (HBM) unless noted, sizes are plain ints, `stream` is a hipStream_t passed as void* (NULL = default stream);
+ * every call is asynchronous on that stream, performs no allocation and no host synchronisation.
+ * Return value: 0 on success, a negative VITG_ERR_* otherwise (nothing is launched on error).
+ *
+ * dtype codes: VITG_BF16 / VITG_F16 select the 16-bit storage type of activations and weights
+ * (MFMA inputs); accumulation, residual stream, norm/softmax statistics are always fp32.
+ */
+#ifndef VIDEOITG_HIP_H
+#define VIDEOITG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITG_BF16 0
+#define VITG_F16 1
+#define VITG_F32 2
+
+#define VITG_ACT_NONE 0
+#define VITG_ACT_GELU_TANH 1 /* SigLIP MLP: gelu_pytorch_tanh */
+#define VITG_ACT_GELU_ERF 2  /* projector: nn.GELU() exact erf (mlp_proj.py:33) */
+
+#define VITG_GEMM_STORE16 0 /* out16[m,n] = act(acc + bias) */
+#define VITG_GEMM_F32 1     /* outf32[m,n] = act(acc + bias) + res[(m % res_mod), n]   (residual stream update) */
+#define VITG_GEMM_SWIGLU 2  /* W rows interleaved [32 gate | 32 up]...: out16[m, n/2] = silu(gate) * up */
+
+#define VITG_ERR_SHAPE (-1)
+#define VITG_ERR_ALIGN (-2)
+#define VITG_ERR_DTYPE (-3)
+#define VITG_ERR_ARG (-4)
+#define VITG_ERR_LAUNCH (-5)
+
+/* Library / device identification.  vitg_version() needs no GPU. */
+int vitg_version(void);
+/* Fills name (<= name_len bytes, NUL terminated) with the gcnArchName of the current device and returns the
+ * compute-unit count, or a negative error when no HIP device is usable. */
+int vitg_device_info(char* name, int name_len);
+
+/* A0[T*G*G, Kpad] (16-bit) = im2col of pixel_values [T,3,R,R] NCHW (pix_dtype VITG_F32/F16/BF16), k ordered
+ * (c,ky,kx) like the conv weight [Dv,3,p,p] flattened, zero for k >= 3*p*p.
+ * Replaces the unfold half of [3P] SiglipVisionEmbeddings.patch_embedding (cuDNN conv2d), reached from
+ * /root/reference/eagle/model/multimodal_encoder/clip_encoder.py:146,151. */
+int vitg_patchify(const void* pix, int pix_dtype, void* out, int T, int R, int patch, int Kpad, int dtype,
+                  void* stream);
+
+/* C = A[M,K] . W[N,K]^T with fused epilogue (mode VITG_GEMM_*).  A, W 16-bit row-major with leading dims
+ * lda/ldw (elements, multiples of 8); K a multiple of 64 (callers zero-pad); bias fp32 [N] or NULL.
+ * Replaces every cuBLAS GEMM of the path: SigLIP patch-embed/q/k/v/out/fc1/fc2 ([3P] modeling_siglip via
+ * clip_encoder.py:146), projector Linear x2 (/root/reference/eagle/model/multimodal_projector/mlp_proj.py:31-35,72),
+ * Qwen2 q/k/v/o/gate/up/down ([3P] modeling_qwen2 via
+ * /root/reference/eagle/model/language_model/grounding_qwen2.py:135), including the bias add, GELU / SiLU*mul
+ * activation and residual add that the reference runs as separate elementwise kernels. */
+int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, int mode,
+              const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
+              void* stream);
+
+/* out[m, 0..ldo) = LayerNorm(x[m, 0..D)) * w + b  (fp32 stats, eps inside rsqrt), columns D..ldo-1 zeroed.
+ * out_dtype VITG_BF16/F16/F32.  Replaces [3P] SigLIP layer_norm1/2 (clip_encoder.py:146). */
+int vitg_layernorm(const float* x, int ldx, const float* w, const float* b, void* out, int ldo, int out_dtype,
+                   long M, int D, float eps, void* stream);
+
+/* out = x * rsqrt(mean(x^2) + eps) * w.  Replaces [3P] Qwen2RMSNorm (grounding_qwen2.py:135). */
+int vitg_rmsnorm(const float* x, int ldx, const float* w, void* out, int ldo, int out_dtype, long M, int D,
+                 float eps, void* stream);
+
+/* In-place rotary embedding (rotate_half layout) on `heads` consecutive heads of width head_dim starting at
+ * qkv[n*ld]; cos/sin fp32 [N, head_dim/2].  Replaces [3P] apply_rotary_pos_emb (grounding_qwen2.py:135). */
+int vitg_rope(void* qkv, int ld, const float* cos_t, const float* sin_t, long N, int heads, int head_dim, int dtype,
+              void* stream);
+
+/* Non-causal softmax(QK^T * scale) V, fp32 softmax, GQA (heads % kv_heads == 0), head_dim 72 or 128.
+ * Strides in elements: *_bs batch, *_rs token row, *_hs head.  variant 0 = production path, 1 = cross-check
+ * path that reads V from LDS with scalar loads instead of ds_read_b64_tr_b16.
+ * Replaces flash-attn 2 fwd: SigLIP (clip_encoder.py:117 forces flash_attention_2) and the bidirectional
+ * Qwen2 attention (grounding_qwen2.py:45-53, is_causal=False). */
+int vitg_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads, int S,
+                   int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs, int v_rs, int o_rs,
+                   int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype, int variant, void* stream);
+
+/* Bilinear G x G -> HW x HW token pool (align_corners=False, no antialias) of fp32 features [T*G*G, ldx] into
+ * 16-bit [T*HW*HW, ldo]; HW == G is a plain cast.  Replaces F.interpolate at mlp_proj.py:57-68. */
+int vitg_bilinear_pool(const float* x, int ldx, void* out, int ldo, int T, int G, int HW, int D, int dtype,
+                       void* stream);
+
+/* out[i, :] = table[ids[i], :] (16-bit table -> fp32 rows).  Replaces embed_tokens at
+ * /root/reference/eagle/model/eagle_archv1.py:310. */
+int vitg_embed_gather(const long long* ids, int n, const void* table, int D, float* out, int ldo, int dtype,
+                      void* stream);
+
+/* logits[t] = mean_j h[t*tokens_per_frame + j, :] . w + b   (fp32).  Replaces grounding_qwen2.py:148-156. */
+int vitg_pool_score(const float* h, int ldh, int frames, int tokens_per_frame, int D, const float* w,
+                    const float* b, float* logits, void* stream);
+
+/* scores[i] = sigmoid(logits[i]); order = argsort(scores) descending, ties by lower i (n <= 8192).
+ * Replaces sigmoid + torch.sort at /root/reference/infer.py:72-74 and lmms_eval/models/videoitg.py:302-303
+ * (whose tie order is unspecified; this one is deterministic). */
+int vitg_rank(const float* logits, int n, float* scores, int* order, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

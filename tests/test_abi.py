@@ -1,0 +1,60 @@
+"""The C-ABI library loads (no GPU needed) and exports exactly what include/videoitg_hip.h declares."""
+import os
+import re
+
+import pytest
+
+from videoitg_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    src = open(os.path.join(ROOT, "include", "videoitg_hip.h")).read()
+    return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+
+def header_symbols():
+    return sorted(set(re.findall(r"\bint\s+(vitg_\w+)\s*\(", _header())))
+
+
+def test_header_declares_entry_points():
+    syms = header_symbols()
+    assert "vitg_gemm" in syms and "vitg_attention" in syms and len(syms) >= 12
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.load()
+    for s in header_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/videoitg_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+    assert lib.vitg_version() >= 100
+
+
+def test_arg_counts_match_header():
+    src = _header()
+    for name, args in _lib.SIGNATURES.items():
+        m = re.search(r"\bint\s+" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), (name, n, len(args))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "videoitg_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.VitgError):
+        _lib.load()

@@ -1,0 +1,91 @@
+"""-m gpu: the whole selector forward through libvideoitg_hip.so vs (a) the committed golden logits produced by the
+reference itself and (b) the oracle on the same seeded inputs.  Tolerance: |sigmoid score delta| <= 1e-3
+(BASELINE.json north_star) and identical Top-K index sets."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520"]
+SCORE_TOL = 1e-3
+
+
+def run_case(golden_dir, name, dtype, variant=0):
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    z = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    cfg = ITGConfig.from_dict(json.loads(str(z["cfg"])))
+    seed = int(z["seed"])
+    T = z["T"].tolist()
+    images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i) for i, t in enumerate(T)]
+    sd, vsd = synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed)
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, dtype, "cuda:0"), attn_variant=variant)
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    got = eng.forward(ids, mask, [im.cuda() for im in images])
+    torch.cuda.synchronize()
+    return z, [g.float().cpu() for g in got], T
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference_golden(golden_dir, name, dtype):
+    z, got, T = run_case(golden_dir, name, dtype)
+    worst = 0.0
+    for b in range(len(T)):
+        ref = torch.from_numpy(z[f"logits{b}"])
+        assert got[b].shape == ref.shape == (T[b], 1)
+        assert torch.isfinite(got[b]).all()
+        d = (torch.sigmoid(got[b]) - torch.sigmoid(ref)).abs().max().item()
+        worst = max(worst, d)
+        print(f"{name}[{b}] {dtype}: max|dscore|={d:.2e} max|dlogit|={(got[b] - ref).abs().max().item():.2e}")
+    assert worst <= SCORE_TOL, worst
+
+
+@pytest.mark.parametrize("name", ["pool_post", "oddgrid"])
+def test_tr_read_and_scalar_v_paths_agree(golden_dir, name):
+    _, a, _ = run_case(golden_dir, name, torch.float16, variant=0)
+    _, b, _ = run_case(golden_dir, name, torch.float16, variant=1)
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() < 1e-4
+
+
+def test_model_object_surface(golden_dir):
+    """load_pretrained_model / model(...).logits / sigmoid-sort-topk as infer.py:15-21,60-79 does it."""
+    from videoitg_amd import synth
+    from videoitg_amd.constants import DEFAULT_IMAGE_TOKEN, IMAGE_TOKEN_INDEX
+    from videoitg_amd.mm_utils import get_model_name_from_path, pad_sequence, tokenizer_image_token
+    from videoitg_amd.model.builder import load_pretrained_model
+    from videoitg_amd import ops
+    from oracle import videoitg_oracle as O
+    path = "synthetic:tiny:0"
+    tok, model, proc, ctx = load_pretrained_model(path, None, get_model_name_from_path(path), device_map="cuda:0")
+    model.half().eval().to(torch.device("cuda:0"))
+    assert ctx == 2048
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, (8, 40, 60, 3), dtype=np.uint8)
+    pix = proc.preprocess(frames, return_tensors="pt")["pixel_values"]
+    assert pix.shape == (8, 3, 56, 56) and pix.dtype == torch.float32 and pix.min() >= -1 and pix.max() <= 1
+    video = pix.half().to("cuda:0")
+    prompt = DEFAULT_IMAGE_TOKEN + "which frame shows the cat?" + "\n"
+    ids = tokenizer_image_token(prompt, tok, IMAGE_TOKEN_INDEX, return_tensors="pt")
+    pad_id = tok.pad_token_id if tok.pad_token_id is not None else tok.eos_token_id
+    ids = pad_sequence(tok, [ids], batch_first=True, padding_value=pad_id).to("cuda:0")
+    with torch.inference_mode():
+        resp = model(ids, attention_mask=ids.ne(pad_id), images=[video])
+        logits = resp.logits[0]
+        assert logits.shape == (8, 1)
+        scores = logits.sigmoid().view(-1)
+    cfg = model.config
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    want = O.forward(cfg, sd, vsd, ids.cpu(), None, [pix.half().float()])[0].view(-1)
+    assert (scores.float().cpu() - torch.sigmoid(want)).abs().max().item() <= SCORE_TOL
+    s2, order = ops.rank(logits.view(-1).float())
+    _, worder = O.rank_frames(want)
+    frame_idx = list(range(0, 80, 10))
+    sel = sorted(frame_idx[i] for i in order[:3].tolist())
+    assert sel == O.topk_selection(want, frame_idx, 3)

@@ -1,0 +1,240 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against a plain PyTorch fp32 CPU reference of the same op
+on the same seeded (16-bit-exact) inputs.  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+EPS16 = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    from videoitg_amd import ops as o
+    name, cus = o.device_info()
+    assert "gfx950" in name, name
+    return o
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 432, 192), (1000, 1152, 640), (257, 3584, 1152), (77, 256, 4352),
+                                   (2048, 1024, 512)])
+def test_gemm_store16_bias_act(ops, dtype, M, N, K):
+    a, w, b = rnd((M, K), 1, dtype=dtype), rnd((N, K), 2, K ** -0.5, dtype=dtype), rnd((N,), 3, 0.1, torch.float32)
+    for act, fn in [(ops.ACT_NONE, lambda x: x), (ops.ACT_GELU_TANH, lambda x: F.gelu(x, approximate="tanh")),
+                    (ops.ACT_GELU_ERF, F.gelu)]:
+        want = fn(a @ w.t() + b)
+        out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+        ops.gemm(a.to(dtype).cuda(), w.to(dtype).cuda(), out, mode=ops.GEMM_STORE16, bias=b.cuda(), act=act)
+        got = out.float().cpu()
+        assert torch.isfinite(got).all()
+        # fp32 accumulate, one 16-bit rounding of the output (+ tiny accumulation-order noise)
+        tol = EPS16[dtype] * want.abs().max().item() + 1e-3
+        assert (got - want).abs().max().item() <= tol, (act, (got - want).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_is_transpose_correct(ops, dtype):
+    """A = I-like probe with an asymmetric W catches swapped row/col writes."""
+    M = N = 128
+    K = 128
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    w = (torch.arange(N * K).reshape(N, K) % 251).float() / 16.0
+    want = a @ w.t()
+    out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm(a.to(dtype).cuda(), w.to(dtype).cuda(), out, mode=ops.GEMM_F32)
+    assert (out.cpu() - a.to(dtype).float() @ w.to(dtype).float().t()).abs().max().item() < 1e-5
+    assert (out.cpu() - want).abs().max().item() < 0.1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,P", [(729 * 2, 1152, 640, 729), (100, 144, 192, 16), (513, 256, 256, 0)])
+def test_gemm_f32_residual(ops, dtype, M, N, K, P):
+    a, w, b = rnd((M, K), 4, dtype=dtype), rnd((N, K), 5, K ** -0.5, dtype=dtype), rnd((N,), 6, 0.1, torch.float32)
+    if P:                                   # patch-embed form: + pos[m % P]
+        res = rnd((P, N), 7, 1.0, torch.float32)
+        want = a @ w.t() + b + res.repeat(M // P + 1, 1)[:M]
+        out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        ops.gemm(a.to(dtype).cuda(), w.to(dtype).cuda(), out, mode=ops.GEMM_F32, bias=b.cuda(), res=res.cuda(), res_mod=P)
+    else:                                   # residual-stream form, in place
+        x = rnd((M, N), 8, 1.0, torch.float32)
+        want = a @ w.t() + b + x
+        out = x.cuda()
+        ops.gemm(a.to(dtype).cuda(), w.to(dtype).cuda(), out, mode=ops.GEMM_F32, bias=b.cuda(), res=out)
+    assert (out.cpu() - want).abs().max().item() < 2e-4 * math.sqrt(K)      # fp32 accumulation-order noise only
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,F_,K", [(200, 592, 256), (1300, 1024, 512)])
+def test_gemm_swiglu(ops, dtype, M, F_, K):
+    from videoitg_amd.ops import pad64
+    fp = pad64(F_)
+    a, g, u = rnd((M, K), 9, dtype=dtype), rnd((F_, K), 10, K ** -0.5, dtype=dtype), rnd((F_, K), 11, K ** -0.5, dtype=dtype)
+    want = F.silu(a @ g.t()) * (a @ u.t())
+    gp = F.pad(g, (0, 0, 0, fp - F_)).reshape(fp // 32, 1, 32, K)
+    up = F.pad(u, (0, 0, 0, fp - F_)).reshape(fp // 32, 1, 32, K)
+    gu = torch.cat([gp, up], 1).reshape(2 * fp, K)
+    out = torch.full((M, fp), float("nan"), dtype=dtype, device="cuda")
+    ops.gemm(a.to(dtype).cuda(), gu.to(dtype).cuda(), out, mode=ops.GEMM_SWIGLU)
+    got = out.float().cpu()
+    assert (got[:, F_:] == 0).all()
+    assert (got[:, :F_] - want).abs().max().item() <= EPS16[dtype] * want.abs().max().item() + 1e-3
+
+
+def ref_attention(q, k, v, scale):
+    rep = q.shape[1] // k.shape[1]
+    k, v = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
+    return torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) @ v
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,H,HKV,S,D", [(3, 2, 2, 729, 72), (2, 16, 16, 16, 72), (1, 3, 3, 25, 72), (1, 4, 2, 523, 128),
+                                         (1, 28, 4, 1300, 128), (2, 2, 1, 64, 128), (1, 2, 2, 4, 72)])
+def test_attention(ops, dtype, variant, B, H, HKV, S, D):
+    q, k, v = rnd((B, H, S, D), 20, dtype=dtype), rnd((B, HKV, S, D), 21, dtype=dtype), rnd((B, HKV, S, D), 22, dtype=dtype)
+    want = ref_attention(q, k, v, D ** -0.5)
+    # packed token-major layout [B, S, (H + 2 HKV) * D] like the fused QKV GEMM output
+    ld = (H + 2 * HKV) * D
+    packed = torch.cat([q.permute(0, 2, 1, 3).reshape(B, S, H * D), k.permute(0, 2, 1, 3).reshape(B, S, HKV * D),
+                        v.permute(0, 2, 1, 3).reshape(B, S, HKV * D)], -1).to(dtype).cuda().contiguous()
+    flat = packed.view(B * S, ld)
+    o = torch.zeros((B * S, H * D), dtype=dtype, device="cuda")
+    ops.attention(flat, flat[:, H * D:], flat[:, (H + HKV) * D:], o, batch=B, heads=H, kv_heads=HKV, seq=S, head_dim=D,
+                  q_strides=(S * ld, ld, D), k_strides=(S * ld, ld, D), v_strides=(S * ld, ld, D), o_strides=(S * H * D, H * D, D),
+                  scale=D ** -0.5, variant=variant)
+    got = o.float().cpu().view(B, S, H, D).permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    # P and the output are rounded to 16 bit: error <~ a few ulp16 of |v|max
+    tol = 6 * EPS16[dtype] * v.abs().max().item()
+    assert (got - want).abs().max().item() <= tol, ((got - want).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_spiked_key_forces_rescale(ops, dtype):
+    """One key far above the rest in a late tile: exercises the online-softmax rescale with a large max jump."""
+    B, H, S, D = 1, 1, 300, 128
+    q, k, v = rnd((B, H, S, D), 30, dtype=dtype), rnd((B, H, S, D), 31, dtype=dtype), rnd((B, H, S, D), 32, dtype=dtype)
+    k[0, 0, 257] = (q[0, 0, 5] * 4).to(dtype).float()
+    want = ref_attention(q, k, v, D ** -0.5)
+    ld = 3 * D
+    flat = torch.cat([q[0, 0], k[0, 0], v[0, 0]], -1).to(dtype).cuda().contiguous()
+    o = torch.zeros((S, D), dtype=dtype, device="cuda")
+    ops.attention(flat, flat[:, D:], flat[:, 2 * D:], o, batch=1, heads=1, kv_heads=1, seq=S, head_dim=D, q_strides=(0, ld, D),
+                  k_strides=(0, ld, D), v_strides=(0, ld, D), o_strides=(0, D, D), scale=D ** -0.5)
+    assert (o.float().cpu() - want[0, 0]).abs().max().item() <= 6 * EPS16[dtype] * v.abs().max().item()
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("M,D", [(1000, 1152), (37, 144), (515, 3584), (64, 256)])
+def test_layernorm_rmsnorm(ops, out_dtype, M, D):
+    from videoitg_amd.ops import pad64
+    x = rnd((M, D), 40, 3.0, torch.float32) + 0.5
+    w, b = rnd((D,), 41, 0.1, torch.float32) + 1.0, rnd((D,), 42, 0.1, torch.float32)
+    ldo = pad64(D)
+    tol = 1e-5 if out_dtype == torch.float32 else EPS16[out_dtype] * 8
+    out = torch.full((M, ldo), float("nan"), dtype=out_dtype, device="cuda")
+    ops.layernorm(x.cuda(), w.cuda(), b.cuda(), out, D, 1e-6)
+    got = out.float().cpu()
+    assert (got[:, D:] == 0).all()
+    assert (got[:, :D] - F.layer_norm(x, (D,), w, b, 1e-6)).abs().max().item() <= tol * 6
+    out.fill_(float("nan"))
+    ops.rmsnorm(x.cuda(), w.cuda(), out, D, 1e-6)
+    got = out.float().cpu()
+    want = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert (got[:, D:] == 0).all()
+    assert (got[:, :D] - want).abs().max().item() <= tol * 6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rope(ops, dtype):
+    N, nq, nkv, hd = 333, 4, 2, 128
+    ld = (nq + 2 * nkv) * hd
+    x = rnd((N, ld), 50, dtype=dtype)
+    inv = 1.0 / (1e6 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.outer(torch.arange(N, dtype=torch.float32), inv)
+    cos, sin = fr.cos(), fr.sin()
+    want = x.clone()
+    heads = x[:, :(nq + nkv) * hd].view(N, nq + nkv, hd)
+    c, s = torch.cat([cos, cos], -1)[:, None], torch.cat([sin, sin], -1)[:, None]
+    rot = torch.cat([-heads[..., hd // 2:], heads[..., :hd // 2]], -1)
+    want[:, :(nq + nkv) * hd] = (heads * c + rot * s).reshape(N, -1)
+    t = x.to(dtype).cuda()
+    ops.rope_(t, cos.cuda(), sin.cuda(), nq + nkv, hd)
+    got = t.float().cpu()
+    assert torch.equal(got[:, (nq + nkv) * hd:], x[:, (nq + nkv) * hd:])           # v untouched
+    assert (got - want).abs().max().item() <= EPS16[dtype] * want.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("pix_dtype", [torch.float32, torch.float16])
+def test_patchify_matches_conv(ops, pix_dtype):
+    T, R, ps, Dv = 3, 56, 14, 32
+    pix = rnd((T, 3, R, R), 60, dtype=torch.bfloat16)
+    w = rnd((Dv, 3, ps, ps), 61, 0.05, torch.bfloat16)
+    want = F.conv2d(pix, w, stride=ps).flatten(2).transpose(1, 2).reshape(-1, Dv)
+    a0 = ops.patchify(pix.to(pix_dtype).cuda(), ps, 640, torch.bfloat16).float().cpu()
+    assert (a0[:, 588:] == 0).all()
+    got = a0[:, :588] @ w.reshape(Dv, -1).t()
+    assert (got - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("T,G,HW,D", [(4, 27, 5, 1152), (3, 4, 3, 144), (2, 5, 3, 144), (5, 2, 1, 144), (2, 4, 4, 144), (1, 32, 5, 64)])
+def test_bilinear_pool(ops, T, G, HW, D):
+    from videoitg_amd.ops import pad64
+    x = rnd((T * G * G, D), 70, 1.0, torch.float32)
+    want = F.interpolate(x.view(T, G, G, D).permute(0, 3, 1, 2), size=(HW, HW), mode="bilinear", align_corners=False)
+    want = want.permute(0, 2, 3, 1).reshape(T * HW * HW, D) if HW < G else x
+    out = torch.full((T * HW * HW, pad64(D)), float("nan"), dtype=torch.float16, device="cuda")
+    ops.bilinear_pool(x.cuda(), out, T, G, HW, D)
+    got = out.float().cpu()
+    assert (got[:, D:] == 0).all()
+    assert (got[:, :D] - want).abs().max().item() <= EPS16[torch.float16] * want.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_gather_and_pool_score(ops, dtype):
+    V, D, T, tok = 320, 256, 7, 9
+    table = rnd((V, D), 80, dtype=dtype)
+    ids = torch.tensor([5, 0, 319, 7, 7], dtype=torch.long)
+    out = torch.zeros((5, D), dtype=torch.float32, device="cuda")
+    ops.embed_gather(ids.cuda(), table.to(dtype).cuda(), out)
+    assert torch.equal(out.cpu(), table[ids])
+    h = rnd((3 + T * tok, D), 81, 1.0, torch.float32)
+    w, b = rnd((D,), 82, 0.1, torch.float32), torch.tensor([0.25])
+    want = h[3:].view(T, tok, D).mean(1) @ w + b
+    lg = torch.empty(T, dtype=torch.float32, device="cuda")
+    ops.pool_score(h.cuda()[3:], T, tok, D, w.cuda(), b.cuda(), lg)
+    assert (lg.cpu() - want).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 512, 513, 1024, 3000])
+def test_rank_stable_descending(ops, n):
+    g = torch.Generator().manual_seed(n)
+    lg = torch.randn(n, generator=g) * 3
+    if n > 4:
+        lg[n // 2] = lg[1]                    # exact tie
+        lg[n - 1] = lg[1]
+        lg[0] = 30.0                          # sigmoid saturates to 1.0 in fp32: ties with lg[3]
+        lg[3] = 40.0
+    scores, order = ops.rank(lg.cuda())
+    s = torch.sigmoid(lg)
+    want = torch.sort(s, descending=True, stable=True).indices
+    got_scores = scores.cpu()
+    assert (got_scores - s).abs().max().item() < 1e-6
+    # the kernel ranks its own fp32 sigmoid; recompute the stable order from the scores it produced
+    assert torch.equal(order.cpu().long(), torch.sort(got_scores, descending=True, stable=True).indices)
+    if torch.equal(got_scores, s):
+        assert torch.equal(order.cpu().long(), want)
+EOF
+echo done

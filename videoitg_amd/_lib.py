@@ -1,0 +1,69 @@
+"""ctypes binding of libvideoitg_hip.so (the C ABI declared in include/videoitg_hip.h).
+
+The product path has NO fallback: if the library is missing or an entry point fails, this raises.
+PyTorch is used only as plumbing around it (device memory, streams).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvideoitg_hip.so")
+
+BF16, F16, F32 = 0, 1, 2
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
+GEMM_STORE16, GEMM_F32, GEMM_SWIGLU = 0, 1, 2
+
+_ERR = {-1: "VITG_ERR_SHAPE", -2: "VITG_ERR_ALIGN", -3: "VITG_ERR_DTYPE", -4: "VITG_ERR_ARG", -5: "VITG_ERR_LAUNCH"}
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# name -> argtypes; must list every symbol include/videoitg_hip.h declares (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "vitg_version": [],
+    "vitg_device_info": [C.c_char_p, _i],
+    "vitg_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "vitg_gemm": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
+    "vitg_layernorm": [_p, _i, _p, _p, _p, _i, _i, _l, _i, _f, _p],
+    "vitg_rmsnorm": [_p, _i, _p, _p, _i, _i, _l, _i, _f, _p],
+    "vitg_rope": [_p, _i, _p, _p, _l, _i, _i, _i, _p],
+    "vitg_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p],
+    "vitg_bilinear_pool": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "vitg_embed_gather": [_p, _i, _p, _i, _p, _i, _i, _p],
+    "vitg_pool_score": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
+    "vitg_rank": [_p, _i, _p, _p, _p],
+}
+
+_lib = None
+
+
+class VitgError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the library (no GPU needed for this) and set prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitgError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the selector forward.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _i
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise VitgError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

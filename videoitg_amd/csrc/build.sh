@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libvideoitg_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../libvideoitg_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+OBJ="$HERE/build"
+mkdir -p "$OBJ"
+pids=()
+for f in device gemm attention elementwise; do
+  src="$HERE/$f.hip"; obj="$OBJ/$f.o"
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/../../include/videoitg_hip.h" -nt "$obj" ]; then
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$src" -o "$obj" "$@" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/device.o "$OBJ"/gemm.o "$OBJ"/attention.o "$OBJ"/elementwise.o
+echo "built $OUT"

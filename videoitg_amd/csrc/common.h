@@ -1,0 +1,79 @@
+// Shared device helpers for the VideoITG gfx950 (CDNA4) kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vitg {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+enum : int { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
+
+// ---- 16-bit element traits -------------------------------------------------------------------
+template <typename T> struct T16;
+template <> struct T16<bf16_t> {
+    typedef bf16x8 vec8;
+    typedef bf16x4 vec4;
+    static __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+    static __device__ __forceinline__ bf16_t from_f32(float f) { return (bf16_t)f; }   // RNE
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct T16<f16_t> {
+    typedef f16x8 vec8;
+    typedef f16x4 vec4;
+    static __device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
+    static __device__ __forceinline__ f16_t from_f32(float f) { return (f16_t)f; }
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename V, typename U> __device__ __forceinline__ V bitcast(const U& u) {
+    static_assert(sizeof(V) == sizeof(U), "bitcast size");
+    return __builtin_bit_cast(V, u);
+}
+
+// ---- wave / block reductions -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- activations -------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2u)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace vitg

@@ -1,0 +1,372 @@
+// HBM-bound kernels of the selector forward: patchify (im2col), LayerNorm, RMSNorm, RoPE, bilinear token
+// pool, embedding gather, per-frame mean-pool + score head, sigmoid + stable descending rank.
+// All loads/stores are 8-16 B per lane; reductions are wave-level (64 lanes) with fp32 statistics.
+#include "common.h"
+#include "../../include/videoitg_hip.h"
+
+namespace vitg {
+
+template <typename T> __device__ __forceinline__ float ld_as_f32(const void* p, long i);
+template <> __device__ __forceinline__ float ld_as_f32<float>(const void* p, long i) { return ((const float*)p)[i]; }
+template <> __device__ __forceinline__ float ld_as_f32<bf16_t>(const void* p, long i) { return (float)((const bf16_t*)p)[i]; }
+template <> __device__ __forceinline__ float ld_as_f32<f16_t>(const void* p, long i) { return (float)((const f16_t*)p)[i]; }
+
+// ------------------------------------------------------------------------------------------------
+// patchify: pixel_values [T,3,R,R] (NCHW) -> A[T*G*G, Kpad], k = c*ps*ps + ky*ps + kx (the order of the
+// conv weight [Dv,3,ps,ps] flattened), zero-filled k >= 3*ps*ps.  One wave per output row.
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void patchify_kernel(const void* __restrict__ pix, TO* __restrict__ out, int T, int R, int ps, int G,
+                                int Kpad, long rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int P = G * G;
+    const int t = (int)(row / P), pi = (int)(row % P);
+    const int py = pi / G, px = pi % G;
+    const int KK = 3 * ps * ps;
+    const long img = (long)t * 3 * R * R;
+    for (int k = lane; k < Kpad; k += 64) {
+        float v = 0.f;
+        if (k < KK) {
+            const int c = k / (ps * ps), rem = k % (ps * ps);
+            const int ky = rem / ps, kx = rem % ps;
+            v = ld_as_f32<TI>(pix, img + ((long)c * R + (py * ps + ky)) * R + (px * ps + kx));
+        }
+        out[row * Kpad + k] = T16<TO>::from_f32(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm over fp32 rows -> 16-bit (or fp32) rows with row stride ldo >= D; columns D..ldo-1
+// are written as zero so the result can feed a GEMM whose K is padded to a multiple of 64.
+// One wave per row, row cached in registers (D <= 64*4*NV).
+// ------------------------------------------------------------------------------------------------
+template <typename TO, bool RMS, int NV>
+__global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bia,
+                            void* __restrict__ out, int ldo, int out_f32, long M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * ldx;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) v[i] = *(const f32x4*)(xr + c);
+        else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s += RMS ? (v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3])
+                 : (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s / D + eps);
+    } else {
+        mean = s / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / D + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c >= ldo) continue;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            const f32x4 ww = *(const f32x4*)(w + c);
+            r = (v[i] - mean) * rstd * ww;
+            if (!RMS) r += *(const f32x4*)(bia + c);
+        }
+        if (out_f32) *(f32x4*)((float*)out + row * ldo + c) = r;
+        else {
+            typename T16<TO>::vec4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = T16<TO>::from_f32(r[e]);
+            *(typename T16<TO>::vec4*)((TO*)out + row * ldo + c) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE (rotate_half layout) in place on the q and k heads of a packed qkv row:
+//   x[i] <- x[i] cos_i - x[i+hd/2] sin_i ;  x[i+hd/2] <- x[i+hd/2] cos_i + x[i] sin_i
+// cos/sin tables fp32 [N, hd/2] (built on the host in fp32 like Qwen2RotaryEmbedding).
+// One thread handles 4 consecutive i of one (token, head).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rope_kernel(T* __restrict__ qkv, int ld, const float* __restrict__ cs, const float* __restrict__ sn,
+                            long N, int heads, int hd) {
+    const int half = hd >> 1, per = half >> 2;           // threads per head
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = N * heads * per;
+    if (gid >= total) return;
+    const int j = (int)(gid % per);
+    const int hh = (int)((gid / per) % heads);
+    const long n = gid / ((long)per * heads);
+    T* p = qkv + n * ld + (long)hh * hd + j * 4;
+    typedef typename T16<T>::vec4 v4;
+    v4 a = *(v4*)p, b = *(v4*)(p + half);
+    const f32x4 c = *(const f32x4*)(cs + n * half + j * 4), s = *(const f32x4*)(sn + n * half + j * 4);
+    v4 ra, rb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x1 = T16<T>::to_f32(a[e]), x2 = T16<T>::to_f32(b[e]);
+        ra[e] = T16<T>::from_f32(x1 * c[e] - x2 * s[e]);
+        rb[e] = T16<T>::from_f32(x2 * c[e] + x1 * s[e]);
+    }
+    *(v4*)p = ra;
+    *(v4*)(p + half) = rb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear token pool G x G -> HW x HW (F.interpolate bilinear, align_corners=False, no antialias) over
+// fp32 tower features [T, G*G, D] -> 16-bit [T*HW*HW, ldo] (pad columns zeroed).
+// src = (dst + 0.5) * G/HW - 0.5 clamped at 0; i0 = floor(src), i1 = min(i0+1, G-1), w1 = src - i0.
+// ------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out, int ldo, int T, int G, int HW,
+                            int D) {
+    const long orow = blockIdx.x;                 // t*HW*HW + oy*HW + ox
+    const int t = (int)(orow / (HW * HW)), o = (int)(orow % (HW * HW));
+    const int oy = o / HW, ox = o % HW;
+    const float sc = (float)G / (float)HW;
+    float sy = (oy + 0.5f) * sc - 0.5f, sx = (ox + 0.5f) * sc - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, G - 1), x1 = min(x0 + 1, G - 1);
+    const float wy1 = sy - y0, wx1 = sx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+    const float* base = x + (long)t * G * G * ldx;
+    const float* p00 = base + (long)(y0 * G + x0) * ldx;
+    const float* p01 = base + (long)(y0 * G + x1) * ldx;
+    const float* p10 = base + (long)(y1 * G + x0) * ldx;
+    const float* p11 = base + (long)(y1 * G + x1) * ldx;
+    for (int c = threadIdx.x * 4; c < ldo; c += blockDim.x * 4) {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            // same association as ATen's upsample_bilinear2d: w_y0*(w_x0*a + w_x1*b) + w_y1*(w_x0*c + w_x1*d)
+            r = wy0 * (wx0 * *(const f32x4*)(p00 + c) + wx1 * *(const f32x4*)(p01 + c)) +
+                wy1 * (wx0 * *(const f32x4*)(p10 + c) + wx1 * *(const f32x4*)(p11 + c));
+        }
+        typename T16<TO>::vec4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = T16<TO>::from_f32(r[e]);
+        *(typename T16<TO>::vec4*)(out + orow * ldo + c) = ov;
+    }
+}
+
+// fp32 rows -> 16-bit rows (no pooling branch HW == G), pad columns zeroed
+template <typename TO>
+__global__ void cast_rows_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out, int ldo, int D) {
+    const long row = blockIdx.x;
+    for (int c = threadIdx.x * 4; c < ldo; c += blockDim.x * 4) {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (c < D) r = *(const f32x4*)(x + row * ldx + c);
+        typename T16<TO>::vec4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = T16<TO>::from_f32(r[e]);
+        *(typename T16<TO>::vec4*)(out + row * ldo + c) = ov;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding gather: ids[n] -> out_f32[row0 + n, :] = table[ids[n], :]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_kernel(const long long* __restrict__ ids, const T* __restrict__ table, int D,
+                             float* __restrict__ out, int ldo) {
+    const long id = ids[blockIdx.x];
+    const T* src = table + id * D;
+    float* dst = out + (long)blockIdx.x * ldo;
+    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+        const typename T16<T>::vec4 v = *(const typename T16<T>::vec4*)(src + c);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = T16<T>::to_f32(v[e]);
+        *(f32x4*)(dst + c) = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// score head: logits[t] = mean_{j<tok}(h[row0 + t*tok + j, :]) . w + b      (h fp32, w fp32)
+// one block (256 threads) per frame
+// ------------------------------------------------------------------------------------------------
+__global__ void pool_score_kernel(const float* __restrict__ h, int ldh, int tok, int D, const float* __restrict__ w,
+                                  const float* __restrict__ b, float* __restrict__ logits) {
+    __shared__ float part[4];
+    const int t = blockIdx.x;
+    const float* base = h + (long)t * tok * ldh;
+    float acc = 0.f;
+    for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < tok; ++j) s += *(const f32x4*)(base + (long)j * ldh + c);
+        const f32x4 ww = *(const f32x4*)(w + c);
+        acc += s[0] * ww[0] + s[1] * ww[1] + s[2] * ww[2] + s[3] * ww[3];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) logits[t] = (part[0] + part[1] + part[2] + part[3]) / tok + b[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// rank: scores = sigmoid(logits); order = stable argsort descending (ties: lower position first).
+// Single block bitonic sort of 64-bit keys (~orderable(score) << 32 | index) in LDS; n <= 8192.
+// ------------------------------------------------------------------------------------------------
+__global__ void rank_kernel(const float* __restrict__ logits, int n, int npow2, float* __restrict__ scores,
+                            int* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = (unsigned long long*)smem;
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        unsigned long long k = ~0ull;                       // padding sorts last
+        if (i < n) {
+            const float s = 1.0f / (1.0f + expf(-logits[i]));
+            scores[i] = s;
+            unsigned u = __float_as_uint(s);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable
+            u = ~u;                                            // descending
+            k = ((unsigned long long)u << 32) | (unsigned)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int sz = 2; sz <= npow2; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+                const int j = i ^ st;
+                if (j > i) {
+                    const unsigned long long a = keys[i], b = keys[j];
+                    const bool up = (i & sz) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = (int)(keys[i] & 0xffffffffu);
+}
+
+}  // namespace vitg
+
+using namespace vitg;
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH)
+
+extern "C" int vitg_patchify(const void* pix, int pix_dtype, void* out, int T, int R, int patch, int Kpad, int dtype,
+                             void* stream) {
+    if (T <= 0) return 0;
+    if (R % patch) return VITG_ERR_SHAPE;
+    if (Kpad < 3 * patch * patch) return VITG_ERR_SHAPE;
+    const int G = R / patch;
+    const long rows = (long)T * G * G;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 blk(256), grid((unsigned)((rows + 3) / 4));
+#define PF(TI, TO) hipLaunchKernelGGL((patchify_kernel<TI, TO>), grid, blk, 0, s, pix, (TO*)out, T, R, patch, G, Kpad, rows)
+    if (dtype == DT_BF16) {
+        if (pix_dtype == DT_F32) PF(float, bf16_t); else if (pix_dtype == DT_BF16) PF(bf16_t, bf16_t); else if (pix_dtype == DT_F16) PF(f16_t, bf16_t); else return VITG_ERR_DTYPE;
+    } else if (dtype == DT_F16) {
+        if (pix_dtype == DT_F32) PF(float, f16_t); else if (pix_dtype == DT_BF16) PF(bf16_t, f16_t); else if (pix_dtype == DT_F16) PF(f16_t, f16_t); else return VITG_ERR_DTYPE;
+    } else return VITG_ERR_DTYPE;
+#undef PF
+    return CHECK_LAUNCH();
+}
+
+template <bool RMS>
+static int norm_dispatch(const float* x, int ldx, const float* w, const float* b, void* out, int ldo, int out_dtype,
+                         long M, int D, float eps, hipStream_t s) {
+    if (M <= 0) return 0;
+    if (D % 4 || ldo % 4 || ldx % 4) return VITG_ERR_ALIGN;
+    if (ldo < D) return VITG_ERR_SHAPE;
+    const int need = ceil_div(ldo, 256);
+    dim3 blk(256), grid((unsigned)((M + 3) / 4));
+    const int of32 = out_dtype == DT_F32;
+#define NK(TO, NV) hipLaunchKernelGGL((norm_kernel<TO, RMS, NV>), grid, blk, 0, s, x, ldx, w, b, out, ldo, of32, M, D, eps)
+#define NKS(TO) do { if (need <= 1) NK(TO, 1); else if (need <= 2) NK(TO, 2); else if (need <= 5) NK(TO, 5); else if (need <= 8) NK(TO, 8); else if (need <= 16) NK(TO, 16); else return VITG_ERR_SHAPE; } while (0)
+    if (out_dtype == DT_F16) NKS(f16_t); else if (out_dtype == DT_BF16 || out_dtype == DT_F32) NKS(bf16_t); else return VITG_ERR_DTYPE;
+#undef NKS
+#undef NK
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vitg_layernorm(const float* x, int ldx, const float* w, const float* b, void* out, int ldo, int out_dtype,
+                              long M, int D, float eps, void* stream) {
+    return norm_dispatch<false>(x, ldx, w, b, out, ldo, out_dtype, M, D, eps, (hipStream_t)stream);
+}
+
+extern "C" int vitg_rmsnorm(const float* x, int ldx, const float* w, void* out, int ldo, int out_dtype, long M, int D,
+                            float eps, void* stream) {
+    return norm_dispatch<true>(x, ldx, w, nullptr, out, ldo, out_dtype, M, D, eps, (hipStream_t)stream);
+}
+
+extern "C" int vitg_rope(void* qkv, int ld, const float* cos_t, const float* sin_t, long N, int heads, int head_dim,
+                         int dtype, void* stream) {
+    if (N <= 0 || heads <= 0) return 0;
+    if (head_dim % 8 || ld % 4) return VITG_ERR_ALIGN;
+    const long total = N * heads * (head_dim / 8);
+    dim3 blk(256), grid((unsigned)((total + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DT_BF16) hipLaunchKernelGGL((rope_kernel<bf16_t>), grid, blk, 0, s, (bf16_t*)qkv, ld, cos_t, sin_t, N, heads, head_dim);
+    else if (dtype == DT_F16) hipLaunchKernelGGL((rope_kernel<f16_t>), grid, blk, 0, s, (f16_t*)qkv, ld, cos_t, sin_t, N, heads, head_dim);
+    else return VITG_ERR_DTYPE;
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vitg_bilinear_pool(const float* x, int ldx, void* out, int ldo, int T, int G, int HW, int D, int dtype,
+                                  void* stream) {
+    if (T <= 0) return 0;
+    if (D % 4 || ldo % 4 || ldx % 4 || ldo < D) return VITG_ERR_ALIGN;
+    if (HW <= 0 || HW > G) return VITG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 blk(256);
+    if (HW == G) {
+        dim3 grid((unsigned)((long)T * G * G));
+        if (dtype == DT_BF16) hipLaunchKernelGGL((cast_rows_kernel<bf16_t>), grid, blk, 0, s, x, ldx, (bf16_t*)out, ldo, D);
+        else if (dtype == DT_F16) hipLaunchKernelGGL((cast_rows_kernel<f16_t>), grid, blk, 0, s, x, ldx, (f16_t*)out, ldo, D);
+        else return VITG_ERR_DTYPE;
+    } else {
+        dim3 grid((unsigned)((long)T * HW * HW));
+        if (dtype == DT_BF16) hipLaunchKernelGGL((pool_kernel<bf16_t>), grid, blk, 0, s, x, ldx, (bf16_t*)out, ldo, T, G, HW, D);
+        else if (dtype == DT_F16) hipLaunchKernelGGL((pool_kernel<f16_t>), grid, blk, 0, s, x, ldx, (f16_t*)out, ldo, T, G, HW, D);
+        else return VITG_ERR_DTYPE;
+    }
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vitg_embed_gather(const long long* ids, int n, const void* table, int D, float* out, int ldo, int dtype,
+                                 void* stream) {
+    if (n <= 0) return 0;
+    if (D % 4 || ldo % 4) return VITG_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DT_BF16) hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(n), dim3(256), 0, s, ids, (const bf16_t*)table, D, out, ldo);
+    else if (dtype == DT_F16) hipLaunchKernelGGL((embed_kernel<f16_t>), dim3(n), dim3(256), 0, s, ids, (const f16_t*)table, D, out, ldo);
+    else return VITG_ERR_DTYPE;
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vitg_pool_score(const float* h, int ldh, int frames, int tokens_per_frame, int D, const float* w,
+                               const float* b, float* logits, void* stream) {
+    if (frames <= 0) return 0;
+    if (D % 4 || ldh % 4 || tokens_per_frame <= 0) return VITG_ERR_ALIGN;
+    hipLaunchKernelGGL(pool_score_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, h, ldh, tokens_per_frame, D, w, b, logits);
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vitg_rank(const float* logits, int n, float* scores, int* order, void* stream) {
+    if (n <= 0) return 0;
+    if (n > 8192) return VITG_ERR_SHAPE;
+    int p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    static bool done = false;
+    if (!done) { hipFuncSetAttribute((const void*)rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8); done = true; }
+    hipLaunchKernelGGL(rank_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, (hipStream_t)stream, logits, n, p2, scores, order);
+    return CHECK_LAUNCH();
+}

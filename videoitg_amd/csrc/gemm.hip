@@ -1,0 +1,238 @@
+// C[M,N] = A[M,K] * W[N,K]^T with fused epilogues, 16-bit inputs, fp32 MFMA accumulation (gfx950).
+//
+// Both operands are K-contiguous (activations row-major, nn.Linear weights [out,in]), which is the
+// natural MFMA layout: no transposes anywhere.  Tile 128x128x64, 4 waves (2x2), each wave a 64x64
+// sub-tile as 2x2 v_mfma_f32_32x32x16.  The MFMA "A" operand is the WEIGHT tile and the "B" operand the
+// ACTIVATION tile, so the accumulator of a lane holds 4 consecutive output features of one token row:
+// epilogue loads/stores are 8-16 B per lane and bias / residual reads vectorise.
+//
+// LDS: [128 rows][8 x 16-B chunks] per operand, chunk index XOR ((row>>1)&7): conflict-free for the
+// ds_read_b128 lane groups (MI355X_MICROARCH.md §LDS).  Double-buffered, one barrier per K-tile; global
+// loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them.
+//
+// Work-group order: XCD-contiguous remap (block b runs on XCD b%8) + 8-row-tile groups, so the ~64
+// concurrently resident blocks of an XCD form an 8x8 super-tile that shares operand panels in its L2.
+#include "common.h"
+#include "../../include/videoitg_hip.h"
+
+namespace vitg {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GEMM_THREADS = 256;
+
+struct GemmArgs {
+    const void* A; int lda;
+    const void* W; int ldw;
+    int M, N, K;
+    const float* bias;        // [N] fp32 or null
+    int act;                  // VITG_ACT_*
+    void* out; int ldo;       // mode STORE16/SWIGLU: T16*, mode F32: float*
+    const float* res; int ldr; int res_mod;   // mode F32: out = acc + bias + res[(m % res_mod), n] (res may be null)
+    int tiles_m, tiles_n;
+};
+
+enum { MODE_STORE16 = 0, MODE_F32 = 1, MODE_SWIGLU = 2 };
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {        // bytes within one operand tile
+    return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm128_kernel(GemmArgs g) {
+    typedef typename T16<T>::vec8 vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [buf][A|W][128*128B]
+    constexpr int TILE_BYTES = BM * BK * 2;                        // 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block -> tile (XCD-contiguous, grouped) ------------------------------------------
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GM = 8;
+    const int per_group = GM * g.tiles_n;
+    const int grp = bid / per_group;
+    const int first_m = grp * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    const int in_g = bid - grp * per_group;
+    const int tm = first_m + in_g % gsz;
+    const int tn = in_g / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging assignment: 1024 chunks per operand tile, 4 per thread ---------------------
+    const char* Ab = (const char*)g.A;
+    const char* Wb = (const char*)g.W;
+    const char* a_src[4];
+    const char* w_src[4];
+    int st_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * GEMM_THREADS;
+        const int row = c >> 3, kc = c & 7;
+        const int am = min(m0 + row, g.M - 1), wn_ = min(n0 + row, g.N - 1);
+        a_src[i] = Ab + ((size_t)am * g.lda + kc * 8) * 2;
+        w_src[i] = Wb + ((size_t)wn_ * g.ldw + kc * 8) * 2;
+        st_off[i] = lds_off(row, kc);
+    }
+
+    f32x16 acc[2][2];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[4], rw[4];
+    const int nk = g.K / BK;
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *(const u32x4*)(a_src[i] + (size_t)kt * (BK * 2));
+            rw[i] = *(const u32x4*)(w_src[i] + (size_t)kt * (BK * 2));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* base = smem + buf * (2 * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(u32x4*)(base + st_off[i]) = ra[i];
+            *(u32x4*)(base + TILE_BYTES + st_off[i]) = rw[i];
+        }
+    };
+
+    const int frow = lane & 31, fh = lane >> 5;
+    auto compute = [&](int buf) {
+        const char* As = smem + buf * (2 * TILE_BYTES);
+        const char* Ws = As + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            vec8 fa[2], fw[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = *(const vec8*)(As + lds_off(wm * 64 + t * 32 + frow, ks * 2 + fh));
+                fw[t] = *(const vec8*)(Ws + lds_off(wn * 64 + t * 32 + frow, ks * 2 + fh));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = T16<T>::mfma32(fw[nt], fa[mt], acc[nt][mt]);
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kt + 1);
+        compute(kt & 1);
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3] for 4 column groups per 32x32 tile ----------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wm * 64 + mt * 32 + frow;
+        if (m >= g.M) continue;
+        if constexpr (MODE == MODE_SWIGLU) {
+            // weight rows interleaved [32 gate | 32 up]: tile nt=0 gate, nt=1 up, same lane/register
+            T* out = (T*)g.out;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int nn = n0 + wn * 64 + q4 * 8 + fh * 4;       // column in the interleaved N space (gate part)
+                const int no = (n0 + wn * 64) / 2 + q4 * 8 + fh * 4;  // output column
+                if (nn >= g.N) continue;
+                typename T16<T>::vec4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gt = acc[0][mt][q4 * 4 + e], up = acc[1][mt][q4 * 4 + e];
+                    v[e] = T16<T>::from_f32(silu_f(gt) * up);
+                }
+                *(typename T16<T>::vec4*)(out + (size_t)m * g.ldo + no) = v;
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int n = n0 + wn * 64 + nt * 32 + q4 * 8 + fh * 4;
+                    if (n >= g.N) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][q4 * 4 + e];
+                    if (g.bias) v += *(const f32x4*)(g.bias + n);
+                    if (g.act == VITG_ACT_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                    } else if (g.act == VITG_ACT_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                    }
+                    if constexpr (MODE == MODE_F32) {
+                        if (g.res) {
+                            const int rm = g.res_mod > 0 ? m % g.res_mod : m;
+                            v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+                        }
+                        *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
+                    } else {
+                        typename T16<T>::vec4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
+                        *(typename T16<T>::vec4*)((T*)g.out + (size_t)m * g.ldo + n) = o;
+                    }
+                }
+        }
+    }
+}
+
+template <typename T>
+static int launch(const GemmArgs& g, int mode, hipStream_t s) {
+    const int grid = g.tiles_m * g.tiles_n;
+    const size_t lds = 2 * 2 * BM * BK * 2;   // 64 KiB
+    if (mode == MODE_STORE16) hipLaunchKernelGGL((gemm128_kernel<T, MODE_STORE16>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+    else if (mode == MODE_F32) hipLaunchKernelGGL((gemm128_kernel<T, MODE_F32>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+    else hipLaunchKernelGGL((gemm128_kernel<T, MODE_SWIGLU>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+    return (int)hipGetLastError();
+}
+
+}  // namespace vitg
+
+using namespace vitg;
+
+static int g_attr_done = 0;
+static void set_attrs() {
+    if (g_attr_done) return;
+    g_attr_done = 1;
+    const int lds = 2 * 2 * BM * BK * 2;
+#define SETA(T, Mo) hipFuncSetAttribute((const void*)gemm128_kernel<T, Mo>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+    SETA(bf16_t, MODE_STORE16); SETA(bf16_t, MODE_F32); SETA(bf16_t, MODE_SWIGLU);
+    SETA(f16_t, MODE_STORE16); SETA(f16_t, MODE_F32); SETA(f16_t, MODE_SWIGLU);
+#undef SETA
+}
+
+extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype,
+                         int mode, const float* bias, int act, void* out, int ldo,
+                         const float* res, int ldr, int res_mod, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || K % BK != 0) return VITG_ERR_SHAPE;
+    if ((lda % 8) || (ldw % 8)) return VITG_ERR_ALIGN;
+    if (mode < 0 || mode > 2) return VITG_ERR_ARG;
+    if (mode == VITG_GEMM_SWIGLU && (N % 64 != 0)) return VITG_ERR_SHAPE;
+    if (mode != VITG_GEMM_SWIGLU && (N % 4 != 0 || ldo % 4 != 0)) return VITG_ERR_ALIGN;
+    if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
+    set_attrs();
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
+    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN);
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
+    return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+}

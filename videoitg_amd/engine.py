@@ -1,0 +1,330 @@
+"""The selector forward (rows A7-A12 of SURVEY.md §8a) as a sequence of calls into libvideoitg_hip.so.
+
+``PackedWeights`` re-lays a checkpoint (HF key names) once at load time into the shapes the
+kernels want (fused QKV, 32/32-interleaved gate/up for the fused SwiGLU epilogue, every GEMM K dimension
+zero-padded to a multiple of 64, fp32 biases / norm weights / position table).  ``SelectorEngine.forward``
+then runs ViT -> pool -> projector -> splice -> bidirectional Qwen2 -> score head with an fp32 residual
+stream and 16-bit MFMA inputs.  torch is used for allocation and stream plumbing only.
+
+Reference call sites mirrored: clip_encoder.py:123-154 (tower, hidden_states[-2]), mlp_proj.py:39-75
+(projector), eagle_archv1.py:211-400 (splice), grounding_qwen2.py:45-66,135-156 (decoder + head).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F  # weight re-layout only (pad / interpolate of the position table at load time)
+
+from . import ops
+from .config import ITGConfig
+from .constants import IMAGE_TOKEN_INDEX
+from .ops import pad64
+
+SD = Dict[str, torch.Tensor]
+
+
+def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    r, c = w.shape
+    if r == rows and c == cols:
+        return w
+    return F.pad(w, (0, cols - c, 0, rows - r))
+
+
+def _pad1(b: torch.Tensor, n: int) -> torch.Tensor:
+    return b if b.shape[0] == n else F.pad(b, (0, n - b.shape[0]))
+
+
+@dataclass
+class VitLayerW:
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor
+    qkv_w: torch.Tensor; qkv_b: torch.Tensor
+    out_w: torch.Tensor; out_b: torch.Tensor
+    ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    fc1_w: torch.Tensor; fc1_b: torch.Tensor
+    fc2_w: torch.Tensor; fc2_b: torch.Tensor
+
+
+@dataclass
+class LlmLayerW:
+    in_ln: torch.Tensor
+    qkv_w: torch.Tensor; qkv_b: torch.Tensor
+    o_w: torch.Tensor
+    post_ln: torch.Tensor
+    gu_w: torch.Tensor
+    down_w: torch.Tensor
+
+
+@dataclass
+class PackedWeights:
+    cfg: ITGConfig
+    dtype: torch.dtype
+    device: torch.device
+    patch_w: torch.Tensor = None; patch_b: torch.Tensor = None
+    pos_native: torch.Tensor = None                # fp32 [P0, Dv]
+    pos_cache: Dict[int, torch.Tensor] = field(default_factory=dict)
+    vit: List[VitLayerW] = field(default_factory=list)
+    proj0_w: torch.Tensor = None; proj0_b: torch.Tensor = None
+    proj2_w: torch.Tensor = None; proj2_b: torch.Tensor = None
+    embed: torch.Tensor = None
+    llm: List[LlmLayerW] = field(default_factory=list)
+    norm_w: torch.Tensor = None
+    head_w: torch.Tensor = None; head_b: torch.Tensor = None
+
+    # ---- packing ---------------------------------------------------------------------------------
+    def _w16(self, w: torch.Tensor, rows: Optional[int] = None, cols: Optional[int] = None) -> torch.Tensor:
+        w = w.to(self.device)
+        rows = w.shape[0] if rows is None else rows
+        cols = pad64(w.shape[1]) if cols is None else cols
+        return _pad2(w, rows, cols).to(self.dtype).contiguous()
+
+    def _f32(self, t: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+        t = t.to(self.device, torch.float32)
+        return (_pad1(t, n) if n is not None else t).contiguous()
+
+    def pack_vision_embeddings(self, vsd: SD) -> None:
+        e = "vision_model.embeddings."
+        w = vsd[e + "patch_embedding.weight"]
+        self.patch_w = self._w16(w.reshape(w.shape[0], -1))
+        self.patch_b = self._f32(vsd[e + "patch_embedding.bias"])
+        self.pos_native = self._f32(vsd[e + "position_embedding.weight"])
+
+    def pack_vision_layer(self, vsd: SD, i: int) -> None:
+        v = self.cfg.vision
+        p = f"vision_model.encoder.layers.{i}."
+        fvp = pad64(v.intermediate_size)
+        qkv_w = torch.cat([vsd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        qkv_b = torch.cat([vsd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        self.vit.append(VitLayerW(
+            ln1_w=self._f32(vsd[p + "layer_norm1.weight"]), ln1_b=self._f32(vsd[p + "layer_norm1.bias"]),
+            qkv_w=self._w16(qkv_w), qkv_b=self._f32(qkv_b),
+            out_w=self._w16(vsd[p + "self_attn.out_proj.weight"]), out_b=self._f32(vsd[p + "self_attn.out_proj.bias"]),
+            ln2_w=self._f32(vsd[p + "layer_norm2.weight"]), ln2_b=self._f32(vsd[p + "layer_norm2.bias"]),
+            fc1_w=self._w16(vsd[p + "mlp.fc1.weight"], rows=fvp), fc1_b=self._f32(vsd[p + "mlp.fc1.bias"], fvp),
+            fc2_w=self._w16(vsd[p + "mlp.fc2.weight"]), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
+        ))
+
+    def pack_projector_and_head(self, sd: SD) -> None:
+        pre = "model.mm_projector.out_projection."
+        dp = pad64(self.cfg.hidden_size)
+        self.proj0_w = self._w16(sd[pre + "0.weight"], rows=dp)
+        self.proj0_b = self._f32(sd[pre + "0.bias"], dp)
+        self.proj2_w = self._w16(sd[pre + "2.weight"])
+        self.proj2_b = self._f32(sd[pre + "2.bias"])
+        self.embed = sd["model.embed_tokens.weight"].to(self.device, self.dtype).contiguous()
+        self.norm_w = self._f32(sd["model.norm.weight"])
+        self.head_w = self._f32(sd["out_proj.weight"].reshape(-1))
+        self.head_b = self._f32(sd["out_proj.bias"].reshape(-1))
+
+    def pack_llm_layer(self, sd: SD, i: int) -> None:
+        p = f"model.layers.{i}."
+        fp = pad64(self.cfg.intermediate_size)
+        qkv_w = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        qkv_b = torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        g = sd[p + "mlp.gate_proj.weight"].to(self.device)
+        u = sd[p + "mlp.up_proj.weight"].to(self.device)
+        g = _pad2(g, fp, g.shape[1]).reshape(fp // 32, 1, 32, -1)
+        u = _pad2(u, fp, u.shape[1]).reshape(fp // 32, 1, 32, -1)
+        gu = torch.cat([g, u], 1).reshape(2 * fp, -1)           # rows: [32 gate | 32 up] repeated
+        self.llm.append(LlmLayerW(
+            in_ln=self._f32(sd[p + "input_layernorm.weight"]),
+            qkv_w=self._w16(qkv_w), qkv_b=self._f32(qkv_b),
+            o_w=self._w16(sd[p + "self_attn.o_proj.weight"]),
+            post_ln=self._f32(sd[p + "post_attention_layernorm.weight"]),
+            gu_w=self._w16(gu),
+            down_w=self._w16(sd[p + "mlp.down_proj.weight"]),
+        ))
+
+    @staticmethod
+    def from_state_dicts(cfg: ITGConfig, sd: SD, vsd: SD, dtype: torch.dtype, device) -> "PackedWeights":
+        pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device(device))
+        pw.pack_vision_embeddings(vsd)
+        for i in range(cfg.num_vit_layers_needed()):
+            pw.pack_vision_layer(vsd, i)
+        pw.pack_projector_and_head(sd)
+        for i in range(cfg.num_hidden_layers):
+            pw.pack_llm_layer(sd, i)
+        return pw
+
+    def pos_table(self, grid: int) -> torch.Tensor:
+        """fp32 [grid*grid, Dv]; bicubic resample of the native table when the input side is not the native one
+        ([3P] SiglipVisionEmbeddings.interpolate_pos_encoding).  Load-time/cache work, not on the timed path."""
+        if grid not in self.pos_cache:
+            pos = self.pos_native
+            g0 = int(round(math.sqrt(pos.shape[0])))
+            if g0 != grid:
+                p = pos.reshape(1, g0, g0, -1).permute(0, 3, 1, 2)
+                p = F.interpolate(p, size=(grid, grid), mode="bicubic", align_corners=False)
+                pos = p.permute(0, 2, 3, 1).reshape(grid * grid, -1).contiguous()
+            self.pos_cache[grid] = pos
+        return self.pos_cache[grid]
+
+
+class SelectorEngine:
+    """Runs the forward.  One instance per process / GPU."""
+
+    def __init__(self, weights: PackedWeights, attn_variant: int = 0):
+        self.w = weights
+        self.cfg = weights.cfg
+        self.dtype = weights.dtype
+        self.device = weights.device
+        self.attn_variant = attn_variant
+        self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    # workspace: cached by (name, shape, dtype); zero-initialised once so that pad columns stay zero
+    def _buf(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def release_workspace(self) -> None:
+        self._ws.clear()
+
+    # ---- A7: SigLIP tower -> fp32 features [T*P, Dv] ------------------------------------------------
+    def vit_forward(self, pix: torch.Tensor) -> Tuple[torch.Tensor, int]:
+        cfg, v, w = self.cfg, self.cfg.vision, self.w
+        T, _, R, _ = pix.shape
+        G = R // v.patch_size
+        P = G * G
+        M = T * P
+        Dv, Dvp, Fvp = v.hidden_size, pad64(v.hidden_size), pad64(v.intermediate_size)
+        H, hd = v.num_attention_heads, v.head_dim
+        a0 = ops.patchify(pix, v.patch_size, w.patch_w.shape[1], self.dtype)
+        x = self._buf("vit_x", (M, Dv), torch.float32)
+        ops.gemm(a0, w.patch_w, x, mode=ops.GEMM_F32, bias=w.patch_b, res=w.pos_table(G), res_mod=P)
+        del a0
+        h = self._buf("vit_h", (M, Dvp), self.dtype, zero=True)
+        qkv = self._buf("vit_qkv", (M, 3 * Dv), self.dtype)
+        o = self._buf("vit_o", (M, Dvp), self.dtype, zero=True)
+        f = self._buf("vit_f", (M, Fvp), self.dtype)
+        scale = hd ** -0.5
+        for lw in w.vit:
+            ops.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
+            ops.gemm(h, lw.qkv_w, qkv, mode=ops.GEMM_STORE16, bias=lw.qkv_b)
+            ops.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
+                          q_strides=(P * 3 * Dv, 3 * Dv, hd), k_strides=(P * 3 * Dv, 3 * Dv, hd),
+                          v_strides=(P * 3 * Dv, 3 * Dv, hd), o_strides=(P * Dvp, Dvp, hd), scale=scale,
+                          variant=self.attn_variant)
+            ops.gemm(o, lw.out_w, x, mode=ops.GEMM_F32, bias=lw.out_b, res=x)
+            ops.layernorm(x, lw.ln2_w, lw.ln2_b, h, Dv, v.layer_norm_eps)
+            ops.gemm(h, lw.fc1_w, f, mode=ops.GEMM_STORE16, bias=lw.fc1_b, act=ops.ACT_GELU_TANH)
+            ops.gemm(f, lw.fc2_w, x, mode=ops.GEMM_F32, bias=lw.fc2_b, res=x)
+        return x, G
+
+    # ---- A9: pool + projector, written straight into rows of the LLM residual stream ------------------
+    def project_into(self, feats: torch.Tensor, T: int, G: int, hw: int, dst_rows: torch.Tensor) -> None:
+        cfg, w = self.cfg, self.w
+        Dv, Dvp, Dp = cfg.vision.hidden_size, pad64(cfg.vision.hidden_size), pad64(cfg.hidden_size)
+        nv = T * hw * hw
+        pooled = self._buf("pooled", (nv, Dvp), self.dtype)
+        ops.bilinear_pool(feats, pooled, T, G, hw, Dv)
+        g = self._buf("proj_g", (nv, Dp), self.dtype)
+        ops.gemm(pooled, w.proj0_w, g, mode=ops.GEMM_STORE16, bias=w.proj0_b, act=ops.ACT_GELU_ERF)
+        ops.gemm(g, w.proj2_w, dst_rows, mode=ops.GEMM_F32, bias=w.proj2_b)
+
+    def rope_tables(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """fp32 cos/sin [n, hd/2], inv_freq = theta^(-2i/hd), positions 0..n-1 ([3P] Qwen2RotaryEmbedding;
+        position_ids=None -> arange, eagle_archv1.py:396-397).  Built in fp32 on the host, cached per length."""
+        if n not in self._rope:
+            hd = self.cfg.head_dim
+            inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+            fr = torch.outer(torch.arange(n, dtype=torch.float32), inv)
+            self._rope[n] = (fr.cos().to(self.device).contiguous(), fr.sin().to(self.device).contiguous())
+        return self._rope[n]
+
+    # ---- A11: bidirectional Qwen2 stack over fp32 x [N, D] (in place) -> final-normed fp32 -------------
+    def llm_forward(self, x: torch.Tensor) -> torch.Tensor:
+        cfg, w = self.cfg, self.w
+        N, D = x.shape
+        Dp, Fp = pad64(D), pad64(cfg.intermediate_size)
+        nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        qkv_n = (nq + 2 * nkv) * hd
+        op = pad64(nq * hd)
+        h = self._buf("llm_h", (N, Dp), self.dtype, zero=True)
+        qkv = self._buf("llm_qkv", (N, qkv_n), self.dtype)
+        o = self._buf("llm_o", (N, op), self.dtype, zero=True)
+        f = self._buf("llm_f", (N, Fp), self.dtype)
+        cos, sin = self.rope_tables(N)
+        scale = hd ** -0.5
+        for lw in w.llm:
+            ops.rmsnorm(x, lw.in_ln, h, D, cfg.rms_norm_eps)
+            ops.gemm(h, lw.qkv_w, qkv, mode=ops.GEMM_STORE16, bias=lw.qkv_b)
+            ops.rope_(qkv, cos, sin, nq + nkv, hd)
+            ops.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
+                          head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
+                          o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
+            ops.gemm(o, lw.o_w, x, mode=ops.GEMM_F32, res=x)
+            ops.rmsnorm(x, lw.post_ln, h, D, cfg.rms_norm_eps)
+            ops.gemm(h, lw.gu_w, f, mode=ops.GEMM_SWIGLU)
+            ops.gemm(f, lw.down_w, x, mode=ops.GEMM_F32, res=x)
+        out = self._buf("llm_out", (N, D), torch.float32)
+        ops.rmsnorm(x, w.norm_w, out, D, cfg.rms_norm_eps)
+        return out
+
+    # ---- whole path for one sample whose frames are already encoded ---------------------------------
+    def score_video(self, feats: torch.Tensor, T: int, G: int, ids: torch.Tensor) -> torch.Tensor:
+        """feats fp32 [T*P, Dv] (this video's rows), ids HOST int64 [L] (unpadded, one IMAGE_TOKEN_INDEX) ->
+        logits fp32 [T]."""
+        cfg = self.cfg
+        ids = ids.cpu()
+        pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
+        if len(pos) != 1:
+            raise ValueError(f"exactly one <image> token per sample is supported on the selector path, got {len(pos)}")
+        hw = cfg.pooled_grid(T) if cfg.pooled_grid(T) < G else G
+        nv = T * hw * hw
+        pre, post = ids[:pos[0]], ids[pos[0] + 1:]
+        n = pre.numel() + nv + post.numel()
+        if cfg.tokenizer_model_max_length is not None and n > cfg.tokenizer_model_max_length:
+            keep = cfg.tokenizer_model_max_length                   # eagle_archv1.py:341-345 truncates the tail
+            if keep < pre.numel() + nv:
+                raise ValueError("tokenizer_model_max_length truncates visual tokens: the reference's per-frame reshape "
+                                 "(grounding_qwen2.py:153) fails in this case too")
+            post = post[:keep - pre.numel() - nv]
+            n = keep
+        x = self._buf("llm_x", (n, cfg.hidden_size), torch.float32)
+        if pre.numel():
+            ops.embed_gather(pre.contiguous().to(self.device), self.w.embed, x[:pre.numel()])
+        self.project_into(feats, T, G, hw, x[pre.numel():pre.numel() + nv])
+        if post.numel():
+            ops.embed_gather(post.contiguous().to(self.device), self.w.embed, x[pre.numel() + nv:])
+        hfin = self.llm_forward(x)
+        logits = torch.empty(T, dtype=torch.float32, device=self.device)
+        ops.pool_score(hfin[pre.numel():], T, hw * hw, cfg.hidden_size, self.w.head_w, self.w.head_b, logits)
+        return logits
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], images: Sequence[torch.Tensor]
+                ) -> List[torch.Tensor]:
+        """EagleQwenG.forward (grounding_qwen2.py:86-181), inference branch: list of [T_b,1] fp32 logits.
+        Padded batches are run sample by sample on the unpadded ids (eagle_archv1.py:272 strips padding; the
+        padded rows never influence real ones because keys are masked), which is value-identical."""
+        images = [im if im.dim() == 4 else im.unsqueeze(0) for im in images]
+        if input_ids.dim() == 1:
+            input_ids = input_ids.unsqueeze(0)
+        B = input_ids.shape[0]
+        if len(images) != B:
+            raise ValueError(f"{len(images)} videos for a batch of {B} prompts")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
+        attention_mask = attention_mask.bool()
+        sizes = {tuple(im.shape[1:]) for im in images}
+        if len(sizes) != 1:
+            raise ValueError("all videos in a batch must share one frame size")
+        pix = torch.cat([im.to(self.device) for im in images], 0) if B > 1 else images[0].to(self.device)
+        feats, G = self.vit_forward(pix)
+        P = G * G
+        out, row = [], 0
+        ids_host = input_ids.cpu()
+        mask_host = attention_mask.cpu()
+        for b in range(B):
+            T = images[b].shape[0]
+            ids = ids_host[b][mask_host[b]]                          # eagle_archv1.py:272
+            lg = self.score_video(feats[row * P:(row + T) * P], T, G, ids)
+            out.append(lg.reshape(T, 1))
+            row += T
+        return out

@@ -1,0 +1,180 @@
+"""``EagleQwenG`` twin: the model object of the operator surface (SURVEY.md §8b "Model object").
+
+Same call contract as /root/reference/eagle/model/language_model/grounding_qwen2.py:69-181:
+
+    out = model(input_ids, attention_mask=attention_mask, images=[Tensor[T,3,H,W], ...])
+    out.logits            # python list of B tensors [T_b, 1] (raw logits; caller applies sigmoid)
+
+and it tolerates the chaining the reference callers do (``.half().eval().to(device)``, infer.py:21;
+``accelerator.prepare_model(model, evaluation_mode=True)``, lmms_eval/models/videoitg.py:205).  It is an
+``nn.Module`` only so that those wrappers accept it; it holds no parameters — the arithmetic runs in
+libvideoitg_hip.so through ``SelectorEngine`` and there is no fallback when that library is absent.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ..config import ITGConfig
+from ..engine import PackedWeights, SelectorEngine
+from ..image_processor import SiglipImageProcessor
+
+EagleQwenGConfig = ITGConfig
+
+
+@dataclass
+class SelectorOutput:
+    """Field-compatible with the CausalLMOutputWithPast the reference returns (grounding_qwen2.py:175-181)."""
+    logits: List[torch.Tensor]
+    loss: Optional[torch.Tensor] = None
+    past_key_values: Any = None
+    hidden_states: Any = None
+    attentions: Any = None
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else (self.loss, self.logits)[k]
+
+
+class _VisionTowerHandle:
+    """What callers touch on ``model.get_vision_tower()`` (builder.py:163-168, videoitg.py:179)."""
+
+    def __init__(self, cfg: ITGConfig):
+        self.config = cfg.vision
+        self.vision_tower_name = cfg.mm_vision_tower
+        self.image_processor = SiglipImageProcessor(size=cfg.vision.image_size)
+        self.is_loaded = True
+        self.select_layer = cfg.mm_vision_select_layer
+        self.select_feature = cfg.mm_vision_select_feature
+
+    def load_model(self, device_map=None):
+        return None
+
+    def to(self, *a, **k):
+        return self
+
+    @property
+    def hidden_size(self):
+        return self.config.hidden_size
+
+    @property
+    def num_patches(self):
+        return self.config.num_patches
+
+    @property
+    def num_patches_per_side(self):
+        return self.config.grid
+
+    @property
+    def image_size(self):
+        return self.config.image_size
+
+
+class EagleQwenG(nn.Module):
+    config_class = EagleQwenGConfig
+
+    def __init__(self, config: ITGConfig, state_dict: Dict[str, torch.Tensor], vision_state_dict: Dict[str, torch.Tensor],
+                 torch_dtype: torch.dtype = torch.float16, device="cuda"):
+        super().__init__()
+        if config.mm_projector_type != "seq_mlp":
+            raise ValueError(f"Unknown projector type: {config.mm_projector_type}")       # multimodal_projector/builder.py:69
+        if config.mm_use_4_vision_tokens:
+            raise ValueError("mm_use_4_vision_tokens=True (2x2 token merge) is not part of the VideoITG selector path; "
+                             "the released config carries False (train_itg.py:1358)")
+        if config.mm_vision_select_feature != "patch":
+            raise ValueError(f"Unexpected select feature: {config.mm_vision_select_feature}")  # clip_encoder.py:128
+        self.config = config
+        self._src = (state_dict, vision_state_dict)
+        self._dtype = torch_dtype
+        self._device = torch.device(device)
+        self._engine: Optional[SelectorEngine] = None
+        self._tower = _VisionTowerHandle(config)
+
+    # ---- chaining the callers do ---------------------------------------------------------------
+    def _set(self, dtype=None, device=None):
+        if dtype is not None and dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"the selector kernels take fp16 or bf16 MFMA inputs, not {dtype}")
+        changed = (dtype is not None and dtype != self._dtype) or (device is not None and torch.device(device) != self._device)
+        if dtype is not None:
+            self._dtype = dtype
+        if device is not None:
+            self._device = torch.device(device)
+        if changed and self._engine is not None:
+            if self._src is None:
+                raise RuntimeError("weights were already packed and the source state dict was released; "
+                                   "set dtype/device before the first forward or load with keep_source=True")
+            self._engine = None
+        return self
+
+    def half(self):
+        return self._set(dtype=torch.float16)
+
+    def bfloat16(self):
+        return self._set(dtype=torch.bfloat16)
+
+    def to(self, *args, **kwargs):
+        dtype = kwargs.get("dtype")
+        device = kwargs.get("device")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif isinstance(a, (str, torch.device)):
+                device = a
+        return self._set(dtype=dtype, device=device)
+
+    def cuda(self, device=None):
+        return self._set(device="cuda" if device is None else device)
+
+    def eval(self):
+        return super().eval()
+
+    def tie_weights(self):
+        return None
+
+    def requires_grad_(self, requires_grad: bool = False):
+        return self
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def get_model(self):
+        return self
+
+    def get_vision_tower(self):
+        return self._tower
+
+    # ---- engine ----------------------------------------------------------------------------------
+    def engine(self, keep_source: bool = False) -> SelectorEngine:
+        if self._engine is None:
+            if self._device.type != "cuda":
+                raise RuntimeError("the VideoITG selector forward runs on an MI355X (device 'cuda:k' under ROCm); "
+                                   "there is no CPU path")
+            sd, vsd = self._src
+            with torch.cuda.device(self._device):
+                pw = PackedWeights.from_state_dicts(self.config, sd, vsd, self._dtype, self._device)
+            self._engine = SelectorEngine(pw)
+            if not keep_source:
+                self._src = None
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, input_ids: torch.LongTensor = None, attention_mask: Optional[torch.Tensor] = None,
+                position_ids=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, images=None, image_sizes=None, return_dict=None,
+                modalities=None, dpo_forward=False, cache_position=None, grounding_labels=None, token_types=None,
+                **_ignored) -> SelectorOutput:
+        if images is None or input_ids is None:
+            raise ValueError("the selector forward needs input_ids and images (grounding_qwen2.py:107-108)")
+        if grounding_labels is not None or dpo_forward or inputs_embeds is not None:
+            raise NotImplementedError("training / dpo / inputs_embeds branches are outside the inference hot path")
+        eng = self.engine()
+        with torch.cuda.device(self._device):
+            logits = eng.forward(input_ids, attention_mask, list(images))
+        return SelectorOutput(logits=logits)

@@ -1,0 +1,144 @@
+"""Tensor-facing wrappers over the C ABI (include/videoitg_hip.h).  Tensors are torch CUDA(=HIP) tensors used as
+typed views of HBM; every call goes to libvideoitg_hip.so on torch's current stream.  No torch math here."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, BF16, F16, F32, GEMM_F32, GEMM_STORE16, GEMM_SWIGLU  # noqa: F401
+
+_DT = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    return _DT[dtype]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype=None):
+    if not t.is_cuda:
+        raise _lib.VitgError("device tensor required (the selector forward has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.VitgError(f"expected {dtype}, got {t.dtype}")
+    return t
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def device_info():
+    buf = C.create_string_buffer(64)
+    cus = _lib.load().vitg_device_info(buf, 64)
+    if cus < 0:
+        raise _lib.VitgError("no usable HIP device")
+    return buf.value.decode(), cus
+
+
+def patchify(pix: torch.Tensor, patch: int, kpad: int, dtype: torch.dtype) -> torch.Tensor:
+    """pix [T,3,R,R] (fp32/fp16/bf16, contiguous) -> [T*G*G, kpad]"""
+    _req(pix)
+    pix = pix.contiguous()
+    T, Cc, R, _ = pix.shape
+    assert Cc == 3
+    G = R // patch
+    out = torch.empty((T * G * G, kpad), dtype=dtype, device=pix.device)
+    _lib.call("vitg_patchify", _ptr(pix), dt_code(pix.dtype), _ptr(out), T, R, patch, kpad, dt_code(dtype), _stream())
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: Optional[int] = None,
+         bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
+         res_mod: int = 0, m: Optional[int] = None) -> torch.Tensor:
+    """out = epilogue(a[:m] @ w[:n].T).  a [M,K] and w [N,K] 16-bit 2-D (row stride may exceed K),
+    out 2-D (16-bit for STORE16/SWIGLU, fp32 for F32)."""
+    _req(a)
+    _req(w, a.dtype)
+    M = a.shape[0] if m is None else m
+    N = w.shape[0] if n is None else n
+    K = w.shape[1]
+    assert a.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    if mode == GEMM_F32:
+        _req(out, torch.float32)
+    else:
+        _req(out, a.dtype)
+    if bias is not None:
+        _req(bias, torch.float32)
+    if res is not None:
+        _req(res, torch.float32)
+    _lib.call("vitg_gemm", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, N, K, dt_code(a.dtype), mode, _ptr(bias), act,
+              _ptr(out), out.stride(0), _ptr(res), 0 if res is None else res.stride(0), res_mod, _stream())
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, d: int, eps: float) -> torch.Tensor:
+    _req(x, torch.float32)
+    _lib.call("vitg_layernorm", _ptr(x), x.stride(0), _ptr(_req(w, torch.float32)), _ptr(_req(b, torch.float32)),
+              _ptr(out), out.stride(0), dt_code(out.dtype), x.shape[0], d, eps, _stream())
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, d: int, eps: float) -> torch.Tensor:
+    _req(x, torch.float32)
+    _lib.call("vitg_rmsnorm", _ptr(x), x.stride(0), _ptr(_req(w, torch.float32)), _ptr(out), out.stride(0),
+              dt_code(out.dtype), x.shape[0], d, eps, _stream())
+    return out
+
+
+def rope_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, head_dim: int) -> torch.Tensor:
+    """rotate the first `heads` heads of every row of qkv [N, ld] in place"""
+    _req(qkv)
+    _lib.call("vitg_rope", _ptr(qkv), qkv.stride(0), _ptr(_req(cos, torch.float32)), _ptr(_req(sin, torch.float32)),
+              qkv.shape[0], heads, head_dim, dt_code(qkv.dtype), _stream())
+    return qkv
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, *, batch: int, heads: int, kv_heads: int,
+              seq: int, head_dim: int, q_strides, k_strides, v_strides, o_strides, scale: float, variant: int = 0):
+    """q/k/v/o are base tensors (views at the first element); *_strides = (batch, row, head) in elements."""
+    _req(q)
+    _lib.call("vitg_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(o), batch, heads, kv_heads, seq, head_dim,
+              q_strides[0], k_strides[0], v_strides[0], o_strides[0], q_strides[1], k_strides[1], v_strides[1], o_strides[1],
+              q_strides[2], k_strides[2], v_strides[2], o_strides[2], scale, dt_code(q.dtype), variant, _stream())
+    return o
+
+
+def bilinear_pool(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d: int) -> torch.Tensor:
+    _req(x, torch.float32)
+    _lib.call("vitg_bilinear_pool", _ptr(x), x.stride(0), _ptr(out), out.stride(0), T, G, HW, d, dt_code(out.dtype), _stream())
+    return out
+
+
+def embed_gather(ids: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _req(ids, torch.int64)
+    _req(out, torch.float32)
+    _lib.call("vitg_embed_gather", _ptr(ids), ids.numel(), _ptr(table), table.shape[1], _ptr(out), out.stride(0),
+              dt_code(table.dtype), _stream())
+    return out
+
+
+def pool_score(h: torch.Tensor, frames: int, tokens_per_frame: int, d: int, w: torch.Tensor, b: torch.Tensor,
+               logits: torch.Tensor) -> torch.Tensor:
+    _req(h, torch.float32)
+    _lib.call("vitg_pool_score", _ptr(h), h.stride(0), frames, tokens_per_frame, d, _ptr(_req(w, torch.float32)),
+              _ptr(_req(b, torch.float32)), _ptr(_req(logits, torch.float32)), _stream())
+    return logits
+
+
+def rank(logits: torch.Tensor):
+    _req(logits, torch.float32)
+    n = logits.numel()
+    scores = torch.empty(n, dtype=torch.float32, device=logits.device)
+    order = torch.empty(n, dtype=torch.int32, device=logits.device)
+    _lib.call("vitg_rank", _ptr(logits), n, _ptr(scores), _ptr(order), _stream())
+    return scores, order
