@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py — frames scored / second of the VideoITG frame-selector forward on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one selector forward over one synthetic video (BASELINE.json configs[1]: 512 frames x 448^2,
+VideoITG-8B architecture, random-init weights, 60-token prompt): pixel_values and input_ids already resident in
+HBM -> SigLIP tower -> pool + projector -> splice -> 28 bidirectional Qwen2 layers -> score head -> sigmoid ->
+stable descending sort -> index list on the host (rows A7-A13 of SURVEY.md §8a; timed region of §8d).
+
+N > 1: one process per GPU; the video's frames are sharded over ranks for the tower/projector and the LLM runs
+context-parallel (per-layer RCCL all-gather of K/V, final all-gather of the logits), so total work is fixed
+("scaling": "strong").
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the MFMA GEMM; HIP
+events around every GEMM launch of the timed steps, on the launch stream) and `cpu_baseline` (the oracle timed on
+this host's cores on a bounded sample, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/fp16, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--res", type=int, default=448)
+    ap.add_argument("--prompt-len", type=int, default=60)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--config", default="full", choices=["full", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------
+def algorithmic_flops(cfg, T, R, n_text):
+    """per-video algorithmic FLOPs (multiply-add = 2), needed ViT layers only."""
+    v = cfg.vision
+    G = R // v.patch_size
+    P = G * G
+    Dv, Fv, Lv = v.hidden_size, v.intermediate_size, cfg.num_vit_layers_needed()
+    hw = min(cfg.pooled_grid(T), G)
+    N = T * hw * hw + n_text
+    D, Fl, Ll = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    kvw = cfg.num_key_value_heads * cfg.head_dim
+    patch = 2.0 * T * P * (3 * v.patch_size ** 2) * Dv
+    vit_gemm = T * Lv * 2.0 * P * (4 * Dv * Dv + 2 * Dv * Fv)
+    vit_attn = T * Lv * 4.0 * P * P * Dv
+    proj = 2.0 * T * hw * hw * (Dv * D + D * D)
+    llm_gemm = Ll * 2.0 * N * (D * (D + 2 * kvw) + D * D + 3 * D * Fl)
+    llm_attn = Ll * 4.0 * N * N * D
+    head = 2.0 * T * D
+    return dict(patch=patch, vit_gemm=vit_gemm, vit_attn=vit_attn, proj=proj, llm_gemm=llm_gemm, llm_attn=llm_attn,
+                head=head, total=patch + vit_gemm + vit_attn + proj + llm_gemm + llm_attn + head,
+                gemm=patch + vit_gemm + proj + llm_gemm, N=N, P=P, hw=hw)
+
+
+class GemmTimer:
+    """HIP events (torch.cuda.Event on the current stream = the stream every kernel is launched on) around each
+    GEMM launch; resolved after the timed region."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def wrap(self, fn):
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+            return r
+        return timed
+
+    def summary(self):
+        ms = [a.elapsed_time(b) for a, b in self.pairs]
+        return len(ms), sum(ms)
+
+
+def cpu_baseline(cfg, T, R, n_text, threads):
+    """Oracle (kind "port") on this host's cores, bounded sample of the same workload:
+    ViT: embed + 2 encoder layers on 8 frames at R;  LLM: 1 decoder layer at the full N.  Extrapolated to the whole
+    video (26 ViT layers x T/8 frame groups, 28 LLM layers); projector/head are <0.1 % and ignored."""
+    from oracle import videoitg_oracle as O          # checker/baseline only
+    from videoitg_amd import synth
+    torch.set_num_threads(threads)
+    fl = algorithmic_flops(cfg, T, R, n_text)
+    v = cfg.vision
+    specs = {k: (s, m, sd) for k, s, m, sd in synth.vision_param_specs(cfg)}
+    vsd = {}
+    for k, (s, m, sd) in specs.items():
+        if k.startswith("vision_model.embeddings") or ".layers.0." in k or ".layers.1." in k:
+            vsd[k] = synth.synth_tensor(0, k, s, m, sd)
+    nf = 8
+    pix = synth.synth_pixel_values(nf, R, seed=1234)
+    with torch.inference_mode():
+        O.siglip_tower(pix[:2], vsd, patch=v.patch_size, num_heads=v.num_attention_heads, num_layers=2, select_layer=2)  # warm
+        t0 = time.perf_counter()
+        O.siglip_tower(pix, vsd, patch=v.patch_size, num_heads=v.num_attention_heads, num_layers=2, select_layer=2,
+                       frame_chunk=nf)
+        t_vit = time.perf_counter() - t0
+    sd = {}
+    for k, s, m, sdv in synth.llm_param_specs(cfg):
+        if ".layers.0." in k:
+            sd[k] = synth.synth_tensor(0, k, s, m, sdv)
+    N = fl["N"]
+    x = torch.randn(1, N, cfg.hidden_size)
+    cos, sin = O.rope_tables(N, cfg.head_dim, cfg.rope_theta)
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        O.qwen2_layer(x, sd, 0, num_heads=cfg.num_attention_heads, num_kv_heads=cfg.num_key_value_heads,
+                      eps=cfg.rms_norm_eps, cos=cos, sin=sin, key_mask=None)
+        t_llm = time.perf_counter() - t0
+    est = t_vit * (T / nf) * (cfg.num_vit_layers_needed() / 2.0) + t_llm * cfg.num_hidden_layers
+    return dict(value=T / est, unit="frames/s", cores=threads, kind="port",
+                sample=f"oracle (torch CPU fp32): SigLIP embed+2 layers on {nf} frames@{R} in {t_vit:.2f}s, 1 Qwen2 layer at "
+                       f"N={N} in {t_llm:.2f}s; extrapolated x{T // nf} frame groups x{cfg.num_vit_layers_needed()}/2 layers + "
+                       f"x{cfg.num_hidden_layers} layers = {est:.0f}s per video",
+                sample_seconds=round(t_vit + t_llm, 2))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path for the product)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from videoitg_amd import ops, synth
+    from videoitg_amd.config import ITGConfig, tiny_config
+    from videoitg_amd.engine import SelectorEngine
+    from videoitg_amd.parallel import ContextParallel
+    from videoitg_amd.synth_device import packed_random_weights
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    cfg = ITGConfig() if args.config == "full" else tiny_config(vision_token_num=16384)
+    T, R = args.frames, args.res
+    if args.config == "tiny":
+        R = cfg.vision.image_size
+    weights = packed_random_weights(cfg, dtype, dev, seed=args.seed)
+    eng = SelectorEngine(weights)
+    cp = ContextParallel(rank, world) if world > 1 else None
+
+    # synthetic inputs, identical on every rank; resident in HBM before the timed region
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    ids = torch.cat([torch.tensor([-200]), synth.synth_prompt_ids(args.prompt_len, cfg.vocab_size)]).unsqueeze(0)
+    pix = (torch.rand((T, 3, R, R), generator=g) * 2 - 1).to(dtype).to(dev)
+
+    timer = GemmTimer()
+    ops.gemm = timer.wrap(ops.gemm)
+
+    def step():
+        if cp is None:
+            logits = eng.forward(ids, None, [pix])[0].view(-1)
+        else:
+            logits = cp.forward(eng, ids, pix)
+        scores, order = ops.rank(logits)
+        return order.cpu().tolist(), scores          # D2H of the index list = end of the timed region
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        order, scores = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    n_launch, gemm_ms = timer.summary()
+    fl = algorithmic_flops(cfg, T, R, ids.shape[1] - 1)
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        gemm_flops_step = fl["gemm"] / world                     # this rank's share (frames / tokens are sharded)
+        per_launch_flops = gemm_flops_step * args.steps / max(n_launch, 1)
+        avg_ms = gemm_ms / max(n_launch, 1)
+        achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames scored/sec", "value": round(T / (dt / args.steps), 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic (random-init weights of the VideoITG-8B architecture, uniform pixels, "
+                                         "60-token prompt)",
+            "config": {"workload": f"{T} frames x {R}^2, SigLIP-so400m/14 ({cfg.num_vit_layers_needed()} layers) + seq_mlp "
+                                   f"(pool {fl['hw']}x{fl['hw']}) + Qwen2-7B bidirectional ({cfg.num_hidden_layers} layers), "
+                                   f"N={fl['N']} tokens; pixels+ids resident in HBM -> sorted index list on host",
+                       "frames": T, "resolution": R, "llm_tokens": fl["N"],
+                       "parallelism": "single GPU" if world == 1 else f"frame-sharded tower + context-parallel LLM x{world}",
+                       "algorithmic_tflop_per_video": round(fl["total"] / 1e12, 1)},
+            "end_to_end_tflops": round(fl["total"] / (dt / args.steps) / 1e12, 1),
+            "roofline": {"kernel": "gemm128_kernel (all GEMMs of the step)", "bound": "mfma", "achieved": round(achieved, 1),
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": traffic, "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
+                         "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)},
+            "top32": sorted(order[:32]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            eng.release_workspace()
+            out["cpu_baseline"] = cpu_baseline(cfg, T, R, ids.shape[1] - 1, os.cpu_count() or 1)
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

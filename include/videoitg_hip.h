@@ -75,12 +75,13 @@ int vitg_rope(void* qkv, int ld, const float* cos_t, const float* sin_t, long N,
               void* stream);
 
 /* Non-causal softmax(QK^T * scale) V, fp32 softmax, GQA (heads % kv_heads == 0), head_dim 72 or 128.
+ * S queries attend to Sk keys (Sk == S on one GPU; Sk = all-gathered keys in the context-parallel LLM).
  * Strides in elements: *_bs batch, *_rs token row, *_hs head.  variant 0 = production path, 1 = cross-check
  * path that reads V from LDS with scalar loads instead of ds_read_b64_tr_b16.
  * Replaces flash-attn 2 fwd: SigLIP (clip_encoder.py:117 forces flash_attention_2) and the bidirectional
  * Qwen2 attention (grounding_qwen2.py:45-53, is_causal=False). */
 int vitg_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads, int S,
-                   int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs, int v_rs, int o_rs,
+                   int Sk, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs, int v_rs, int o_rs,
                    int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype, int variant, void* stream);
 
 /* Bilinear G x G -> HW x HW token pool (align_corners=False, no antialias) of fp32 features [T*G*G, ldx] into

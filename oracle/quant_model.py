@@ -1,0 +1,117 @@
+"""ORACLE-SIDE numerics model — test infrastructure, NOT product code.
+
+Two rounding models layered on the fp32 restatement (oracle/videoitg_oracle.py), used to derive the error budget
+that DESIGN.md quotes and that tests/test_numerics_budget.py checks on CPU:
+
+* ``mode="product"``: rounds to the 16-bit type exactly where libvideoitg_hip.so does (MFMA inputs only: norm
+  outputs, fused-QKV output, RoPE output, softmax probabilities, attention output, GELU / SwiGLU output, pooled
+  features, projector hidden); residual stream, accumulators, norm/softmax statistics stay fp32.
+* ``mode="reference16"``: rounds after EVERY op like the reference's own inference does when the whole module is
+  ``.half()`` (/root/reference/eagle/model/builder.py:59, infer.py:21): residual adds, norm outputs, GEMM outputs,
+  activations all produce 16-bit tensors (matmuls accumulate in fp32 inside the BLAS kernel, flash-attn keeps
+  softmax statistics in fp32 and P in 16 bit).
+
+Comparing each against the fp32 oracle gives (a) the rounding noise the product SHOULD show if its kernels are
+otherwise exact and (b) the noise the reference's own fp16 run carries.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import videoitg_oracle as O
+
+
+class Q:
+    def __init__(self, dtype: Optional[torch.dtype], mode: str):
+        self.dtype, self.mode = dtype, mode
+
+    def mm(self, t):       # MFMA-input rounding (both modes)
+        return t if self.dtype is None else t.to(self.dtype).float()
+
+    def every(self, t):    # op-output rounding (reference16 only)
+        return self.mm(t) if self.mode == "reference16" else t
+
+
+def _attn(q, k, v, scale, qz: Q, q_chunk=1024):
+    rep = q.shape[1] // k.shape[1]
+    k, v = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
+    out = torch.empty_like(q)
+    for s in range(0, q.shape[2], q_chunk):
+        sc = torch.matmul(q[:, :, s:s + q_chunk], k.transpose(-1, -2)) * scale
+        m = sc.max(-1, keepdim=True).values
+        p = torch.exp(sc - m)
+        l = p.sum(-1, keepdim=True)                         # fp32 row sum of the unrounded p (as the kernel does)
+        out[:, :, s:s + q_chunk] = torch.matmul(qz.mm(p), v) / l
+    return out
+
+
+def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tensor], dtype=torch.float16,
+            mode: str = "product"):
+    qz = Q(dtype, mode)
+    v = cfg.vision
+    images = [im if im.dim() == 4 else im.unsqueeze(0) for im in images]
+    pix = qz.mm(torch.cat(list(images), 0).float())
+    # ---- tower
+    w = vsd["vision_model.embeddings.patch_embedding.weight"]
+    x = F.conv2d(pix, w, vsd["vision_model.embeddings.patch_embedding.bias"], stride=v.patch_size)
+    T, Dv, G, _ = x.shape
+    x = qz.every(x.flatten(2).transpose(1, 2) + O.siglip_pos_embedding(vsd, G).unsqueeze(0))
+    H = v.num_attention_heads
+    hd = Dv // H
+    n_run = v.num_hidden_layers + 1 + cfg.mm_vision_select_layer
+    for i in range(n_run):
+        p = f"vision_model.encoder.layers.{i}."
+        h = qz.mm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm1.weight"], vsd[p + "layer_norm1.bias"], v.layer_norm_eps))
+        q, k, vv = (qz.mm(F.linear(h, vsd[p + f"self_attn.{n}_proj.weight"], vsd[p + f"self_attn.{n}_proj.bias"]))
+                    .view(T, -1, H, hd).transpose(1, 2) for n in "qkv")
+        o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz)).transpose(1, 2).reshape(T, -1, Dv)
+        x = qz.every(x + qz.every(F.linear(o, vsd[p + "self_attn.out_proj.weight"], vsd[p + "self_attn.out_proj.bias"])))
+        h = qz.mm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm2.weight"], vsd[p + "layer_norm2.bias"], v.layer_norm_eps))
+        f = qz.mm(O.gelu_tanh(qz.every(F.linear(h, vsd[p + "mlp.fc1.weight"], vsd[p + "mlp.fc1.bias"]))))
+        x = qz.every(x + qz.every(F.linear(f, vsd[p + "mlp.fc2.weight"], vsd[p + "mlp.fc2.bias"])))
+    feats = torch.split(x, [im.shape[0] for im in images], 0)
+    # ---- projector
+    pre = "model.mm_projector.out_projection."
+    visual = []
+    for f in feats:
+        hw = O.pooled_grid(f.shape[0], int(f.shape[1] ** 0.5), cfg.vision_token_num)
+        pl = qz.mm(O.bilinear_pool(f, hw))
+        g = qz.mm(F.gelu(qz.every(F.linear(pl, sd[pre + "0.weight"], sd[pre + "0.bias"]))))
+        visual.append(qz.every(F.linear(g, sd[pre + "2.weight"], sd[pre + "2.bias"])).flatten(0, 1))
+    xs, mask, tts = O.splice(input_ids, attention_mask, visual, sd, max_length=cfg.tokenizer_model_max_length,
+                             padding_side=cfg.tokenizer_padding_side)
+    # ---- LLM, one sample at a time on its unpadded rows (value-identical to the masked batch)
+    nq, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    D = cfg.hidden_size
+    hd = D // nq
+    logits = []
+    for b, im in enumerate(images):
+        x = xs[b][mask[b]].unsqueeze(0)
+        N = x.shape[1]
+        cos, sin = O.rope_tables(N, hd, cfg.rope_theta)
+        if mode == "reference16":
+            cos, sin = qz.mm(cos), qz.mm(sin)            # HF casts the tables to the activation dtype
+        for i in range(cfg.num_hidden_layers):
+            p = f"model.layers.{i}."
+            h = qz.mm(O.rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps))
+            q = qz.mm(F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"])).view(1, N, nq, hd).transpose(1, 2)
+            k = qz.mm(F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])).view(1, N, nkv, hd).transpose(1, 2)
+            vv = qz.mm(F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])).view(1, N, nkv, hd).transpose(1, 2)
+            q = qz.mm(q * cos + O.rotate_half(q) * sin)
+            k = qz.mm(k * cos + O.rotate_half(k) * sin)
+            o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz)).transpose(1, 2).reshape(1, N, D)
+            x = qz.every(x + qz.every(F.linear(o, sd[p + "self_attn.o_proj.weight"])))
+            h = qz.mm(O.rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
+            g = qz.every(F.linear(h, sd[p + "mlp.gate_proj.weight"]))
+            u = qz.every(F.linear(h, sd[p + "mlp.up_proj.weight"]))
+            f = qz.mm(qz.every(F.silu(g)) * u)
+            x = qz.every(x + qz.every(F.linear(f, sd[p + "mlp.down_proj.weight"])))
+        hfin = qz.every(O.rms_norm(x, sd["model.norm.weight"], cfg.rms_norm_eps))
+        tt = tts[b][mask[b]]
+        pooled = qz.every(hfin[0][tt == 3].reshape(im.shape[0], -1, D).mean(1))
+        logits.append(qz.every(F.linear(pooled, sd["out_proj.weight"], sd["out_proj.bias"])))
+    return logits

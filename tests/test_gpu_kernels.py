@@ -236,5 +236,3 @@ def test_rank_stable_descending(ops, n):
     assert torch.equal(order.cpu().long(), torch.sort(got_scores, descending=True, stable=True).indices)
     if torch.equal(got_scores, s):
         assert torch.equal(order.cpu().long(), want)
-EOF
-echo done

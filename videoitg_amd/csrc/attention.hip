@@ -21,7 +21,8 @@ struct AttnArgs {
     long q_bs, k_bs, v_bs, o_bs;     // batch strides (elements)
     int q_rs, k_rs, v_rs, o_rs;      // row (token) strides (elements)
     int q_hs, k_hs, v_hs, o_hs;      // head strides (elements)
-    int S;                           // sequence length (queries == keys)
+    int S;                           // number of queries
+    int Sk;                          // number of keys (== S unless the keys were all-gathered from other ranks)
     int group;                       // q heads per kv head
     float scale_log2e;               // softmax scale * log2(e)
 };
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
             const int c = tid + i * ATT_THREADS;
             if (c < NCH) {
                 const int row = c / C::CH, ch = c % C::CH;
-                const int key = min(kt * ATT_BK + row, a.S - 1);
+                const int key = min(kt * ATT_BK + row, a.Sk - 1);
                 rk[i] = *(const u32x4*)(K + (long)key * a.k_rs + ch * 8);
                 rv[i] = *(const u32x4*)(V + (long)key * a.v_rs + ch * 8);
             }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    const int nkt = ceil_div(a.S, ATT_BK);
+    const int nkt = ceil_div(a.Sk, ATT_BK);
     load_kv(0);
     store_kv(0);
     __syncthreads();
@@ -145,13 +146,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
             }
         }
         // lane (q = ql, h): s[t][r] is key  kt*64 + t*32 + 8*(r>>2) + 4*h + (r&3)
-        if (kt * ATT_BK + ATT_BK > a.S) {
+        if (kt * ATT_BK + ATT_BK > a.Sk) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * ATT_BK + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    if (key >= a.S) s[t][r] = -INFINITY;
+                    if (key >= a.Sk) s[t][r] = -INFINITY;
                 }
         }
         // ---- online softmax (base-2), lane-local + one exchange with lane^32 ----------------------------
@@ -255,10 +256,11 @@ static int launch_attn(const AttnArgs& a, int batch, int heads, hipStream_t s) {
 using namespace vitg;
 
 extern "C" int vitg_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads,
-                              int S, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs,
+                              int S, int Sk, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs,
                               int v_rs, int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype,
                               int variant, void* stream) {
     if (batch <= 0 || heads <= 0 || S <= 0) return 0;
+    if (Sk <= 0) return VITG_ERR_SHAPE;
     if (kv_heads <= 0 || heads % kv_heads) return VITG_ERR_SHAPE;
     if (head_dim != 72 && head_dim != 128) return VITG_ERR_SHAPE;
     if ((q_rs | k_rs | v_rs | o_rs | q_hs | k_hs | v_hs | o_hs) % 4) return VITG_ERR_ALIGN;
@@ -269,7 +271,7 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
     a.q_rs = q_rs; a.k_rs = k_rs; a.v_rs = v_rs; a.o_rs = o_rs;
     a.q_hs = q_hs; a.k_hs = k_hs; a.v_hs = v_hs; a.o_hs = o_hs;
-    a.S = S; a.group = heads / kv_heads;
+    a.S = S; a.Sk = Sk; a.group = heads / kv_heads;
     a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     int rc;

@@ -239,9 +239,12 @@ class SelectorEngine:
         return self._rope[n]
 
     # ---- A11: bidirectional Qwen2 stack over fp32 x [N, D] (in place) -> final-normed fp32 -------------
-    def llm_forward(self, x: torch.Tensor) -> torch.Tensor:
+    def llm_forward(self, x: torch.Tensor, pos0: int = 0, total: Optional[int] = None, kv_gather=None) -> torch.Tensor:
+        """x: this rank's rows (all rows on one GPU).  Context-parallel use (videoitg_amd.parallel): pos0 = global
+        position of row 0, total = global token count, kv_gather(local K|V rows) -> all K|V rows."""
         cfg, w = self.cfg, self.w
         N, D = x.shape
+        total = N if total is None else total
         Dp, Fp = pad64(D), pad64(cfg.intermediate_size)
         nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         qkv_n = (nq + 2 * nkv) * hd
@@ -250,15 +253,23 @@ class SelectorEngine:
         qkv = self._buf("llm_qkv", (N, qkv_n), self.dtype)
         o = self._buf("llm_o", (N, op), self.dtype, zero=True)
         f = self._buf("llm_f", (N, Fp), self.dtype)
-        cos, sin = self.rope_tables(N)
+        cos, sin = self.rope_tables(total)
+        cos, sin = cos[pos0:pos0 + N], sin[pos0:pos0 + N]
         scale = hd ** -0.5
+        kvw = 2 * nkv * hd
         for lw in w.llm:
             ops.rmsnorm(x, lw.in_ln, h, D, cfg.rms_norm_eps)
             ops.gemm(h, lw.qkv_w, qkv, mode=ops.GEMM_STORE16, bias=lw.qkv_b)
             ops.rope_(qkv, cos, sin, nq + nkv, hd)
-            ops.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
-                          head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
-                          o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
+            if kv_gather is None:
+                ops.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
+                              head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
+                              o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
+            else:
+                kv = kv_gather(qkv[:, nq * hd:])                 # [total, 2*nkv*hd]: K heads then V heads per row
+                ops.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
+                              head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, kvw, hd), v_strides=(0, kvw, hd),
+                              o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
             ops.gemm(o, lw.o_w, x, mode=ops.GEMM_F32, res=x)
             ops.rmsnorm(x, lw.post_ln, h, D, cfg.rms_norm_eps)
             ops.gemm(h, lw.gu_w, f, mode=ops.GEMM_SWIGLU)

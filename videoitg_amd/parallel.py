@@ -1,0 +1,132 @@
+"""One video over N GPUs: frame-sharded tower/projector + context-parallel bidirectional LLM.
+
+The reference has no intra-video parallelism (one model per GPU, whole videos per rank:
+/root/reference/lmms_eval/models/videoitg.py:154-177, lmms_eval/utils.py:689-695).  Sharding the *model call* by
+frames would change the scores (every visual token attends to every other one and to the prompt, and the pooled
+grid depends on the global frame count, mlp_proj.py:48), so the split that preserves results is:
+
+* tower + pool + projector: rank r owns frames [f0_r, f1_r); the pooled grid uses the GLOBAL T; no collective;
+* LLM: rank r owns the token rows of its frames (+ the text before <image> on rank 0, the text after it on the
+  last rank); weights replicated; per layer ONE exchange — an all-gather of the local K|V rows (GQA: 2*4*128
+  values per token) — then local queries attend to all keys (non-causal => perfectly balanced, no zig-zag);
+  RoPE uses global positions;
+* score head: local frames -> all-gather of the T logits -> every rank ranks them.
+
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests) is the only
+communication layer.  The planning and gather code is device-agnostic so the world_size-2 gloo tests exercise the
+same code that runs on the GPUs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .constants import IMAGE_TOKEN_INDEX
+
+
+@dataclass
+class ShardPlan:
+    world: int
+    frames: List[range]          # frames owned by each rank
+    n_pre: int                   # text tokens before <image> (rank 0)
+    n_post: int                  # text tokens after <image> (last rank)
+    tokens_per_frame: int
+    n_local: List[int]           # LLM rows per rank
+    offset: List[int]            # global position of each rank's first row
+    total: int
+
+    def vis_start(self, rank: int) -> int:
+        """local row index of the first visual token on `rank`"""
+        return self.n_pre if rank == 0 else 0
+
+
+def make_plan(world: int, T: int, tokens_per_frame: int, n_pre: int, n_post: int) -> ShardPlan:
+    base, extra = divmod(T, world)
+    frames, f = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        frames.append(range(f, f + n))
+        f += n
+    n_local = [len(fr) * tokens_per_frame for fr in frames]
+    n_local[0] += n_pre
+    n_local[-1] += n_post
+    offset, acc = [], 0
+    for n in n_local:
+        offset.append(acc)
+        acc += n
+    return ShardPlan(world, frames, n_pre, n_post, tokens_per_frame, n_local, offset, acc)
+
+
+class RowGatherer:
+    """all-gather of a ragged row-sharded matrix: rank r contributes rows [offset_r, offset_r + n_r)."""
+
+    def __init__(self, plan: ShardPlan, rank: int, group=None):
+        self.plan, self.rank, self.group = plan, rank, group
+        self.n_max = max(plan.n_local)
+        self.even = len(set(plan.n_local)) == 1
+        self._send = self._recv = self._out = None
+
+    def __call__(self, local: torch.Tensor) -> torch.Tensor:
+        p = self.plan
+        n, c = local.shape
+        assert n == p.n_local[self.rank]
+        if self._send is None or self._send.shape[1] != c or self._send.dtype != local.dtype:
+            self._send = torch.zeros((self.n_max, c), dtype=local.dtype, device=local.device)
+            self._recv = torch.empty((p.world * self.n_max, c), dtype=local.dtype, device=local.device)
+            self._out = self._recv if self.even else torch.empty((p.total, c), dtype=local.dtype, device=local.device)
+        self._send[:n].copy_(local)
+        dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+        if self.even:
+            return self._recv
+        for r in range(p.world):
+            self._out[p.offset[r]:p.offset[r] + p.n_local[r]].copy_(self._recv[r * self.n_max:r * self.n_max + p.n_local[r]])
+        return self._out
+
+
+def gather_logits(local: torch.Tensor, plan: ShardPlan, rank: int, group=None) -> torch.Tensor:
+    """per-rank frame logits -> all T logits on every rank, in frame order"""
+    fmax = max(len(f) for f in plan.frames)
+    send = torch.zeros(fmax, dtype=local.dtype, device=local.device)
+    send[:local.numel()].copy_(local.reshape(-1))
+    recv = torch.empty(plan.world * fmax, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return torch.cat([recv[r * fmax:r * fmax + len(plan.frames[r])] for r in range(plan.world)])
+
+
+class ContextParallel:
+    def __init__(self, rank: int, world: int, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def forward(self, eng, input_ids: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
+        """input_ids [1, L] (one <image>), pix [T,3,R,R] resident on every rank (only the local frames are read)
+        -> logits fp32 [T] on every rank."""
+        from . import ops
+        cfg = eng.cfg
+        ids = input_ids.reshape(-1).cpu()
+        pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
+        if len(pos) != 1:
+            raise ValueError("exactly one <image> token per sample")
+        pre, post = ids[:pos[0]], ids[pos[0] + 1:]
+        T = pix.shape[0]
+        G = pix.shape[-1] // cfg.vision.patch_size
+        hw = min(cfg.pooled_grid(T), G)                      # GLOBAL frame count (mlp_proj.py:48)
+        plan = make_plan(self.world, T, hw * hw, pre.numel(), post.numel())
+        fr = plan.frames[self.rank]
+        feats, _ = eng.vit_forward(pix[fr.start:fr.stop])
+        n = plan.n_local[self.rank]
+        x = eng._buf("llm_x", (n, cfg.hidden_size), torch.float32)
+        vs = plan.vis_start(self.rank)
+        nv = len(fr) * hw * hw
+        if self.rank == 0 and pre.numel():
+            ops.embed_gather(pre.contiguous().to(eng.device), eng.w.embed, x[:pre.numel()])
+        eng.project_into(feats, len(fr), G, hw, x[vs:vs + nv])
+        if self.rank == self.world - 1 and post.numel():
+            ops.embed_gather(post.contiguous().to(eng.device), eng.w.embed, x[vs + nv:])
+        gather = RowGatherer(plan, self.rank, self.group)
+        hfin = eng.llm_forward(x, pos0=plan.offset[self.rank], total=plan.total, kv_gather=gather)
+        local = torch.empty(len(fr), dtype=torch.float32, device=eng.device)
+        ops.pool_score(hfin[vs:], len(fr), hw * hw, cfg.hidden_size, eng.w.head_w, eng.w.head_b, local)
+        return gather_logits(local, plan, self.rank, self.group)
