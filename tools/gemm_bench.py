@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-shape GEMM throughput on the GPU (random fp16/bf16 data).  VITG_GEMM_TILE=128|256 pins the kernel.
+    python tools/gemm_bench.py [fp16|bf16]"""
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videoitg_amd import ops  # noqa: E402
+
+dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float16
+SHAPES = [  # name, M, N, K, mode
+    ("vit_qkv", 524288, 3456, 1152, ops.GEMM_STORE16),
+    ("vit_fc1", 524288, 4352, 1152, ops.GEMM_STORE16),
+    ("vit_out", 524288, 1152, 1152, ops.GEMM_F32),
+    ("vit_fc2", 524288, 1152, 4352, ops.GEMM_F32),
+    ("llm_qkv", 12860, 4608, 3584, ops.GEMM_STORE16),
+    ("llm_o", 12860, 3584, 3584, ops.GEMM_F32),
+    ("llm_gateup", 12860, 37888, 3584, ops.GEMM_SWIGLU),
+    ("llm_down", 12860, 3584, 18944, ops.GEMM_F32),
+    ("square8k", 8192, 8192, 8192, ops.GEMM_STORE16),
+]
+for name, M, N, K, mode in SHAPES:
+    a = (torch.rand((M, K), device="cuda") * 2 - 1).to(dt)
+    w = ((torch.rand((N, K), device="cuda") * 2 - 1) * K ** -0.5).to(dt)
+    if mode == ops.GEMM_F32:
+        out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+        kw = dict(res=out)
+    elif mode == ops.GEMM_SWIGLU:
+        out = torch.empty((M, N // 2), dtype=dt, device="cuda")
+        kw = {}
+    else:
+        out = torch.empty((M, N), dtype=dt, device="cuda")
+        kw = dict(bias=torch.zeros(N, device="cuda"), act=ops.ACT_GELU_TANH if "fc1" in name else ops.ACT_NONE)
+    for _ in range(2):
+        ops.gemm(a, w, out, mode=mode, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    it = 5
+    e0.record()
+    for _ in range(it):
+        ops.gemm(a, w, out, mode=mode, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / it
+    print(f"{name:12s} M={M:7d} N={N:6d} K={K:6d} {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TF/s", flush=True)
+    del a, w, out

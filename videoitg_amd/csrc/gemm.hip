@@ -12,26 +12,15 @@
 //
 // Work-group order: XCD-contiguous remap (block b runs on XCD b%8) + 8-row-tile groups, so the ~64
 // concurrently resident blocks of an XCD form an 8x8 super-tile that shares operand panels in its L2.
-#include "common.h"
-#include "../../include/videoitg_hip.h"
+#include "gemm_common.h"
+#include <stdlib.h>
 
 namespace vitg {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GEMM_THREADS = 256;
 
-struct GemmArgs {
-    const void* A; int lda;
-    const void* W; int ldw;
-    int M, N, K;
-    const float* bias;        // [N] fp32 or null
-    int act;                  // VITG_ACT_*
-    void* out; int ldo;       // mode STORE16/SWIGLU: T16*, mode F32: float*
-    const float* res; int ldr; int res_mod;   // mode F32: out = acc + bias + res[(m % res_mod), n] (res may be null)
-    int tiles_m, tiles_n;
-};
 
-enum { MODE_STORE16 = 0, MODE_F32 = 1, MODE_SWIGLU = 2 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {        // bytes within one operand tile
     return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -46,21 +35,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm128_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- block -> tile (XCD-contiguous, grouped) ------------------------------------------
-    const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    constexpr int GM = 8;
-    const int per_group = GM * g.tiles_n;
-    const int grp = bid / per_group;
-    const int first_m = grp * GM;
-    const int gsz = min(g.tiles_m - first_m, GM);
-    const int in_g = bid - grp * per_group;
-    const int tm = first_m + in_g % gsz;
-    const int tn = in_g / gsz;
+    int tm, tn;
+    block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, 8, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- staging assignment: 1024 chunks per operand tile, 4 per thread ---------------------
@@ -233,6 +209,10 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
     g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN);
     hipStream_t s = (hipStream_t)stream;
-    const int rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
+    static int force = -1;          // VITG_GEMM_TILE=128|256 pins the kernel (A/B measurements); default: auto
+    if (force < 0) { const char* e = getenv("VITG_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    int rc;
+    if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
+    else rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
 }

@@ -1,0 +1,248 @@
+// C[M,N] = A[M,K] * W[N,K]^T, 256 x BN x 32 tile (BN = 256 or 128), 8 waves (2 M x 4 N), ring-buffered LDS fed by
+// LDS-DMA (global_load_lds_dwordx4) with loads in flight ACROSS the per-K-tile barrier (gfx950).
+//
+//   ring of 4 stages, prefetch distance 3 K-tiles:
+//     iteration t:  s_waitcnt vmcnt(<loads of the 2 newer tiles>)   -> this wave's DMA for tile t has landed
+//                   s_barrier                                       -> every wave's has; all waves left compute(t-1)
+//                   issue DMA of tile t+3 into stage (t+3)&3 == (t-1)&3   (free: nobody reads tile t-1 any more)
+//                   compute(t) from stage t&3: ds_read_b128 fragments + v_mfma_f32_32x32x16
+//   One raw s_barrier per K-tile, never a vmcnt(0) in the steady state, no VGPR round trip and no ds_write for
+//   staging.  (__syncthreads() would drain the DMA queue: cdna_hip_programming.md §5 "glds vs register staging".)
+//
+// LDS image of one operand tile: [rows][4 chunks x 16 B] (64-B rows), chunk index XOR ((row>>3)&3): conflict-free for
+// the ds_read_b128 lane groups with the 32x32x16 fragment pattern (row = lane&31, chunk = 2*ks + lane>>5).  The DMA
+// writes LDS lane-linearly, so the swizzle is applied to the per-lane SOURCE address (rule 21 of the guide).
+//
+// MFMA "A" operand = weight rows, "B" operand = activation rows (as in gemm.hip): a lane's accumulator holds 4
+// consecutive output features of one token.
+#include "gemm_common.h"
+#include <stdlib.h>
+
+namespace vitg {
+
+constexpr int G2_BM = 256, G2_THREADS = 512;
+
+// Two shipped configurations (chosen per shape by launch256_t):
+//   <BN=256, WM=2, STAGES=4>: wave tile 128x64, 128 KiB LDS, 1 block/CU  - best steady state (large K)
+//   <BN=128, WM=4, STAGES=3>: wave tile  64x64,  72 KiB LDS, 2 blocks/CU - one block's prologue/epilogue overlaps the
+//                                                                          other's main loop (small K, heavy epilogues)
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK>
+__global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g) {
+    typedef typename T16<T>::vec8 vec8;
+    constexpr int WN = 8 / WM;
+    constexpr int MT = G2_BM / WM / 32;                  // 32-row activation tiles per wave
+    constexpr int NT = BN / WN / 32;                     // 32-wide weight tiles per wave
+    constexpr int KS = BK / 16;                          // 16-deep MFMA k-steps per K-tile
+    constexpr int ROWB = BK * 2;                         // bytes per LDS row (64 or 128)
+    constexpr int CPR = BK / 8;                          // 16-B chunks per row
+    constexpr int RPI = 1024 / ROWB;                     // rows covered by one DMA instruction (1 KiB)
+    constexpr int A_BYTES = G2_BM * ROWB;
+    constexpr int W_BYTES = BN * ROWB;
+    constexpr int STAGE = A_BYTES + W_BYTES;
+    constexpr int A_INSTR = A_BYTES / 1024 / 8;          // DMA instructions per wave per K-tile
+    constexpr int W_INSTR = W_BYTES / 1024 / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+
+    int tm, tn;
+    block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    const int m0 = tm * G2_BM, n0 = tn * BN;
+
+    // ---- DMA assignment: one instruction = RPI rows x ROWB bytes; lane -> (row = lane / CPR, LDS chunk slot = lane % CPR)
+    // chunk swizzle: BK=32: (row>>3)&3, BK=64: (row>>1)&7 -- both invariant under row += 32 and conflict-free for the
+    // ds_read_b128 lane groups with the 32x32x16 fragment pattern.
+    auto swz = [](int row) { return BK == 32 ? ((row >> 3) & 3) : ((row >> 1) & 7); };
+    const int drow = lane / CPR, dslot = lane % CPR;
+    const char* a_src[A_INSTR];
+    const char* w_src[W_INSTR];
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+        const int R = (wave * A_INSTR + j) * RPI + drow;                // row within the 256-row activation tile
+        const int am = min(m0 + R, g.M - 1);
+        a_src[j] = (const char*)g.A + ((size_t)am * g.lda + ((dslot ^ swz(R)) << 3)) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) {
+        const int R = (wave * W_INSTR + j) * RPI + drow;
+        const int wn = min(n0 + R, g.N - 1);
+        w_src[j] = (const char*)g.W + ((size_t)wn * g.ldw + ((dslot ^ swz(R)) << 3)) * 2;
+    }
+    constexpr int LPT = A_INSTR + W_INSTR;               // DMA instructions per thread per K-tile
+    auto issue_one = [&](int kt, int j) {                // j-th DMA instruction of K-tile kt (j compile-time after unroll)
+        char* st = smem + (kt % STAGES) * STAGE;
+        const size_t koff = (size_t)kt * ROWB;
+        if (j < A_INSTR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j - A_INSTR] + koff),
+                                             (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * W_INSTR + j - A_INSTR) * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) issue_one(kt, j);
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    // fragment byte offsets inside a tile: row*64 + ((chunk ^ ((row>>3)&3)) << 4); rows = base + 32*i + frow
+    int a_off[KS], w_off[KS];
+    {
+        const int sw = swz(frow);                        // same for row and row + 32*i
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int ch = ((ks * 2 + fh) ^ sw) << 4;
+            a_off[ks] = (wr * (MT * 32) + frow) * ROWB + ch;
+            w_off[ks] = A_BYTES + (wc * (NT * 32) + frow) * ROWB + ch;
+        }
+    }
+
+    const int nk = g.K / BK;
+    constexpr int DIST = STAGES - 1;                     // prefetch distance in K-tiles
+    issue(0);
+    if (DIST > 1 && nk > 1) issue(1);
+    if (DIST > 2 && nk > 2) issue(2);
+
+    // Software pipeline at 16-deep k-step granularity with two named fragment sets: the MFMAs of one k-step run while
+    // the ds_read_b128 of the next k-step are in flight (LDS latency off the MFMA critical path).
+    vec8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
+    auto wait_tile = [&](int kt) {                       // this wave's DMA of tile kt has landed
+        const int newer = min(nk - 1 - kt, DIST - 1);    // tiles issued after kt that may still be in flight
+        if (DIST > 2 && newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (DIST > 1 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#define G2_READ(FA, FW, KT, KS_)                                                                              \
+    {                                                                                                         \
+        const char* st_ = smem + ((KT) % STAGES) * STAGE;                                                     \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i) FW[i] = *(const vec8*)(st_ + w_off[KS_] + i * (32 * ROWB)); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *(const vec8*)(st_ + a_off[KS_] + i * (32 * ROWB)); \
+    }
+#define G2_MMA(FA, FW)                                                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T16<T>::mfma32(FW[nt], FA[mt], acc[nt][mt]);
+
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (DIST < nk) issue(DIST);
+    G2_READ(fa0, fw0, 0, 0)
+    // The two waves that share a SIMD (wave i and wave i+4) issue their DMA bursts at DIFFERENT points of the
+    // iteration -- right after the barrier vs. after the first k-step pair -- so that one wave's DMA issue (tens of
+    // cycles per instruction) is covered by its sibling's MFMAs instead of both stalling the matrix pipe together.
+    const bool early = wave < 4;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int kp = 0; kp < KS / 2; ++kp) {            // k-step pair (2kp, 2kp+1): F0 holds step 2kp on entry
+            G2_READ(fa1, fw1, kt, 2 * kp + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            G2_MMA(fa0, fw0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (kp == 0 && !early && kt + DIST < nk && kt > 0) {
+                issue(kt + DIST);                        // late half: stage (kt+DIST)%STAGES == (kt-1)%STAGES, free since barrier kt
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kp + 1 < KS / 2) {
+                G2_READ(fa0, fw0, kt, 2 * kp + 2)
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (kt + 1 < nk) {
+                wait_tile(kt + 1);
+                // every ds_read of stage kt (incl. F1 above) must have completed before another wave may overwrite it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (early && kt + 1 + DIST < nk) issue(kt + 1 + DIST);   // into stage (kt+1+DIST) % STAGES == kt % STAGES
+                G2_READ(fa0, fw0, kt + 1, 0)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            G2_MMA(fa1, fw1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef G2_READ
+#undef G2_MMA
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wr * (MT * 32) + mt * 32 + frow;
+        if (m >= g.M) continue;
+        if constexpr (MODE == MODE_SWIGLU) {
+            static_assert(MODE != MODE_SWIGLU || NT == 2, "SwiGLU pairs the two 32-wide weight tiles of a wave");
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int nn = n0 + wc * (NT * 32) + q4 * 8 + fh * 4;
+                if (nn >= g.N) continue;
+                f32x4 gt, up;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gt[e] = acc[0][mt][q4 * 4 + e]; up[e] = acc[NT - 1][mt][q4 * 4 + e]; }
+                epilogue_swiglu_quad<T>(g, m, (n0 + wc * (NT * 32)) / 2 + q4 * 8 + fh * 4, gt, up);
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int n = n0 + wc * (NT * 32) + nt * 32 + q4 * 8 + fh * 4;
+                    if (n >= g.N) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][q4 * 4 + e];
+                    epilogue_quad<T, MODE>(g, m, n, v);
+                }
+        }
+    }
+}
+
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK>
+static int launch256(GemmArgs g, hipStream_t s) {
+    constexpr int lds = STAGES * (G2_BM * BK * 2 + BN * BK * 2);
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done = true;
+    }
+    g.tiles_m = ceil_div(g.M, G2_BM);
+    g.tiles_n = ceil_div(g.N, BN);
+    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
+    return (int)hipGetLastError();
+}
+
+bool gemm256_applicable(const GemmArgs& g, int mode) {
+    (void)mode;
+    return g.M >= 256 && g.N >= 128 && g.K % 64 == 0;
+}
+
+static int g_cfg = -1;      // VITG_GEMM_CFG pins the configuration (A/B measurements): 1 = 256x256x32 ring-4,
+                            // 2 = 256x128x32 ring-3 (2 blocks/CU), 3 = 256x256x64 ring-2
+
+template <typename T, int MODE>
+static int launch256_m(const GemmArgs& g, hipStream_t s) {
+    if (g_cfg < 0) { const char* e = getenv("VITG_GEMM_CFG"); g_cfg = e ? atoi(e) : 0; }
+    const int cfg = g_cfg ? g_cfg : 3;
+    if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
+    if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
+    return launch256<T, MODE, 256, 2, 2, 64>(g, s);
+}
+
+template <typename T>
+static int launch256_t(const GemmArgs& g, int mode, hipStream_t s) {
+    if (mode == MODE_SWIGLU) return launch256_m<T, MODE_SWIGLU>(g, s);
+    if (mode == MODE_F32) return launch256_m<T, MODE_F32>(g, s);
+    return launch256_m<T, MODE_STORE16>(g, s);
+}
+
+int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s) {
+    return dtype == DT_BF16 ? launch256_t<bf16_t>(g, mode, s) : launch256_t<f16_t>(g, mode, s);
+}
+
+}  // namespace vitg
