@@ -133,3 +133,32 @@ def test_model_object_surface(golden_dir):
     frame_idx = list(range(0, 80, 10))
     sel = sorted(frame_idx[i] for i in order[:3].tolist())
     assert sel == O.topk_selection(want, frame_idx, 3)
+
+
+def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
+    """The multi-GPU code path (frame shard + K/V all-gather over RCCL + logits all-gather) with a 1-rank NCCL group
+    must reproduce the single-GPU forward bit for bit (same kernels, keys gathered from one rank)."""
+    import socket
+    import torch.distributed as dist
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    from videoitg_amd.parallel import ContextParallel
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        cfg = tiny_config(vision_token_num=72)
+        sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+        eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+        pix = synth.synth_pixel_values(8, cfg.vision.image_size, seed=1234).cuda()
+        ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
+        a = eng.forward(ids, None, [pix])[0].view(-1).clone()
+        b = ContextParallel(0, 1).forward(eng, ids, pix)
+        torch.cuda.synchronize()
+        assert torch.equal(a.cpu(), b.cpu())
+    finally:
+        dist.destroy_process_group()

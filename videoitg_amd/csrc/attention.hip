@@ -13,6 +13,8 @@
 // Block = 4 waves x 32 queries = 128 queries; KV tile = 64 keys, double-buffered in LDS.
 #include "common.h"
 #include "../../include/videoitg_hip.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace vitg {
 
@@ -24,23 +26,31 @@ struct AttnArgs {
     int S;                           // number of queries
     int Sk;                          // number of keys (== S unless the keys were all-gathered from other ranks)
     int group;                       // q heads per kv head
+    int kv_heads, nqb;               // kv heads, q-blocks per head
+    int ablate;                      // profiling only (tools/attn_ablate.py): bit0 no QK^T, bit1 no exp, bit2 no PV, bit3 no K/V staging
     float scale_log2e;               // softmax scale * log2(e)
 };
 
-constexpr int ATT_BQ = 128, ATT_BK = 64, ATT_THREADS = 256;
+constexpr int ATT_BK = 64;
+// NW waves per block, 32 queries per wave: BQ = 32*NW queries share one K/V staging stream (NW = 8: 256 queries, 1 block/CU;
+// NW = 4: 128 queries, 2 blocks/CU)
 
 template <int D> struct AttnCfg;
 template <> struct AttnCfg<128> { static constexpr int DK = 128, DV = 128, LDK = 128, LDV = 128, CH = 16; };
-// K rows padded to 80 (zero d 72..79), V rows padded to 96 (pad never stored to the output)
-template <> struct AttnCfg<72> { static constexpr int DK = 80, DV = 96, LDK = 80, LDV = 96, CH = 9; };
+// K rows: 80 used (d 72..79 zero) at a row stride of 88 elements = 176 B: 176*r mod 256 takes 16 distinct 16-B slots
+// over the rows of every ds_read_b128 lane group -> conflict-free (160 B collided rows r and r+8: measured 35 % of LDS
+// cycles).  V rows padded to 96 (192 B, conflict-free for the tr reads; the pad is never stored to the output).
+template <> struct AttnCfg<72> { static constexpr int DK = 80, DV = 96, LDK = 88, LDV = 96, CH = 9; };
 
 template <int D> __device__ __forceinline__ int k_lds_off(int row, int chunk) {   // bytes
     if constexpr (D == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);
-    else return row * 160 + (chunk << 4);
+    else return row * 176 + (chunk << 4);
 }
 
-template <typename T, int D, bool TR>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
+template <typename T, int D, bool TR, int NW, bool ABL = false>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {
+    const int ablate = ABL ? a.ablate : 0;      // ablation switches exist only in the profiling instantiation
+    constexpr int ATT_THREADS = NW * 64, ATT_BQ = NW * 32;
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
     constexpr int KS = C::DK / 16;           // QK^T k-steps
@@ -51,9 +61,22 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
     // layout: [buf0: K | V][buf1: K | V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int kvh = head / a.group;
-    const int q0 = blockIdx.x * ATT_BQ + wave * 32;
+    // Block -> (batch, kv head, head-in-group, q-block).  Hardware block b runs on XCD b % 8 (private 4 MiB L2 each), so
+    // the ids are first made XCD-contiguous: all blocks that read the same K/V (the q-blocks of one kv head) then sit on
+    // ONE XCD and re-read K/V from its L2 instead of 8 XCDs each fetching their own copy from HBM (measured before the
+    // remap: ViT attention fetched 19.6 GB per launch = 8x the K/V bytes, 4.2 TB/s, HBM-bound).
+    int L;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int qb = L % a.nqb;
+    const int hg = (L / a.nqb) % a.group;
+    const int kvh = (L / (a.nqb * a.group)) % a.kv_heads;
+    const int b = L / (a.nqb * a.group * a.kv_heads);
+    const int head = kvh * a.group + hg;
+    const int q0 = qb * ATT_BQ + wave * 32;
 
     const T* Q = (const T*)a.q + b * a.q_bs + (long)head * a.q_hs;
     const T* K = (const T*)a.k + b * a.k_bs + (long)kvh * a.k_hs;
@@ -103,7 +126,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
             if (c < NCH) {
                 const int row = c / C::CH, ch = c % C::CH;
                 *(u32x4*)(kb + k_lds_off<D>(row, ch)) = rk[i];
-                *(u32x4*)(vb + row * (C::LDV * 2) + (ch << 4)) = rv[i];
+                // D=128: V rows are 256 B = one LDS bank row, so the 4 key rows of a tr-read block would collide 4-way;
+                // XOR the 64-B unit index with (row & 3) (read side: voff_dt)
+                const int vch = D == 128 ? (ch ^ ((row & 3) << 2)) : ch;
+                *(u32x4*)(vb + row * (C::LDV * 2) + (vch << 4)) = rv[i];
             }
         }
         if constexpr (D == 72) {
@@ -127,10 +153,22 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
     store_kv(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
+    // lane-dependent LDS offsets, hoisted: inside the loop every fragment address is one of these + an immediate
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = k_lds_off<D>(ql, ks * 2 + h);      // + t*32 rows: row&15 unchanged
+    // V via ds_read_b64_tr_b16: 16-lane group g = lane>>4 -> column block 16*(g&1); lane p = lane&15 supplies the address
+    // of row (p>>2), columns 4*(p&3)..+3 of a 4x16 block; the lane receives column (lane&15), rows 0..3.
+    const int voff = (4 * h + ((lane & 15) >> 2)) * (C::LDV * 2) + ((((lane >> 4) & 1) * 16) + 4 * (lane & 3)) * 2;
+    int voff_dt[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) voff_dt[dt] = voff + (D == 128 ? ((dt ^ ((lane & 15) >> 2)) * 64) : dt * 64);
+
+    auto tile = [&](int kt, auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;
+        const bool more = kt + 1 < nkt && !(ablate & 8);
         if (more) load_kv(kt + 1);
-        const char* kb = smem + (kt & 1) * (KT_BYTES + VT_BYTES);
+        const char* kb = smem + BUF * (KT_BYTES + VT_BYTES);
         const char* vb = kb + KT_BYTES;
 
         // ---- S^T = K Q^T : two 32-key tiles ------------------------------------------------------------
@@ -139,10 +177,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            if (!(ablate & 1)) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const vec8 kf = *(const vec8*)(kb + k_lds_off<D>(t * 32 + ql, ks * 2 + h));
-                s[t] = T16<T>::mfma32(kf, qf[ks], s[t]);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const vec8 kf = *(const vec8*)(kb + koff[ks] + t * 32 * (C::LDK * 2));
+                    s[t] = T16<T>::mfma32(kf, qf[ks], s[t]);
+                }
             }
         }
         // lane (q = ql, h): s[t][r] is key  kt*64 + t*32 + 8*(r>>2) + 4*h + (r&3)
@@ -164,39 +204,41 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;      // scale > 0
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        // exact deferral: when no query of this wave saw its running max grow, alpha == 1 for every lane and the
+        // rescale of O and l (the widest VALU block of the tile) is skipped
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            m_run = m_new;
+        }
         float psum = 0.f;
         vec8 pf[4];                      // k-step kk = 2*t + u uses s[t][8u .. 8u+7]
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], a.scale_log2e, -m_new));
+                const float p = (ablate & 2) ? s[t][r] : __builtin_amdgcn_exp2f(fmaf(s[t][r], a.scale_log2e, -m_run));
                 psum += p;
                 pf[t * 2 + (r >> 3)][r & 7] = T16<T>::from_f32(p);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T ----------------------------------------------------------------------------
         // k-step kk (16 keys: tile t = kk>>1, half u = kk&1): slot (h, j) <-> key t*32 + u*16 + 8*(j>>2) + 4*h + (j&3)
         // A operand lane (d = dt*32 + ql, h) needs V[key(h, j)][d] for j = 0..7: two groups of 4 consecutive keys.
+        if (!(ablate & 4))
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int kbase = (kk >> 1) * 32 + (kk & 1) * 16 + 4 * h;
+            const int krow = (kk >> 1) * 32 + (kk & 1) * 16;             // + 4*h inside voff
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 vec8 vf;
                 if constexpr (TR) {
-                    // 16-lane group g = lane>>4: column block 16*(g&1); lane p = lane&15 supplies the address of
-                    // row (p>>2), columns 4*(p&3)..+3 of the 4x16 block; result: lane gets column (lane&15), rows 0..3.
-                    const int p = lane & 15, cb = ((lane >> 4) & 1) * 16;
-                    const int col = dt * 32 + cb + 4 * (p & 3);
-                    const char* a0 = vb + (kbase + (p >> 2)) * (C::LDV * 2) + col * 2;
+                    const char* a0 = vb + voff_dt[dt] + krow * (C::LDV * 2);
                     const char* a1 = a0 + 8 * (C::LDV * 2);
                     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
                     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
@@ -206,14 +248,22 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
                     const T* vt = (const T*)vb;
                     const int d = dt * 32 + ql;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) vf[j] = vt[(kbase + 8 * (j >> 2) + (j & 3)) * C::LDV + d];
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = krow + 4 * h + 8 * (j >> 2) + (j & 3);
+                        const int dd = D == 128 ? (d ^ ((row & 3) << 5)) : d;      // same 64-B-unit swizzle, in elements
+                        vf[j] = vt[row * C::LDV + dd];
+                    }
                 }
                 o[dt] = T16<T>::mfma32(vf, pf[kk], o[dt]);
             }
         }
 
-        if (more) store_kv((kt + 1) & 1);
+        if (more) store_kv(BUF ^ 1);
         __syncthreads();
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: lane (q, h) holds O[q][dt*32 + 8*(r>>2) + 4*h + (r&3)] -------------------------------
@@ -237,17 +287,18 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, int D, bool TR>
-static int launch_attn(const AttnArgs& a, int batch, int heads, hipStream_t s) {
+template <typename T, int D, bool TR, int NW, bool ABL = false>
+static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
+    a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
     const size_t lds = 2 * (ATT_BK * C::LDK * 2 + ATT_BK * C::LDV * 2);
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute((const void*)attn_kernel<T, D, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)attn_kernel<T, D, TR, NW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         done = true;
     }
-    dim3 grid(ceil_div(a.S, ATT_BQ), heads, batch);
-    hipLaunchKernelGGL((attn_kernel<T, D, TR>), grid, dim3(ATT_THREADS), lds, s, a);
+    dim3 grid(ceil_div(a.S, NW * 32) * heads * batch);
+    hipLaunchKernelGGL((attn_kernel<T, D, TR, NW, ABL>), grid, dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -271,12 +322,25 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
     a.q_rs = q_rs; a.k_rs = k_rs; a.v_rs = v_rs; a.o_rs = o_rs;
     a.q_hs = q_hs; a.k_hs = k_hs; a.v_hs = v_hs; a.o_hs = o_hs;
-    a.S = S; a.Sk = Sk; a.group = heads / kv_heads;
+    a.S = S; a.Sk = Sk; a.group = heads / kv_heads; a.kv_heads = kv_heads; a.nqb = 0;
     a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    const bool tr = variant != 1;     // variant 1 = scalar LDS reads of V (cross-check path for the tr-read)
-#define GO(T, D) (tr ? launch_attn<T, D, true>(a, batch, heads, s) : launch_attn<T, D, false>(a, batch, heads, s))
+    a.ablate = variant >> 4;
+    variant &= 15;
+    const bool tr = variant != 1;
+    if (!tr) { }     // variant 1 = scalar LDS reads of V (cross-check path for the tr-read)
+    // waves per block: 8 (256 queries share one K/V stream) measured faster for the long LLM sequence, 4 for the
+    // short SigLIP sequences; VITG_ATTN_WAVES=4|8 pins it for A/B measurements
+    static int nw_env = -1;
+    if (nw_env < 0) { const char* e = getenv("VITG_ATTN_WAVES"); nw_env = e ? atoi(e) : 0; }
+    const int nw = nw_env ? nw_env : (head_dim == 128 ? 8 : 4);
+    if (a.ablate) {   // profiling instantiations (fp16 only)
+        if (dtype != DT_F16) return VITG_ERR_ARG;
+        rc = head_dim == 72 ? launch_attn<f16_t, 72, true, 4, true>(a, batch, heads, s) : launch_attn<f16_t, 128, true, 8, true>(a, batch, heads, s);
+        return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+    }
+#define GO(T, D) (!tr ? launch_attn<T, D, false, 4>(a, batch, heads, s) : nw == 4 ? launch_attn<T, D, true, 4>(a, batch, heads, s) : launch_attn<T, D, true, 8>(a, batch, heads, s))
     if (dtype == DT_BF16) rc = head_dim == 72 ? GO(bf16_t, 72) : GO(bf16_t, 128);
     else rc = head_dim == 72 ? GO(f16_t, 72) : GO(f16_t, 128);
 #undef GO

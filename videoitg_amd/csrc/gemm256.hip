@@ -172,27 +172,19 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
 #undef G2_MMA
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
+    if constexpr (MODE == MODE_F32) {
+        // fp32 residual update: a lane already owns 16 contiguous bytes per accumulator quad; direct read-modify-write
+        // measured faster than staging (the staged form serialises LDS round trip + residual load latency per pass).
+        const int frow_ = lane & 31, fh_ = lane >> 5;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wr * (MT * 32) + mt * 32 + frow;
-        if (m >= g.M) continue;
-        if constexpr (MODE == MODE_SWIGLU) {
-            static_assert(MODE != MODE_SWIGLU || NT == 2, "SwiGLU pairs the two 32-wide weight tiles of a wave");
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int nn = n0 + wc * (NT * 32) + q4 * 8 + fh * 4;
-                if (nn >= g.N) continue;
-                f32x4 gt, up;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { gt[e] = acc[0][mt][q4 * 4 + e]; up[e] = acc[NT - 1][mt][q4 * 4 + e]; }
-                epilogue_swiglu_quad<T>(g, m, (n0 + wc * (NT * 32)) / 2 + q4 * 8 + fh * 4, gt, up);
-            }
-        } else {
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wr * (MT * 32) + mt * 32 + frow_;
+            if (m >= g.M) continue;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const int n = n0 + wc * (NT * 32) + nt * 32 + q4 * 8 + fh * 4;
+                    const int n = n0 + wc * (NT * 32) + nt * 32 + q4 * 8 + fh_ * 4;
                     if (n >= g.N) continue;
                     f32x4 v;
 #pragma unroll
@@ -200,6 +192,12 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
                     epilogue_quad<T, MODE>(g, m, n, v);
                 }
         }
+    } else {
+        // 16-bit outputs: transposed through wave-private LDS into full-row 16-B stores (gemm_common.h)
+        __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring before it is reused
+        constexpr int STAGE_BYTES = MT * 32 * (MODE == MODE_SWIGLU ? 1 : NT) * 64;
+        static_assert(8 * STAGE_BYTES <= STAGES * STAGE, "epilogue staging must fit in the ring");
+        epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
     }
 }
 
@@ -219,7 +217,9 @@ static int launch256(GemmArgs g, hipStream_t s) {
 
 bool gemm256_applicable(const GemmArgs& g, int mode) {
     (void)mode;
-    return g.M >= 256 && g.N >= 128 && g.K % 64 == 0;
+    // staged epilogue: 16-B row stores need 16-B aligned rows (8 halfs / 4 floats)
+    const bool aligned = g.ldo % 8 == 0 && (g.res == nullptr || g.ldr % 4 == 0) && g.N % 8 == 0;
+    return g.M >= 256 && g.N >= 128 && g.K % 64 == 0 && aligned;
 }
 
 static int g_cfg = -1;      // VITG_GEMM_CFG pins the configuration (A/B measurements): 1 = 256x256x32 ring-4,

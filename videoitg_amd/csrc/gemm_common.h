@@ -67,6 +67,111 @@ __device__ __forceinline__ void epilogue_swiglu_quad(const GemmArgs& g, int m, i
     *(typename T16<T>::vec4*)((T*)g.out + (size_t)m * g.ldo + no) = v;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-staged epilogue of one wave's (MT*32) x (NT*32) accumulator tile.  The MFMA C layout gives a lane 4 consecutive
+// features of ONE token row, i.e. a store instruction would touch 32 different rows with 16 bytes each.  Instead the
+// wave transposes its tile through a private LDS region (XOR-swizzled 16-B chunks) and writes whole rows: 16 B per
+// lane, consecutive lanes on consecutive addresses, full 128-B lines.  Bias / activation / SwiGLU are applied in
+// registers before staging; the fp32 residual is added on the coalesced side.
+//   acc[nt][mt][r]: m = m_base + mt*32 + (lane&31), n = n_base + nt*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+// `stage` = this wave's private LDS (>= MT*32*NT*64 bytes for 16-bit output, >= 32*NT*128 bytes for fp32 output).
+// Requires out/res leading dimensions and n_base to keep 16-B alignment (checked by the host code).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int MODE, int MT, int NT>
+__device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)[NT][MT], char* stage, int m_base, int n_base,
+                                                int lane) {
+    const int frow = lane & 31, fh = lane >> 5;
+    if constexpr (MODE == MODE_F32) {
+        constexpr int CH = NT * 8;                        // 16-B chunks (4 floats) per row
+        constexpr int RB = NT * 128;                      // row bytes
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][q4 * 4 + e];
+                    const int n = n_base + nt * 32 + q4 * 8 + fh * 4;
+                    if (g.bias && n < g.N) v += *(const f32x4*)(g.bias + n);
+                    if (g.act == VITG_ACT_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                    } else if (g.act == VITG_ACT_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                    }
+                    const int c = nt * 8 + q4 * 2 + fh;
+                    *(f32x4*)(stage + frow * RB + ((c ^ (frow & (CH - 1))) << 4)) = v;
+                }
+            // same wave reads back what it wrote: LDS ops of one wave complete in order, no barrier needed
+#pragma unroll
+            for (int i = 0; i < 32 * CH / 64; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / CH, c = idx % CH;
+                f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4));
+                const int m = m_base + mt * 32 + row, n = n_base + c * 4;
+                if (m < g.M && n < g.N) {
+                    if (g.res) {
+                        const int rm = g.res_mod > 0 ? m % g.res_mod : m;
+                        v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+                    }
+                    *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
+                }
+            }
+        }
+    } else {
+        constexpr int NTO = MODE == MODE_SWIGLU ? 1 : NT;  // output 32-column tiles per wave
+        constexpr int CH = NTO * 4;                        // 16-B chunks (8 halfs) per row
+        constexpr int RB = NTO * 64;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v;
+                    if constexpr (MODE == MODE_SWIGLU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[0][mt][q4 * 4 + e]) * acc[NT - 1][mt][q4 * 4 + e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][q4 * 4 + e];
+                        const int n = n_base + nt * 32 + q4 * 8 + fh * 4;
+                        if (g.bias && n < g.N) v += *(const f32x4*)(g.bias + n);
+                        if (g.act == VITG_ACT_GELU_TANH) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                        } else if (g.act == VITG_ACT_GELU_ERF) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                        }
+                    }
+                    typename T16<T>::vec4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
+                    const int row = mt * 32 + frow, c = nt * 4 + q4;
+                    *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4) + fh * 8) = o;
+                }
+        const int n_out = MODE == MODE_SWIGLU ? n_base / 2 : n_base;
+        const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
+#pragma unroll
+        for (int i = 0; i < MT * 32 * CH / 64; ++i) {
+            const int idx = i * 64 + lane;
+            const int row = idx / CH, c = idx % CH;
+            const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4));
+            const int m = m_base + row, n = n_out + c * 8;
+            if (m < g.M) {
+                T* dst = (T*)g.out + (size_t)m * g.ldo + n;
+                if (n + 8 <= n_lim) *(u32x4*)dst = v;
+                else if (n + 4 <= n_lim) *(u32x2*)dst = u32x2{v[0], v[1]};
+            }
+        }
+    }
+}
+
 int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s);   // gemm256.hip
 bool gemm256_applicable(const GemmArgs& g, int mode);
 
