@@ -162,3 +162,35 @@ def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
         assert torch.equal(a.cpu(), b.cpu())
     finally:
         dist.destroy_process_group()
+
+
+def test_full_width_reduced_depth_parity():
+    """Real layer widths (SigLIP 1152/4304/16x72, Qwen2 3584/18944, 28 q / 4 kv heads x128, pos-emb interpolation to a
+    non-native grid, 16->10 token pool) at reduced depth / frame count so the fp32 oracle finishes on the host: every
+    production kernel instantiation (hd 72 and hd 128 attention, 256x256 persistent GEMM incl. K=4352/18944, SwiGLU,
+    LN/RMS at 1152/3584) is on this path."""
+    from oracle import quant_model as QM
+    from oracle import videoitg_oracle as O
+    from videoitg_amd import ops, synth
+    from videoitg_amd.config import ITGConfig, VisionConfig
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    cfg = ITGConfig(vocab_size=2048, num_hidden_layers=2, vision_token_num=1600,
+                    vision=VisionConfig(image_size=384, num_hidden_layers=3))
+    T, R = 16, 224                                               # 16x16 grid from a 27x27 table -> bicubic resample
+    sd, vsd = synth.synth_llm_state_dict(cfg, 3), synth.synth_vision_state_dict(cfg, 3)
+    pix = synth.synth_pixel_values(T, R, seed=77)
+    ids = torch.cat([torch.tensor([-200]), synth.synth_prompt_ids(60, cfg.vocab_size)]).unsqueeze(0)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    want = O.forward(cfg, sd, vsd, ids, None, [pix])[0].view(-1)
+    floor = (torch.sigmoid(QM.forward(cfg, sd, vsd, ids, None, [pix], dtype=torch.float16)[0].view(-1)) - torch.sigmoid(want)).abs().max().item()
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    got = eng.forward(ids, None, [pix.cuda()])[0].view(-1).float().cpu()
+    d = (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item()
+    print(f"full-width: max|dscore|={d:.2e} max|dlogit|={(got - want).abs().max().item():.2e} rounding floor {floor:.2e}; "
+          f"logit range [{want.min():.2f}, {want.max():.2f}]")
+    assert d <= max(SCORE_TOL, 2 * floor), (d, floor)
+    _, order = ops.rank(got.cuda())
+    sref, oref = torch.sort(torch.sigmoid(want), descending=True, stable=True)
+    for k in range(1, T):
+        if (sref[k - 1] - sref[k]).item() > 2.5 * max(SCORE_TOL, floor):
+            assert set(order[:k].cpu().tolist()) == set(oref[:k].tolist()), k

@@ -207,7 +207,8 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
-    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN);
+    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0;
+    { static int fl = -1; if (fl < 0) { const char* e = getenv("VITG_GEMM_FLAGS"); fl = e ? atoi(e) : 0; } g.flags = fl; }
     hipStream_t s = (hipStream_t)stream;
     static int force = -1;          // VITG_GEMM_TILE=128|256 pins the kernel (A/B measurements); default: auto
     if (force < 0) { const char* e = getenv("VITG_GEMM_TILE"); force = e ? atoi(e) : 0; }

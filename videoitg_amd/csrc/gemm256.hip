@@ -201,6 +201,229 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent variant of the 256x256x64 ring-2 configuration: one block per CU walks a static, XCD-contiguous list of
+// tiles.  The K-tile ring simply continues across tile boundaries (the last iteration of a tile prefetches K-tile 0 of the
+// next one), so there is no per-tile block launch, no address set-up stall and no pipeline refill; the epilogue's stores
+// drain while the next tile's first K-tile is already in LDS.  Requires an even number of K-tiles (stage parity).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void linear_to_tile(int L, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+    const int per_group = gm * tiles_n;
+    const int grp = L / per_group;
+    const int first_m = grp * gm;
+    const int gsz = min(tiles_m - first_m, gm);
+    const int in_g = L - grp * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm256p_kernel(GemmArgs g) {
+    typedef typename T16<T>::vec8 vec8;
+    constexpr int BN = 256, BK = 64, MT = 4, NT = 2, KS = 4, ROWB = 128, CPR = 8, RPI = 8;
+    constexpr int A_BYTES = G2_BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+    constexpr int A_INSTR = 4, W_INSTR = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const bool early = wave < 4;
+
+    // ---- static tile schedule: XCD x = bid % 8 owns a contiguous chunk of the (grouped) tile order ------------------
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int chunk0 = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int chunkn = cq + (xcd < cr ? 1 : 0);
+    if (slot >= chunkn) return;                         // whole block exits together
+
+    const int drow = lane / CPR, dslot = lane % CPR;
+    // Source addressing = wave-uniform 64-bit tile base (SGPRs) + per-lane 32-bit byte offset inside the tile (one VGPR per
+    // DMA instruction): half the address registers of per-lane pointers, and the saddr+voffset form needs no VALU.
+    const char* a_base; const char* w_base;              // uniform: A + m0*lda*2, W + n0*ldw*2
+    unsigned a_cur[A_INSTR], w_cur[W_INSTR];
+    auto set_src = [&](int L, int& m0, int& n0) {
+        int tm, tn;
+        linear_to_tile(L, g.tiles_m, g.tiles_n, 8, tm, tn);
+        m0 = tm * G2_BM;
+        n0 = tn * BN;
+        a_base = (const char*)g.A + (size_t)m0 * g.lda * 2;
+        w_base = (const char*)g.W + (size_t)n0 * g.ldw * 2;
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) {
+            const int R = (wave * A_INSTR + j) * RPI + drow;
+            a_cur[j] = (unsigned)(min(R, g.M - 1 - m0) * g.lda + ((dslot ^ ((R >> 1) & 7)) << 3)) * 2u;
+        }
+#pragma unroll
+        for (int j = 0; j < W_INSTR; ++j) {
+            const int R = (wave * W_INSTR + j) * RPI + drow;
+            w_cur[j] = (unsigned)(min(R, g.N - 1 - n0) * g.ldw + ((dslot ^ ((R >> 1) & 7)) << 3)) * 2u;
+        }
+    };
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * STAGE;
+        const char* ab = a_base + (size_t)kt * ROWB;
+        const char* wb = w_base + (size_t)kt * ROWB;
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + a_cur[j]),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < W_INSTR; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + w_cur[j]),
+                                             (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * W_INSTR + j) * 1024), 16, 0, 0);
+    };
+
+    const int frow = lane & 31, fh = lane >> 5;
+    int a_off[KS], w_off[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int ch = ((ks * 2 + fh) ^ ((frow >> 1) & 7)) << 4;
+        a_off[ks] = (wr * 128 + frow) * ROWB + ch;
+        w_off[ks] = A_BYTES + (wc * 64 + frow) * ROWB + ch;
+    }
+    const int nk = g.K / BK;                            // even (checked by the host)
+
+    // ONE live set of source offsets: it is switched to the next tile at the moment the ring wraps (the current tile has
+    // no DMA left to issue by then); the epilogue only needs the tile origin (m0, n0), kept separately.
+    int m0, n0, m0n = 0, n0n = 0;
+    int it = slot;
+    set_src(chunk0 + it, m0, n0);
+    // De-phase the XCDs.  Every tile takes the same time, so without this all 256 CUs reach their epilogue together:
+    // HBM idles during the main loops and then saturates on a 33 MB write burst (measured: time = MFMA time + output bytes /
+    // ~3 TB/s, i.e. no overlap at all).  Delaying XCD x by x/8 of a tile period spreads the bursts evenly while the 32
+    // blocks of one XCD stay in lockstep and keep sharing operand panels in their L2.
+    if (g.stagger_ns > 0 && xcd > 0) {
+        const unsigned long long t0 = wall_clock64();                      // 100 MHz
+        const unsigned long long ticks = (unsigned long long)g.stagger_ns * xcd / 80;   // ns -> 10-ns ticks, x/8
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    }
+    issue(0);
+
+#define GP_READ(FA, FW, KT, KS_)                                                                              \
+    {                                                                                                         \
+        const char* st_ = smem + ((KT) & 1) * STAGE;                                                          \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i) FW[i] = *(const vec8*)(st_ + w_off[KS_] + i * (32 * ROWB)); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *(const vec8*)(st_ + a_off[KS_] + i * (32 * ROWB)); \
+    }
+#define GP_MMA(FA, FW)                                                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T16<T>::mfma32(FW[nt], FA[mt], acc[nt][mt]);
+
+    bool first = true;
+    while (true) {
+        const bool has_next = it + per_xcd < chunkn;
+        f32x16 acc[NT][MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        vec8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
+
+        // K-tile 0 of this tile has landed: the prologue waits for it below, and later tiles wait for it BEFORE the previous
+        // tile's epilogue (vmcnt is in-order and counts stores, so waiting here would also drain the epilogue's stores;
+        // waiting before them lets the stores retire underneath the first iteration instead).
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(1);                                        // every wave (the late half starts staggering at kt = 1); nk >= 4
+        GP_READ(fa0, fw0, 0, 0)
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int kp = 0; kp < KS / 2; ++kp) {
+                GP_READ(fa1, fw1, kt, 2 * kp + 1)
+                __builtin_amdgcn_sched_barrier(0);
+                GP_MMA(fa0, fw0)
+                __builtin_amdgcn_sched_barrier(0);
+                if (kp == 0 && !early && kt > 0) {       // late half: K-tile kt+1 (possibly K-tile 0 of the next tile)
+                    if (kt + 1 < nk) issue(kt + 1);
+                    else if (has_next) { set_src(chunk0 + it + per_xcd, m0n, n0n); issue(0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kp + 1 < KS / 2) {
+                    GP_READ(fa0, fw0, kt, 2 * kp + 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (kt + 1 < nk) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (early) {                          // early half: K-tile kt+2 (possibly K-tile 0 of the next tile)
+                        if (kt + 2 < nk) issue(kt + 2);
+                        else if (has_next) { set_src(chunk0 + it + per_xcd, m0n, n0n); issue(0); }
+                    }
+                    GP_READ(fa0, fw0, kt + 1, 0)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                GP_MMA(fa1, fw1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // nk == 1 cannot happen (nk even); for nk == 2 the late half issued nothing at kt == 0: handled because early/late
+        // both cover "tile kt+1 during iteration kt" for kt >= 1 and the prologue/previous tile covered tile 1... see host check nk >= 4.
+
+        // ---- epilogue (stage 1 = last K-tile's stage is free after the barrier; stage 0 holds the next tile's K-tile 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile's K-tile 0 (issued during the last iteration) landed
+        if constexpr (MODE == MODE_F32) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + wr * 128 + mt * 32 + frow;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int n = n0 + wc * 64 + nt * 32 + q4 * 8 + fh * 4;
+                        if (n >= g.N) continue;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][q4 * 4 + e];
+                        epilogue_quad<T, MODE>(g, m, n, v);
+                    }
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // all waves finished reading stage 1
+            char* stg = smem + STAGE + wave * 8192;     // 8 KiB per wave inside stage 1
+            epilogue_staged<T, MODE, MT, NT, 0, 2>(g, acc, stg, m0 + wr * 128, n0 + wc * 64, lane);
+            epilogue_staged<T, MODE, MT, NT, 2, 2>(g, acc, stg, m0 + wr * 128 + 64, n0 + wc * 64, lane);
+        }
+        if (!has_next) break;
+        it += per_xcd;
+        m0 = m0n;
+        n0 = n0n;
+    }
+#undef GP_READ
+#undef GP_MMA
+}
+
+template <typename T, int MODE>
+static int launch256p(GemmArgs g, hipStream_t s) {
+    constexpr int lds = 2 * (G2_BM * 128 + 256 * 128);
+    static bool done = false;
+    static int cus = 256;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount & ~7;
+        done = true;
+    }
+    g.tiles_m = ceil_div(g.M, G2_BM);
+    g.tiles_n = ceil_div(g.N, 256);
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int grid = ntiles >= cus ? cus : ((ntiles + 7) & ~7);
+    // one tile period ~ 1.15 us per 64-deep K-tile (measured main-loop rate) + epilogue; only worth it with several rounds
+    static int stag = -1;
+    if (stag < 0) { const char* e = getenv("VITG_GEMM_STAGGER"); stag = e ? atoi(e) : 1; }
+    g.stagger_ns = (stag && ntiles >= 4 * cus) ? (g.K / 64) * 1150 + 4000 : 0;
+    hipLaunchKernelGGL((gemm256p_kernel<T, MODE>), dim3(grid), dim3(G2_THREADS), lds, s, g);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int MODE, int BN, int WM, int STAGES, int BK>
 static int launch256(GemmArgs g, hipStream_t s) {
     constexpr int lds = STAGES * (G2_BM * BK * 2 + BN * BK * 2);
@@ -228,8 +451,9 @@ static int g_cfg = -1;      // VITG_GEMM_CFG pins the configuration (A/B measure
 template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     if (g_cfg < 0) { const char* e = getenv("VITG_GEMM_CFG"); g_cfg = e ? atoi(e) : 0; }
-    const int cfg = g_cfg ? g_cfg : 3;
+    const int cfg = g_cfg ? g_cfg : 4;                  // 4 = persistent 256x256x64 (default)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
+    if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
     return launch256<T, MODE, 256, 2, 2, 64>(g, s);
 }

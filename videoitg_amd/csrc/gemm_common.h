@@ -14,6 +14,8 @@ struct GemmArgs {
     void* out; int ldo;       // mode STORE16/SWIGLU: T16*, mode F32: float*
     const float* res; int ldr; int res_mod;   // mode F32: out = acc + bias + res[(m % res_mod), n] (res may be null)
     int tiles_m, tiles_n;
+    int stagger_ns;           // persistent kernel: tile period estimate for de-phasing the XCDs (0 = off)
+    int flags;                // bit0: non-temporal output stores, bit1: (profiling) skip output stores
 };
 
 enum { MODE_STORE16 = 0, MODE_F32 = 1, MODE_SWIGLU = 2 };
@@ -78,15 +80,16 @@ __device__ __forceinline__ void epilogue_swiglu_quad(const GemmArgs& g, int m, i
 // `stage` = this wave's private LDS (>= MT*32*NT*64 bytes for 16-bit output, >= 32*NT*128 bytes for fp32 output).
 // Requires out/res leading dimensions and n_base to keep 16-B alignment (checked by the host code).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int MODE, int MT, int NT>
+template <typename T, int MODE, int MT, int NT, int MT0 = 0, int MTN = MT>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)[NT][MT], char* stage, int m_base, int n_base,
                                                 int lane) {
+    // processes accumulator row-tiles mt in [MT0, MT0 + MTN); m_base is the row of mt = MT0
     const int frow = lane & 31, fh = lane >> 5;
     if constexpr (MODE == MODE_F32) {
         constexpr int CH = NT * 8;                        // 16-B chunks (4 floats) per row
         constexpr int RB = NT * 128;                      // row bytes
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = MT0; mt < MT0 + MTN; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -112,7 +115,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                 const int idx = i * 64 + lane;
                 const int row = idx / CH, c = idx % CH;
                 f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4));
-                const int m = m_base + mt * 32 + row, n = n_base + c * 4;
+                const int m = m_base + (mt - MT0) * 32 + row, n = n_base + c * 4;
                 if (m < g.M && n < g.N) {
                     if (g.res) {
                         const int rm = g.res_mod > 0 ? m % g.res_mod : m;
@@ -127,7 +130,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
         constexpr int CH = NTO * 4;                        // 16-B chunks (8 halfs) per row
         constexpr int RB = NTO * 64;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = MT0; mt < MT0 + MTN; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTO; ++nt)
 #pragma unroll
@@ -152,21 +155,24 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                     typename T16<T>::vec4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
-                    const int row = mt * 32 + frow, c = nt * 4 + q4;
+                    const int row = (mt - MT0) * 32 + frow, c = nt * 4 + q4;
                     *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4) + fh * 8) = o;
                 }
         const int n_out = MODE == MODE_SWIGLU ? n_base / 2 : n_base;
         const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
 #pragma unroll
-        for (int i = 0; i < MT * 32 * CH / 64; ++i) {
+        for (int i = 0; i < MTN * 32 * CH / 64; ++i) {
             const int idx = i * 64 + lane;
             const int row = idx / CH, c = idx % CH;
             const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4));
             const int m = m_base + row, n = n_out + c * 8;
             if (m < g.M) {
                 T* dst = (T*)g.out + (size_t)m * g.ldo + n;
-                if (n + 8 <= n_lim) *(u32x4*)dst = v;
-                else if (n + 4 <= n_lim) *(u32x2*)dst = u32x2{v[0], v[1]};
+                if (g.flags & 2) continue;
+                if (n + 8 <= n_lim) {
+                    if (g.flags & 1) __builtin_nontemporal_store(v, (u32x4*)dst);
+                    else *(u32x4*)dst = v;
+                } else if (n + 4 <= n_lim) *(u32x2*)dst = u32x2{v[0], v[1]};
             }
         }
     }
