@@ -116,6 +116,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
     // the ds_read_b128 of the next k-step are in flight (LDS latency off the MFMA critical path).
     vec8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
     auto wait_tile = [&](int kt) {                       // this wave's DMA of tile kt has landed
+        if (g.flags & 4) return;                         // profiling only: results are wrong, shows the DMA-wait share
         const int newer = min(nk - 1 - kt, DIST - 1);    // tiles issued after kt that may still be in flight
         if (DIST > 2 && newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
         else if (DIST > 1 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
@@ -128,8 +129,10 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
         _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *(const vec8*)(st_ + a_off[KS_] + i * (32 * ROWB)); \
     }
 #define G2_MMA(FA, FW)                                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                         \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T16<T>::mfma32(FW[nt], FA[mt], acc[nt][mt]);
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T16<T>::mfma32(FW[nt], FA[mt], acc[nt][mt]); \
+    __builtin_amdgcn_s_setprio(0);
 
     wait_tile(0);
     __builtin_amdgcn_s_barrier();
@@ -307,8 +310,10 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256p_kernel(GemmArgs g) {
         _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *(const vec8*)(st_ + a_off[KS_] + i * (32 * ROWB)); \
     }
 #define GP_MMA(FA, FW)                                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                         \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T16<T>::mfma32(FW[nt], FA[mt], acc[nt][mt]);
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T16<T>::mfma32(FW[nt], FA[mt], acc[nt][mt]); \
+    __builtin_amdgcn_s_setprio(0);
 
     bool first = true;
     while (true) {
@@ -418,7 +423,7 @@ static int launch256p(GemmArgs g, hipStream_t s) {
     const int grid = ntiles >= cus ? cus : ((ntiles + 7) & ~7);
     // one tile period ~ 1.15 us per 64-deep K-tile (measured main-loop rate) + epilogue; only worth it with several rounds
     static int stag = -1;
-    if (stag < 0) { const char* e = getenv("VITG_GEMM_STAGGER"); stag = e ? atoi(e) : 1; }
+    if (stag < 0) { const char* e = getenv("VITG_GEMM_STAGGER"); stag = e ? atoi(e) : 0; }   // default off: measured no gain (A/B in profiles/r01_gemm_shapes.md)
     g.stagger_ns = (stag && ntiles >= 4 * cus) ? (g.K / 64) * 1150 + 4000 : 0;
     hipLaunchKernelGGL((gemm256p_kernel<T, MODE>), dim3(grid), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
@@ -451,7 +456,7 @@ static int g_cfg = -1;      // VITG_GEMM_CFG pins the configuration (A/B measure
 template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     if (g_cfg < 0) { const char* e = getenv("VITG_GEMM_CFG"); g_cfg = e ? atoi(e) : 0; }
-    const int cfg = g_cfg ? g_cfg : 4;                  // 4 = persistent 256x256x64 (default)
+    const int cfg = g_cfg ? g_cfg : 3;                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
