@@ -42,6 +42,11 @@ int vitg_version(void);
  * compute-unit count, or a negative error when no HIP device is usable. */
 int vitg_device_info(char* name, int name_len);
 
+/* Kernel-selection knobs for A/B measurements and tests (defaults come from the environment variables VITG_GEMM_TILE,
+ * VITG_GEMM_CFG, VITG_GEMM_FLAGS, VITG_GEMM_STAGGER, VITG_ATTN_WAVES).  key: "gemm_tile" (0 auto | 128 | 256), "gemm_cfg"
+ * (0 auto | 1..4), "gemm_flags", "gemm_stagger", "attn_waves" (0 auto | 4 | 8).  Host-only, no GPU needed. */
+int vitg_set_option(const char* key, int value);
+
 /* A0[T*G*G, Kpad] (16-bit) = im2col of pixel_values [T,3,R,R] NCHW (pix_dtype VITG_F32/F16/BF16), k ordered
  * (c,ky,kx) like the conv weight [Dv,3,p,p] flattened, zero for k >= 3*p*p.
  * Replaces the unfold half of [3P] SiglipVisionEmbeddings.patch_embedding (cuDNN conv2d), reached from

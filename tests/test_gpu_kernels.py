@@ -21,6 +21,27 @@ def ops():
     return o
 
 
+@pytest.fixture(params=["auto", "tile128", "cfg1_256x256x32", "cfg2_256x128x32", "cfg3_256x256x64", "cfg4_persistent"])
+def gemm_cfg(request, ops):
+    """Every GEMM kernel configuration is forced in turn (vitg_set_option), so the 256-tile kernels are covered at test
+    sizes too (auto mode would pick the 128 tile for them)."""
+    name = request.param
+    tile, cfg = {"auto": (0, 0), "tile128": (128, 0), "cfg1_256x256x32": (256, 1), "cfg2_256x128x32": (256, 2),
+                 "cfg3_256x256x64": (256, 3), "cfg4_persistent": (256, 4)}[name]
+    ops.set_option("gemm_tile", tile)
+    ops.set_option("gemm_cfg", cfg)
+    yield name
+    ops.set_option("gemm_tile", 0)
+    ops.set_option("gemm_cfg", 0)
+
+
+@pytest.fixture(params=[0, 4, 8])
+def attn_waves(request, ops):
+    ops.set_option("attn_waves", request.param)
+    yield request.param
+    ops.set_option("attn_waves", 0)
+
+
 def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(dtype).float()
@@ -28,8 +49,8 @@ def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 432, 192), (1000, 1152, 640), (257, 3584, 1152), (77, 256, 4352),
-                                   (2048, 1024, 512)])
-def test_gemm_store16_bias_act(ops, dtype, M, N, K):
+                                   (2048, 1024, 512), (9000, 2816, 256)])
+def test_gemm_store16_bias_act(ops, gemm_cfg, dtype, M, N, K):
     a, w, b = rnd((M, K), 1, dtype=dtype), rnd((N, K), 2, K ** -0.5, dtype=dtype), rnd((N,), 3, 0.1, torch.float32)
     for act, fn in [(ops.ACT_NONE, lambda x: x), (ops.ACT_GELU_TANH, lambda x: F.gelu(x, approximate="tanh")),
                     (ops.ACT_GELU_ERF, F.gelu)]:
@@ -60,7 +81,7 @@ def test_gemm_is_transpose_correct(ops, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,P", [(729 * 2, 1152, 640, 729), (100, 144, 192, 16), (513, 256, 256, 0)])
-def test_gemm_f32_residual(ops, dtype, M, N, K, P):
+def test_gemm_f32_residual(ops, gemm_cfg, dtype, M, N, K, P):
     a, w, b = rnd((M, K), 4, dtype=dtype), rnd((N, K), 5, K ** -0.5, dtype=dtype), rnd((N,), 6, 0.1, torch.float32)
     if P:                                   # patch-embed form: + pos[m % P]
         res = rnd((P, N), 7, 1.0, torch.float32)
@@ -77,7 +98,7 @@ def test_gemm_f32_residual(ops, dtype, M, N, K, P):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,F_,K", [(200, 592, 256), (1300, 1024, 512)])
-def test_gemm_swiglu(ops, dtype, M, F_, K):
+def test_gemm_swiglu(ops, gemm_cfg, dtype, M, F_, K):
     from videoitg_amd.ops import pad64
     fp = pad64(F_)
     a, g, u = rnd((M, K), 9, dtype=dtype), rnd((F_, K), 10, K ** -0.5, dtype=dtype), rnd((F_, K), 11, K ** -0.5, dtype=dtype)
@@ -102,7 +123,7 @@ def ref_attention(q, k, v, scale):
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("B,H,HKV,S,D", [(3, 2, 2, 729, 72), (2, 16, 16, 16, 72), (1, 3, 3, 25, 72), (1, 4, 2, 523, 128),
                                          (1, 28, 4, 1300, 128), (2, 2, 1, 64, 128), (1, 2, 2, 4, 72)])
-def test_attention(ops, dtype, variant, B, H, HKV, S, D):
+def test_attention(ops, attn_waves, dtype, variant, B, H, HKV, S, D):
     q, k, v = rnd((B, H, S, D), 20, dtype=dtype), rnd((B, HKV, S, D), 21, dtype=dtype), rnd((B, HKV, S, D), 22, dtype=dtype)
     want = ref_attention(q, k, v, D ** -0.5)
     # packed token-major layout [B, S, (H + 2 HKV) * D] like the fused QKV GEMM output

@@ -23,6 +23,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "vitg_version": [],
     "vitg_device_info": [C.c_char_p, _i],
+    "vitg_set_option": [C.c_char_p, _i],
     "vitg_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "vitg_gemm": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "vitg_layernorm": [_p, _i, _p, _p, _p, _i, _i, _l, _i, _f, _p],

@@ -332,9 +332,9 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     if (!tr) { }     // variant 1 = scalar LDS reads of V (cross-check path for the tr-read)
     // waves per block: 8 (256 queries share one K/V stream) measured faster for the long LLM sequence, 4 for the
     // short SigLIP sequences; VITG_ATTN_WAVES=4|8 pins it for A/B measurements
-    static int nw_env = -1;
-    if (nw_env < 0) { const char* e = getenv("VITG_ATTN_WAVES"); nw_env = e ? atoi(e) : 0; }
-    const int nw = nw_env ? nw_env : (head_dim == 128 ? 8 : 4);
+    const int nw_env = tuning().attn_waves;
+    int nw = nw_env ? nw_env : (head_dim == 128 ? 8 : 4);
+    if (!nw_env && nw == 8 && (long)ceil_div(S, 256) * heads * batch < 384) nw = 4;   // too few 256-query blocks to fill the chip
     if (a.ablate) {   // profiling instantiations (fp16 only)
         if (dtype != DT_F16) return VITG_ERR_ARG;
         rc = head_dim == 72 ? launch_attn<f16_t, 72, true, 4, true>(a, batch, heads, s) : launch_attn<f16_t, 128, true, 8, true>(a, batch, heads, s);

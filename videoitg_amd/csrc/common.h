@@ -77,4 +77,14 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Host-side tuning knobs (vitg_set_option / environment VITG_*): kernel selection for A/B measurements and tests.
+struct Tuning {
+    int gemm_tile;     // 0 auto | 128 | 256
+    int gemm_cfg;      // 0 auto | 1 256x256x32 ring-4 | 2 256x128x32 ring-3 | 3 256x256x64 ring-2 | 4 persistent 256x256x64
+    int gemm_flags;    // bit0 non-temporal stores; bits 1-3 profiling ablations (wrong results)
+    int gemm_stagger;  // persistent kernel: de-phase XCDs
+    int attn_waves;    // 0 auto | 4 | 8
+};
+Tuning& tuning();
+
 }  // namespace vitg

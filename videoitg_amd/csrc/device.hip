@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include "../../include/videoitg_hip.h"
+#include "common.h"
+#include <stdlib.h>
 
 extern "C" int vitg_version(void) { return 100; }
 
@@ -15,4 +17,25 @@ extern "C" int vitg_device_info(char* name, int name_len) {
         name[name_len - 1] = 0;
     }
     return p.multiProcessorCount;
+}
+
+namespace vitg {
+static int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; }
+Tuning& tuning() {
+    static Tuning t = {env_int("VITG_GEMM_TILE"), env_int("VITG_GEMM_CFG"), env_int("VITG_GEMM_FLAGS"), env_int("VITG_GEMM_STAGGER"),
+                       env_int("VITG_ATTN_WAVES")};
+    return t;
+}
+}  // namespace vitg
+
+extern "C" int vitg_set_option(const char* key, int value) {
+    if (!key) return VITG_ERR_ARG;
+    vitg::Tuning& t = vitg::tuning();
+    if (!strcmp(key, "gemm_tile")) t.gemm_tile = value;
+    else if (!strcmp(key, "gemm_cfg")) t.gemm_cfg = value;
+    else if (!strcmp(key, "gemm_flags")) t.gemm_flags = value;
+    else if (!strcmp(key, "gemm_stagger")) t.gemm_stagger = value;
+    else if (!strcmp(key, "attn_waves")) t.attn_waves = value;
+    else return VITG_ERR_ARG;
+    return 0;
 }

@@ -208,12 +208,15 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
     g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0;
-    { static int fl = -1; if (fl < 0) { const char* e = getenv("VITG_GEMM_FLAGS"); fl = e ? atoi(e) : 0; } g.flags = fl; }
+    g.flags = tuning().gemm_flags;
     hipStream_t s = (hipStream_t)stream;
-    static int force = -1;          // VITG_GEMM_TILE=128|256 pins the kernel (A/B measurements); default: auto
-    if (force < 0) { const char* e = getenv("VITG_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    const int force = tuning().gemm_tile;          // 0 auto | 128 | 256 (vitg_set_option / VITG_GEMM_TILE)
     int rc;
-    if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
+    // 256x256 tiles need enough of them to fill 256 CUs (1 block/CU): small-M calls (e.g. the context-parallel LLM at 8
+    // GPUs, M ~ 1.6K rows) fall back to the 128x128 kernel, which has 4x the tiles and runs 2 blocks/CU.
+    const long tiles256 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    const bool big_enough = tiles256 >= 384 || force == 256;
+    if (force != 128 && big_enough && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
     else rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
 }

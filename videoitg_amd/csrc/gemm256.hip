@@ -161,7 +161,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
                 wait_tile(kt + 1);
                 // every ds_read of stage kt (incl. F1 above) must have completed before another wave may overwrite it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if (!(g.flags & 8)) __builtin_amdgcn_s_barrier();      // flags&8: profiling only (wrong results)
                 __builtin_amdgcn_sched_barrier(0);
                 if (early && kt + 1 + DIST < nk) issue(kt + 1 + DIST);   // into stage (kt+1+DIST) % STAGES == kt % STAGES
                 G2_READ(fa0, fw0, kt + 1, 0)
@@ -422,8 +422,7 @@ static int launch256p(GemmArgs g, hipStream_t s) {
     const int ntiles = g.tiles_m * g.tiles_n;
     const int grid = ntiles >= cus ? cus : ((ntiles + 7) & ~7);
     // one tile period ~ 1.15 us per 64-deep K-tile (measured main-loop rate) + epilogue; only worth it with several rounds
-    static int stag = -1;
-    if (stag < 0) { const char* e = getenv("VITG_GEMM_STAGGER"); stag = e ? atoi(e) : 0; }   // default off: measured no gain (A/B in profiles/r01_gemm_shapes.md)
+    const int stag = tuning().gemm_stagger;            // default off: measured no gain
     g.stagger_ns = (stag && ntiles >= 4 * cus) ? (g.K / 64) * 1150 + 4000 : 0;
     hipLaunchKernelGGL((gemm256p_kernel<T, MODE>), dim3(grid), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
@@ -450,13 +449,10 @@ bool gemm256_applicable(const GemmArgs& g, int mode) {
     return g.M >= 256 && g.N >= 128 && g.K % 64 == 0 && aligned;
 }
 
-static int g_cfg = -1;      // VITG_GEMM_CFG pins the configuration (A/B measurements): 1 = 256x256x32 ring-4,
-                            // 2 = 256x128x32 ring-3 (2 blocks/CU), 3 = 256x256x64 ring-2
 
 template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
-    if (g_cfg < 0) { const char* e = getenv("VITG_GEMM_CFG"); g_cfg = e ? atoi(e) : 0; }
-    const int cfg = g_cfg ? g_cfg : 3;                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
+    const int cfg = tuning().gemm_cfg ? tuning().gemm_cfg : 3;                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);

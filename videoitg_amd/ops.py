@@ -45,6 +45,11 @@ def device_info():
     return buf.value.decode(), cus
 
 
+def set_option(key: str, value: int) -> None:
+    """kernel-selection knob (see include/videoitg_hip.h: vitg_set_option)"""
+    _lib.call("vitg_set_option", key.encode(), int(value))
+
+
 def patchify(pix: torch.Tensor, patch: int, kpad: int, dtype: torch.dtype) -> torch.Tensor:
     """pix [T,3,R,R] (fp32/fp16/bf16, contiguous) -> [T*G*G, kpad]"""
     _req(pix)
