@@ -90,9 +90,17 @@ int vitg_attention(const void* q, const void* k, const void* v, void* o, int bat
                    int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype, int variant, void* stream);
 
 /* Bilinear G x G -> HW x HW token pool (align_corners=False, no antialias) of fp32 features [T*G*G, ldx] into
- * 16-bit [T*HW*HW, ldo]; HW == G is a plain cast.  Replaces F.interpolate at mlp_proj.py:57-68. */
+ * 16-bit [T*HW*HW, ldo]; HW == G is a plain cast.  cmap == NULL: x holds all G*G rows per frame; otherwise x holds Pc
+ * compact rows per frame and cmap[y*G+x] is the compact row of token (y,x).  Replaces F.interpolate at mlp_proj.py:57-68. */
 int vitg_bilinear_pool(const float* x, int ldx, void* out, int ldo, int T, int G, int HW, int D, int dtype,
-                       void* stream);
+                       const int* cmap, int Pc, void* stream);
+
+/* out[b*n_idx + i, :] = src[b*rows_per_batch + idx[i], :] for b < batch (byte strides, 16-byte granules).  With
+ * vitg_bilinear_pool's cmap (token y*G+x -> compact row, Pc rows per frame) this lets the LAST needed tower layer run its
+ * Q projection, attention queries, out-proj and MLP only on the tokens the pool reads (81 of 729 at 27x27 -> 5x5): work
+ * the reference performs and then discards (SURVEY.md 2.2 "only 81 of 729 source tokens have non-zero weight"). */
+int vitg_gather_rows(const void* src, long ld_src_bytes, const int* idx, int n_idx, int rows_per_batch, int batch, void* out,
+                     long ld_out_bytes, int row_bytes, void* stream);
 
 /* out[i, :] = table[ids[i], :] (16-bit table -> fp32 rows).  Replaces embed_tokens at
  * /root/reference/eagle/model/eagle_archv1.py:310. */

@@ -194,3 +194,26 @@ def test_full_width_reduced_depth_parity():
     for k in range(1, T):
         if (sref[k - 1] - sref[k]).item() > 2.5 * max(SCORE_TOL, floor):
             assert set(order[:k].cpu().tolist()) == set(oref[:k].tolist()), k
+
+
+@pytest.mark.parametrize("name", ["pool_post", "oddgrid", "chunk520"])
+def test_dead_row_skipping_does_not_change_results(golden_dir, name):
+    """Running the last tower layer only on the tokens the pool reads must give the same logits as running it on all
+    tokens (each output row is computed by the same arithmetic; only rows nothing reads are dropped)."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    z = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    cfg = ITGConfig.from_dict(json.loads(str(z["cfg"])))
+    T = z["T"].tolist()
+    images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i).cuda() for i, t in enumerate(T)]
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    G = cfg.vision.grid
+    assert eng.pool_sources(G, min(cfg.pooled_grid(T[0]), G)) is not None
+    a = [t.clone() for t in eng.forward(ids, mask, images)]
+    eng.skip_dead_rows = False
+    b = eng.forward(ids, mask, images)
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() < 2e-3

@@ -45,55 +45,70 @@ __global__ void patchify_kernel(const void* __restrict__ pix, TO* __restrict__ o
 template <typename TO, bool RMS, int NV>
 __global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bia,
                             void* __restrict__ out, int ldo, int out_f32, long M, int D, float eps) {
+    // One wave per row, rows grid-strided over all waves of the launch; the NEXT row's loads are issued before the current
+    // row's reductions so that every wave always has 2 rows of loads in flight (HBM latency hidden without relying on
+    // occupancy alone).
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + row * ldx;
-    f32x4 v[NV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < D) v[i] = *(const f32x4*)(xr + c);
-        else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        s += RMS ? (v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3])
-                 : (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
-    }
-    s = wave_sum(s);
-    float mean = 0.f, rstd;
-    if (RMS) {
-        rstd = rsqrtf(s / D + eps);
-    } else {
-        mean = s / D;
-        float q = 0.f;
+    f32x4 v[NV], nx[NV];
+    auto load_row = [&](f32x4 (&dst)[NV], long r) {
+        const float* xr = x + r * ldx;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
-            if (c < D) {
+            if (c < D) dst[i] = *(const f32x4*)(xr + c);
+            else dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_row(v, row);
+    for (; row < M; row += nwaves) {
+        const long next = row + nwaves;
+        if (next < M) load_row(nx, next);
+        float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        for (int i = 0; i < NV; ++i)
+            s += RMS ? (v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3])
+                     : (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
+        s = wave_sum(s);
+        float mean = 0.f, rstd;
+        if (RMS) {
+            rstd = rsqrtf(s / D + eps);
+        } else {
+            mean = s / D;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < D) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+                }
+            }
+            q = wave_sum(q);
+            rstd = rsqrtf(q / D + eps);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c >= ldo) continue;
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (c < D) {
+                const f32x4 ww = *(const f32x4*)(w + c);
+                r = (v[i] - mean) * rstd * ww;
+                if (!RMS) r += *(const f32x4*)(bia + c);
+            }
+            if (out_f32) *(f32x4*)((float*)out + row * ldo + c) = r;
+            else {
+                typename T16<TO>::vec4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = T16<TO>::from_f32(r[e]);
+                *(typename T16<TO>::vec4*)((TO*)out + row * ldo + c) = o;
             }
         }
-        q = wave_sum(q);
-        rstd = rsqrtf(q / D + eps);
-    }
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c >= ldo) continue;
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        if (c < D) {
-            const f32x4 ww = *(const f32x4*)(w + c);
-            r = (v[i] - mean) * rstd * ww;
-            if (!RMS) r += *(const f32x4*)(bia + c);
-        }
-        if (out_f32) *(f32x4*)((float*)out + row * ldo + c) = r;
-        else {
-            typename T16<TO>::vec4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = T16<TO>::from_f32(r[e]);
-            *(typename T16<TO>::vec4*)((TO*)out + row * ldo + c) = o;
-        }
+        for (int i = 0; i < NV; ++i) v[i] = nx[i];
     }
 }
 
@@ -135,7 +150,7 @@ __global__ void rope_kernel(T* __restrict__ qkv, int ld, const float* __restrict
 // ------------------------------------------------------------------------------------------------
 template <typename TO>
 __global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out, int ldo, int T, int G, int HW,
-                            int D) {
+                            int D, const int* __restrict__ cmap, int Pc) {
     const long orow = blockIdx.x;                 // t*HW*HW + oy*HW + ox
     const int t = (int)(orow / (HW * HW)), o = (int)(orow % (HW * HW));
     const int oy = o / HW, ox = o % HW;
@@ -146,11 +161,13 @@ __global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = min(y0 + 1, G - 1), x1 = min(x0 + 1, G - 1);
     const float wy1 = sy - y0, wx1 = sx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-    const float* base = x + (long)t * G * G * ldx;
-    const float* p00 = base + (long)(y0 * G + x0) * ldx;
-    const float* p01 = base + (long)(y0 * G + x1) * ldx;
-    const float* p10 = base + (long)(y1 * G + x0) * ldx;
-    const float* p11 = base + (long)(y1 * G + x1) * ldx;
+    // dense input: G*G rows per frame; compact input (cmap != null): only the Pc rows the pool reads, at cmap[y*G+x]
+    const float* base = x + (long)t * (cmap ? Pc : G * G) * ldx;
+    const int i00 = y0 * G + x0, i01 = y0 * G + x1, i10 = y1 * G + x0, i11 = y1 * G + x1;
+    const float* p00 = base + (long)(cmap ? cmap[i00] : i00) * ldx;
+    const float* p01 = base + (long)(cmap ? cmap[i01] : i01) * ldx;
+    const float* p10 = base + (long)(cmap ? cmap[i10] : i10) * ldx;
+    const float* p11 = base + (long)(cmap ? cmap[i11] : i11) * ldx;
     for (int c = threadIdx.x * 4; c < ldo; c += blockDim.x * 4) {
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (c < D) {
@@ -163,6 +180,17 @@ __global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict
         for (int e = 0; e < 4; ++e) ov[e] = T16<TO>::from_f32(r[e]);
         *(typename T16<TO>::vec4*)(out + orow * ldo + c) = ov;
     }
+}
+
+// out[(b*n_idx + i), :] = src[(b*rows_per_batch + idx[i]), :]   (16-byte granules; used to compact the rows the token pool
+// reads before the last tower layer's Q / out-proj / MLP)
+__global__ void gather_rows_kernel(const char* __restrict__ src, long ld_src_b, const int* __restrict__ idx, int n_idx,
+                                   int rows_per_batch, char* __restrict__ out, long ld_out_b, int row_bytes) {
+    const long orow = blockIdx.x;
+    const int b = (int)(orow / n_idx), i = (int)(orow % n_idx);
+    const char* s = src + ((long)b * rows_per_batch + idx[i]) * ld_src_b;
+    char* d = out + orow * ld_out_b;
+    for (int c = threadIdx.x * 16; c < row_bytes; c += blockDim.x * 16) *(u32x4*)(d + c) = *(const u32x4*)(s + c);
 }
 
 // fp32 rows -> 16-bit rows (no pooling branch HW == G), pad columns zeroed
@@ -287,7 +315,8 @@ static int norm_dispatch(const float* x, int ldx, const float* w, const float* b
     if (D % 4 || ldo % 4 || ldx % 4) return VITG_ERR_ALIGN;
     if (ldo < D) return VITG_ERR_SHAPE;
     const int need = ceil_div(ldo, 256);
-    dim3 blk(256), grid((unsigned)((M + 3) / 4));
+    const long want = (M + 3) / 4;
+    dim3 blk(256), grid((unsigned)(want < 4096 ? want : 4096));     // <= 16 waves per CU in flight, rows grid-strided
     const int of32 = out_dtype == DT_F32;
 #define NK(TO, NV) hipLaunchKernelGGL((norm_kernel<TO, RMS, NV>), grid, blk, 0, s, x, ldx, w, b, out, ldo, of32, M, D, eps)
 #define NKS(TO) do { if (need <= 1) NK(TO, 1); else if (need <= 2) NK(TO, 2); else if (need <= 5) NK(TO, 5); else if (need <= 8) NK(TO, 8); else if (need <= 16) NK(TO, 16); else return VITG_ERR_SHAPE; } while (0)
@@ -320,22 +349,32 @@ extern "C" int vitg_rope(void* qkv, int ld, const float* cos_t, const float* sin
     return CHECK_LAUNCH();
 }
 
+extern "C" int vitg_gather_rows(const void* src, long ld_src_bytes, const int* idx, int n_idx, int rows_per_batch, int batch,
+                                void* out, long ld_out_bytes, int row_bytes, void* stream) {
+    if (batch <= 0 || n_idx <= 0) return 0;
+    if (row_bytes % 16 || ld_src_bytes % 16 || ld_out_bytes % 16) return VITG_ERR_ALIGN;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((long)batch * n_idx)), dim3(256), 0, (hipStream_t)stream, (const char*)src,
+                       ld_src_bytes, idx, n_idx, rows_per_batch, (char*)out, ld_out_bytes, row_bytes);
+    return CHECK_LAUNCH();
+}
+
 extern "C" int vitg_bilinear_pool(const float* x, int ldx, void* out, int ldo, int T, int G, int HW, int D, int dtype,
-                                  void* stream) {
+                                  const int* cmap, int Pc, void* stream) {
     if (T <= 0) return 0;
     if (D % 4 || ldo % 4 || ldx % 4 || ldo < D) return VITG_ERR_ALIGN;
     if (HW <= 0 || HW > G) return VITG_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     dim3 blk(256);
     if (HW == G) {
+        if (cmap) return VITG_ERR_ARG;
         dim3 grid((unsigned)((long)T * G * G));
         if (dtype == DT_BF16) hipLaunchKernelGGL((cast_rows_kernel<bf16_t>), grid, blk, 0, s, x, ldx, (bf16_t*)out, ldo, D);
         else if (dtype == DT_F16) hipLaunchKernelGGL((cast_rows_kernel<f16_t>), grid, blk, 0, s, x, ldx, (f16_t*)out, ldo, D);
         else return VITG_ERR_DTYPE;
     } else {
         dim3 grid((unsigned)((long)T * HW * HW));
-        if (dtype == DT_BF16) hipLaunchKernelGGL((pool_kernel<bf16_t>), grid, blk, 0, s, x, ldx, (bf16_t*)out, ldo, T, G, HW, D);
-        else if (dtype == DT_F16) hipLaunchKernelGGL((pool_kernel<f16_t>), grid, blk, 0, s, x, ldx, (f16_t*)out, ldo, T, G, HW, D);
+        if (dtype == DT_BF16) hipLaunchKernelGGL((pool_kernel<bf16_t>), grid, blk, 0, s, x, ldx, (bf16_t*)out, ldo, T, G, HW, D, cmap, Pc);
+        else if (dtype == DT_F16) hipLaunchKernelGGL((pool_kernel<f16_t>), grid, blk, 0, s, x, ldx, (f16_t*)out, ldo, T, G, HW, D, cmap, Pc);
         else return VITG_ERR_DTYPE;
     }
     return CHECK_LAUNCH();

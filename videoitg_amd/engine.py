@@ -171,6 +171,7 @@ class SelectorEngine:
         self.dtype = weights.dtype
         self.device = weights.device
         self.attn_variant = attn_variant
+        self.skip_dead_rows = True        # last tower layer only on the tokens the pool reads (see vit_forward)
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[tuple, torch.Tensor] = {}
 
@@ -186,8 +187,34 @@ class SelectorEngine:
     def release_workspace(self) -> None:
         self._ws.clear()
 
-    # ---- A7: SigLIP tower -> fp32 features [T*P, Dv] ------------------------------------------------
-    def vit_forward(self, pix: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    # ---- which tokens does the bilinear pool read? (mlp_proj.py:57-68 semantics: align_corners=False) ----------------
+    def pool_sources(self, G: int, hw: int):
+        """(idx int32 [Pc] sorted token ids y*G+x that carry weight, cmap int32 [G*G] token -> compact row or -1).
+        27->5: 81 of 729 tokens, 32->5: 100 of 1024.  None when there is no pooling (hw == G)."""
+        key = ("poolsrc", G, hw)
+        if key not in self._ws:
+            if hw >= G:
+                self._ws[key] = None
+            else:
+                used = set()
+                sc = torch.tensor(float(G), dtype=torch.float32) / torch.tensor(float(hw), dtype=torch.float32)
+                for o in range(hw):                              # same fp32 arithmetic as pool_kernel
+                    src = (torch.tensor(float(o), dtype=torch.float32) + 0.5) * sc - 0.5
+                    i0 = int(max(src.item(), 0.0))
+                    used.update((i0, min(i0 + 1, G - 1)))
+                rows = sorted(used)
+                idx = torch.tensor([y * G + x for y in rows for x in rows], dtype=torch.int32)
+                cmap = torch.full((G * G,), -1, dtype=torch.int32)
+                cmap[idx.long()] = torch.arange(idx.numel(), dtype=torch.int32)
+                self._ws[key] = (idx.to(self.device), cmap.to(self.device))
+        return self._ws[key]
+
+    # ---- A7: SigLIP tower -> fp32 features ------------------------------------------------------------------------
+    def vit_forward(self, pix: torch.Tensor, hw: Optional[int] = None):
+        """-> (features fp32, G, cmap, Pc).  Without `hw` (or when nothing is pooled) features are dense [T*P, Dv] and
+        cmap is None.  With a pooled grid, the LAST needed layer computes K/V for all tokens but queries, out-proj and MLP
+        only for the Pc tokens the pool reads (their outputs are the only ones anything downstream consumes), and features
+        are compact [T*Pc, Dv] with cmap: token -> compact row."""
         cfg, v, w = self.cfg, self.cfg.vision, self.w
         T, _, R, _ = pix.shape
         G = R // v.patch_size
@@ -204,26 +231,53 @@ class SelectorEngine:
         o = self._buf("vit_o", (M, Dvp), self.dtype, zero=True)
         f = self._buf("vit_f", (M, Fvp), self.dtype)
         scale = hd ** -0.5
-        for lw in w.vit:
+        src = self.pool_sources(G, hw) if (hw is not None and self.skip_dead_rows and len(w.vit) > 0) else None
+        full_layers = w.vit if src is None else w.vit[:-1]
+        st = (P * 3 * Dv, 3 * Dv, hd)
+        for lw in full_layers:
             ops.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
             ops.gemm(h, lw.qkv_w, qkv, mode=ops.GEMM_STORE16, bias=lw.qkv_b)
             ops.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
-                          q_strides=(P * 3 * Dv, 3 * Dv, hd), k_strides=(P * 3 * Dv, 3 * Dv, hd),
-                          v_strides=(P * 3 * Dv, 3 * Dv, hd), o_strides=(P * Dvp, Dvp, hd), scale=scale,
+                          q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
                           variant=self.attn_variant)
             ops.gemm(o, lw.out_w, x, mode=ops.GEMM_F32, bias=lw.out_b, res=x)
             ops.layernorm(x, lw.ln2_w, lw.ln2_b, h, Dv, v.layer_norm_eps)
             ops.gemm(h, lw.fc1_w, f, mode=ops.GEMM_STORE16, bias=lw.fc1_b, act=ops.ACT_GELU_TANH)
             ops.gemm(f, lw.fc2_w, x, mode=ops.GEMM_F32, bias=lw.fc2_b, res=x)
-        return x, G
+        if src is None:
+            return x, G, None, 0
+        # ---- last needed layer on compact query rows -------------------------------------------------------------
+        idx, cmap = src
+        Pc = idx.numel()
+        Mc = T * Pc
+        lw = w.vit[-1]
+        ops.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
+        ops.gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=ops.GEMM_STORE16, bias=lw.qkv_b[Dv:])          # K|V for every token
+        hq = self._buf("vit_hq", (Mc, Dvp), self.dtype)
+        xq = self._buf("vit_xq", (Mc, Dv), torch.float32)
+        ops.gather_rows(h, idx, P, T, hq, Dvp)
+        ops.gather_rows(x, idx, P, T, xq, Dv)
+        qc = self._buf("vit_qc", (Mc, Dv), self.dtype)
+        ops.gemm(hq, lw.qkv_w[:Dv], qc, mode=ops.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
+        oc = self._buf("vit_oc", (Mc, Dvp), self.dtype, zero=True)
+        ops.attention(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
+                      q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
+                      variant=self.attn_variant)
+        ops.gemm(oc, lw.out_w, xq, mode=ops.GEMM_F32, bias=lw.out_b, res=xq)
+        ops.layernorm(xq, lw.ln2_w, lw.ln2_b, hq, Dv, v.layer_norm_eps)
+        fc = self._buf("vit_fc", (Mc, Fvp), self.dtype)
+        ops.gemm(hq, lw.fc1_w, fc, mode=ops.GEMM_STORE16, bias=lw.fc1_b, act=ops.ACT_GELU_TANH)
+        ops.gemm(fc, lw.fc2_w, xq, mode=ops.GEMM_F32, bias=lw.fc2_b, res=xq)
+        return xq, G, cmap, Pc
 
     # ---- A9: pool + projector, written straight into rows of the LLM residual stream ------------------
-    def project_into(self, feats: torch.Tensor, T: int, G: int, hw: int, dst_rows: torch.Tensor) -> None:
+    def project_into(self, feats: torch.Tensor, T: int, G: int, hw: int, dst_rows: torch.Tensor,
+                     cmap: Optional[torch.Tensor] = None, pc: int = 0) -> None:
         cfg, w = self.cfg, self.w
         Dv, Dvp, Dp = cfg.vision.hidden_size, pad64(cfg.vision.hidden_size), pad64(cfg.hidden_size)
         nv = T * hw * hw
         pooled = self._buf("pooled", (nv, Dvp), self.dtype)
-        ops.bilinear_pool(feats, pooled, T, G, hw, Dv)
+        ops.bilinear_pool(feats, pooled, T, G, hw, Dv, cmap, pc)
         g = self._buf("proj_g", (nv, Dp), self.dtype)
         ops.gemm(pooled, w.proj0_w, g, mode=ops.GEMM_STORE16, bias=w.proj0_b, act=ops.ACT_GELU_ERF)
         ops.gemm(g, w.proj2_w, dst_rows, mode=ops.GEMM_F32, bias=w.proj2_b)
@@ -279,7 +333,8 @@ class SelectorEngine:
         return out
 
     # ---- whole path for one sample whose frames are already encoded ---------------------------------
-    def score_video(self, feats: torch.Tensor, T: int, G: int, ids: torch.Tensor) -> torch.Tensor:
+    def score_video(self, feats: torch.Tensor, T: int, G: int, ids: torch.Tensor, cmap: Optional[torch.Tensor] = None,
+                    pc: int = 0) -> torch.Tensor:
         """feats fp32 [T*P, Dv] (this video's rows), ids HOST int64 [L] (unpadded, one IMAGE_TOKEN_INDEX) ->
         logits fp32 [T]."""
         cfg = self.cfg
@@ -301,7 +356,7 @@ class SelectorEngine:
         x = self._buf("llm_x", (n, cfg.hidden_size), torch.float32)
         if pre.numel():
             ops.embed_gather(pre.contiguous().to(self.device), self.w.embed, x[:pre.numel()])
-        self.project_into(feats, T, G, hw, x[pre.numel():pre.numel() + nv])
+        self.project_into(feats, T, G, hw, x[pre.numel():pre.numel() + nv], cmap, pc)
         if post.numel():
             ops.embed_gather(post.contiguous().to(self.device), self.w.embed, x[pre.numel() + nv:])
         hfin = self.llm_forward(x)
@@ -327,15 +382,18 @@ class SelectorEngine:
         if len(sizes) != 1:
             raise ValueError("all videos in a batch must share one frame size")
         pix = torch.cat([im.to(self.device) for im in images], 0) if B > 1 else images[0].to(self.device)
-        feats, G = self.vit_forward(pix)
-        P = G * G
+        G0 = pix.shape[-1] // self.cfg.vision.patch_size
+        hws = {min(self.cfg.pooled_grid(im.shape[0]), G0) for im in images}
+        hw_all = hws.pop() if len(hws) == 1 else None                 # videos of different length pool differently -> dense
+        feats, G, cmap, pc = self.vit_forward(pix, hw_all)
+        P = pc if cmap is not None else G * G
         out, row = [], 0
         ids_host = input_ids.cpu()
         mask_host = attention_mask.cpu()
         for b in range(B):
             T = images[b].shape[0]
             ids = ids_host[b][mask_host[b]]                          # eagle_archv1.py:272
-            lg = self.score_video(feats[row * P:(row + T) * P], T, G, ids)
+            lg = self.score_video(feats[row * P:(row + T) * P], T, G, ids, cmap, pc)
             out.append(lg.reshape(T, 1))
             row += T
         return out

@@ -120,9 +120,23 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor
     return o
 
 
-def bilinear_pool(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d: int) -> torch.Tensor:
+def bilinear_pool(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d: int, cmap: Optional[torch.Tensor] = None,
+                  pc: int = 0) -> torch.Tensor:
     _req(x, torch.float32)
-    _lib.call("vitg_bilinear_pool", _ptr(x), x.stride(0), _ptr(out), out.stride(0), T, G, HW, d, dt_code(out.dtype), _stream())
+    if cmap is not None:
+        _req(cmap, torch.int32)
+    _lib.call("vitg_bilinear_pool", _ptr(x), x.stride(0), _ptr(out), out.stride(0), T, G, HW, d, dt_code(out.dtype), _ptr(cmap), pc,
+              _stream())
+    return out
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, rows_per_batch: int, batch: int, out: torch.Tensor, width: int) -> torch.Tensor:
+    """out[b*len(idx)+i, :width] = src[b*rows_per_batch + idx[i], :width]"""
+    _req(src)
+    _req(idx, torch.int32)
+    es = src.element_size()
+    _lib.call("vitg_gather_rows", _ptr(src), src.stride(0) * es, _ptr(idx), idx.numel(), rows_per_batch, batch, _ptr(out),
+              out.stride(0) * es, width * es, _stream())
     return out
 
 

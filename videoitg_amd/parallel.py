@@ -115,14 +115,14 @@ class ContextParallel:
         hw = min(cfg.pooled_grid(T), G)                      # GLOBAL frame count (mlp_proj.py:48)
         plan = make_plan(self.world, T, hw * hw, pre.numel(), post.numel())
         fr = plan.frames[self.rank]
-        feats, _ = eng.vit_forward(pix[fr.start:fr.stop])
+        feats, _, cmap, pc = eng.vit_forward(pix[fr.start:fr.stop], hw)
         n = plan.n_local[self.rank]
         x = eng._buf("llm_x", (n, cfg.hidden_size), torch.float32)
         vs = plan.vis_start(self.rank)
         nv = len(fr) * hw * hw
         if self.rank == 0 and pre.numel():
             ops.embed_gather(pre.contiguous().to(eng.device), eng.w.embed, x[:pre.numel()])
-        eng.project_into(feats, len(fr), G, hw, x[vs:vs + nv])
+        eng.project_into(feats, len(fr), G, hw, x[vs:vs + nv], cmap, pc)
         if self.rank == self.world - 1 and post.numel():
             ops.embed_gather(post.contiguous().to(eng.device), eng.w.embed, x[vs + nv:])
         gather = RowGatherer(plan, self.rank, self.group)
