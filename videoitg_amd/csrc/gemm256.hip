@@ -26,7 +26,7 @@ constexpr int G2_BM = 256, G2_THREADS = 512;
 //   <BN=256, WM=2, STAGES=4>: wave tile 128x64, 128 KiB LDS, 1 block/CU  - best steady state (large K)
 //   <BN=128, WM=4, STAGES=3>: wave tile  64x64,  72 KiB LDS, 2 blocks/CU - one block's prologue/epilogue overlaps the
 //                                                                          other's main loop (small K, heavy epilogues)
-template <typename T, int MODE, int BN, int WM, int STAGES, int BK>
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false>
 __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g) {
     typedef typename T16<T>::vec8 vec8;
     constexpr int WN = 8 / WM;
@@ -122,11 +122,30 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
         else if (DIST > 1 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+// Fragment reads.  ASMR: the ds_read_b128 are inline asm, invisible to hipcc's waitcnt pass, and completion is enforced
+// by hand-counted `s_waitcnt lgkmcnt(N)` (G2_WAIT_OLDER): hipcc otherwise waits lgkmcnt(0) in front of the second MFMA
+// block of the loop (conservative loop-carried merge), i.e. it waits for the reads just issued for the NEXT k-step and
+// defeats the software pipeline.  LDS returns in order, so "all but the newest (NT+MT) reads" is exact.
 #define G2_READ(FA, FW, KT, KS_)                                                                              \
     {                                                                                                         \
-        const char* st_ = smem + ((KT) % STAGES) * STAGE;                                                     \
-        _Pragma("unroll") for (int i = 0; i < NT; ++i) FW[i] = *(const vec8*)(st_ + w_off[KS_] + i * (32 * ROWB)); \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *(const vec8*)(st_ + a_off[KS_] + i * (32 * ROWB)); \
+        if constexpr (ASMR) {                                                                                 \
+            const unsigned wb_ = (unsigned)(size_t)(smem + ((KT) % STAGES) * STAGE) + (unsigned)w_off[KS_];    \
+            const unsigned ab_ = (unsigned)(size_t)(smem + ((KT) % STAGES) * STAGE) + (unsigned)a_off[KS_];    \
+            _Pragma("unroll") for (int i = 0; i < NT; ++i)                                                    \
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FW[i]) : "v"(wb_), "n"(i * 32 * ROWB));   \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                    \
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FA[i]) : "v"(ab_), "n"(i * 32 * ROWB));   \
+        } else {                                                                                              \
+            const char* st_ = smem + ((KT) % STAGES) * STAGE;                                                 \
+            _Pragma("unroll") for (int i = 0; i < NT; ++i) FW[i] = *(const vec8*)(st_ + w_off[KS_] + i * (32 * ROWB)); \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *(const vec8*)(st_ + a_off[KS_] + i * (32 * ROWB)); \
+        }                                                                                                     \
+    }
+// all LDS reads except the newest NT+MT (the set issued last) have returned
+#define G2_WAIT_OLDER()                                                                                       \
+    if constexpr (ASMR) {                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + MT) : "memory");                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
 #define G2_MMA(FA, FW)                                                                                        \
     __builtin_amdgcn_s_setprio(1);                                                                            \
@@ -148,6 +167,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
         for (int kp = 0; kp < KS / 2; ++kp) {            // k-step pair (2kp, 2kp+1): F0 holds step 2kp on entry
             G2_READ(fa1, fw1, kt, 2 * kp + 1)
             __builtin_amdgcn_sched_barrier(0);
+            G2_WAIT_OLDER()                              // F0 landed (F1 may be in flight)
             G2_MMA(fa0, fw0)
             __builtin_amdgcn_sched_barrier(0);
             if (kp == 0 && !early && kt + DIST < nk && kt > 0) {
@@ -157,6 +177,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
             if (kp + 1 < KS / 2) {
                 G2_READ(fa0, fw0, kt, 2 * kp + 2)
                 __builtin_amdgcn_sched_barrier(0);
+                G2_WAIT_OLDER()                          // F1 landed
             } else if (kt + 1 < nk) {
                 wait_tile(kt + 1);
                 // every ds_read of stage kt (incl. F1 above) must have completed before another wave may overwrite it
@@ -166,6 +187,9 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
                 if (early && kt + 1 + DIST < nk) issue(kt + 1 + DIST);   // into stage (kt+1+DIST) % STAGES == kt % STAGES
                 G2_READ(fa0, fw0, kt + 1, 0)
                 __builtin_amdgcn_sched_barrier(0);
+            } else if (ASMR) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // last k-step of the last tile: F1 landed
+                __builtin_amdgcn_sched_barrier(0);
             }
             G2_MMA(fa1, fw1)
             __builtin_amdgcn_sched_barrier(0);
@@ -173,6 +197,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
     }
 #undef G2_READ
 #undef G2_MMA
+#undef G2_WAIT_OLDER
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
     if constexpr (MODE == MODE_F32) {
@@ -428,17 +453,17 @@ static int launch256p(GemmArgs g, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <typename T, int MODE, int BN, int WM, int STAGES, int BK>
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false>
 static int launch256(GemmArgs g, hipStream_t s) {
     constexpr int lds = STAGES * (G2_BM * BK * 2 + BN * BK * 2);
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
     g.tiles_m = ceil_div(g.M, G2_BM);
     g.tiles_n = ceil_div(g.N, BN);
-    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
+    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
 
@@ -456,7 +481,8 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
-    return launch256<T, MODE, 256, 2, 2, 64>(g, s);
+    if (cfg == 5) return launch256<T, MODE, 256, 2, 2, 64, true>(g, s);       // 5 = inline-asm LDS reads + counted lgkmcnt (measured = cfg 3)
+    return launch256<T, MODE, 256, 2, 2, 64, false>(g, s);
 }
 
 template <typename T>
