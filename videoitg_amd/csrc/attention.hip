@@ -48,7 +48,7 @@ template <int D> __device__ __forceinline__ int k_lds_off(int row, int chunk) { 
 }
 
 template <typename T, int D, bool TR, int NW, bool ABL = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (256,3) for hd72 spills: 548 -> 428 TF/s
     const int ablate = ABL ? a.ablate : 0;      // ablation switches exist only in the profiling instantiation
     constexpr int ATT_THREADS = NW * 64, ATT_BQ = NW * 32;
     typedef typename T16<T>::vec8 vec8;

@@ -42,7 +42,7 @@ __global__ void patchify_kernel(const void* __restrict__ pix, TO* __restrict__ o
 // are written as zero so the result can feed a GEMM whose K is padded to a multiple of 64.
 // One wave per row, row cached in registers (D <= 64*4*NV).
 // ------------------------------------------------------------------------------------------------
-template <typename TO, bool RMS, int NV>
+template <typename TO, bool RMS, int NV, bool PF>
 __global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bia,
                             void* __restrict__ out, int ldo, int out_f32, long M, int D, float eps) {
     // One wave per row, rows grid-strided over all waves of the launch; the NEXT row's loads are issued before the current
@@ -52,8 +52,9 @@ __global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* _
     const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
     long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    f32x4 v[NV], nx[NV];
-    auto load_row = [&](f32x4 (&dst)[NV], long r) {
+    // PF = false (every wave has exactly one row): no second register set, so occupancy stays high for short launches
+    f32x4 v[NV], nx[PF ? NV : 1];
+    auto load_row = [&](auto& dst, long r) {
         const float* xr = x + r * ldx;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -65,7 +66,7 @@ __global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* _
     load_row(v, row);
     for (; row < M; row += nwaves) {
         const long next = row + nwaves;
-        if (next < M) load_row(nx, next);
+        if constexpr (PF) { if (next < M) load_row(nx, next); }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -107,8 +108,10 @@ __global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* _
                 *(typename T16<TO>::vec4*)((TO*)out + row * ldo + c) = o;
             }
         }
+        if constexpr (PF) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = nx[i];
+            for (int i = 0; i < NV; ++i) v[i] = nx[i];
+        }
     }
 }
 
@@ -318,7 +321,8 @@ static int norm_dispatch(const float* x, int ldx, const float* w, const float* b
     const long want = (M + 3) / 4;
     dim3 blk(256), grid((unsigned)(want < 4096 ? want : 4096));     // <= 16 waves per CU in flight, rows grid-strided
     const int of32 = out_dtype == DT_F32;
-#define NK(TO, NV) hipLaunchKernelGGL((norm_kernel<TO, RMS, NV>), grid, blk, 0, s, x, ldx, w, b, out, ldo, of32, M, D, eps)
+#define NK(TO, NV) do { if (want > 4096) hipLaunchKernelGGL((norm_kernel<TO, RMS, NV, true>), grid, blk, 0, s, x, ldx, w, b, out, ldo, of32, M, D, eps); \
+                        else hipLaunchKernelGGL((norm_kernel<TO, RMS, NV, false>), grid, blk, 0, s, x, ldx, w, b, out, ldo, of32, M, D, eps); } while (0)
 #define NKS(TO) do { if (need <= 1) NK(TO, 1); else if (need <= 2) NK(TO, 2); else if (need <= 5) NK(TO, 5); else if (need <= 8) NK(TO, 8); else if (need <= 16) NK(TO, 16); else return VITG_ERR_SHAPE; } while (0)
     if (out_dtype == DT_F16) NKS(f16_t); else if (out_dtype == DT_BF16 || out_dtype == DT_F32) NKS(bf16_t); else return VITG_ERR_DTYPE;
 #undef NKS
