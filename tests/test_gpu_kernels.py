@@ -35,11 +35,13 @@ def gemm_cfg(request, ops):
     ops.set_option("gemm_cfg", 0)
 
 
-@pytest.fixture(params=[0, 4, 8])
+@pytest.fixture(params=[(0, 0), (4, 0), (8, 0), (4, 1)], ids=["auto", "waves4", "waves8", "waves4_pipelined"])
 def attn_waves(request, ops):
-    ops.set_option("attn_waves", request.param)
+    ops.set_option("attn_waves", request.param[0])
+    ops.set_option("attn_pipe", request.param[1])
     yield request.param
     ops.set_option("attn_waves", 0)
+    ops.set_option("attn_pipe", 0)
 
 
 def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):

@@ -47,7 +47,7 @@ template <int D> __device__ __forceinline__ int k_lds_off(int row, int chunk) { 
     else return row * 176 + (chunk << 4);
 }
 
-template <typename T, int D, bool TR, int NW, bool ABL = false>
+template <typename T, int D, bool TR, int NW, bool ABL = false, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (256,3) for hd72 spills: 548 -> 428 TF/s
     const int ablate = ABL ? a.ablate : 0;      // ablation switches exist only in the profiling instantiation
     constexpr int ATT_THREADS = NW * 64, ATT_BQ = NW * 32;
@@ -105,41 +105,60 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
     constexpr int NCH = ATT_BK * C::CH;                      // chunks per tile (1024 or 576)
     constexpr int PER = (NCH + ATT_THREADS - 1) / ATT_THREADS;
     u32x4 rk[PER], rv[PER];
-    auto load_kv = [&](int kt) {
+    // staging geometry is loop-invariant: per-thread (row, chunk) -> global element offsets and LDS byte offsets are
+    // computed once; per tile only a wave-uniform base advances (the row clamp is needed in the last tile only)
+    int g_row[PER], gk_off[PER], gv_off[PER], lk_off[PER], lv_off[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + i * ATT_THREADS;
+        const int row = c / C::CH, ch = c % C::CH;
+        g_row[i] = row;
+        gk_off[i] = row * a.k_rs + ch * 8;
+        gv_off[i] = row * a.v_rs + ch * 8;
+        lk_off[i] = k_lds_off<D>(row, ch);
+        // D=128: V rows are 256 B = one LDS bank row, so the 4 key rows of a tr-read block would collide 4-way;
+        // XOR the 64-B unit index with (row & 3) (read side: voff_dt)
+        const int vch = D == 128 ? (ch ^ ((row & 3) << 2)) : ch;
+        lv_off[i] = row * (C::LDV * 2) + (vch << 4);
+    }
+    auto load_one = [&](int kt, bool do_k, bool do_v) {
+        const T* Kt = K + (long)kt * ATT_BK * a.k_rs;
+        const T* Vt = V + (long)kt * ATT_BK * a.v_rs;
+        const bool tail = kt * ATT_BK + ATT_BK > a.Sk;          // wave-uniform
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int c = tid + i * ATT_THREADS;
-            if (c < NCH) {
-                const int row = c / C::CH, ch = c % C::CH;
-                const int key = min(kt * ATT_BK + row, a.Sk - 1);
-                rk[i] = *(const u32x4*)(K + (long)key * a.k_rs + ch * 8);
-                rv[i] = *(const u32x4*)(V + (long)key * a.v_rs + ch * 8);
+            if ((NCH % ATT_THREADS == 0) || tid + i * ATT_THREADS < NCH) {
+                int ko = gk_off[i], vo = gv_off[i];
+                if (tail) {
+                    const int r = min(g_row[i], a.Sk - 1 - kt * ATT_BK);
+                    ko += (r - g_row[i]) * a.k_rs;
+                    vo += (r - g_row[i]) * a.v_rs;
+                }
+                if (do_k) rk[i] = *(const u32x4*)(Kt + ko);
+                if (do_v) rv[i] = *(const u32x4*)(Vt + vo);
             }
         }
     };
-    auto store_kv = [&](int buf) {
-        char* kb = smem + buf * (KT_BYTES + VT_BYTES);
-        char* vb = kb + KT_BYTES;
+    auto load_kv = [&](int kt) { load_one(kt, true, true); };
+    auto store_one = [&](int kbuf, int vbuf, bool do_k, bool do_v) {
+        char* kb = smem + kbuf * (KT_BYTES + VT_BYTES);
+        char* vb = smem + vbuf * (KT_BYTES + VT_BYTES) + KT_BYTES;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int c = tid + i * ATT_THREADS;
-            if (c < NCH) {
-                const int row = c / C::CH, ch = c % C::CH;
-                *(u32x4*)(kb + k_lds_off<D>(row, ch)) = rk[i];
-                // D=128: V rows are 256 B = one LDS bank row, so the 4 key rows of a tr-read block would collide 4-way;
-                // XOR the 64-B unit index with (row & 3) (read side: voff_dt)
-                const int vch = D == 128 ? (ch ^ ((row & 3) << 2)) : ch;
-                *(u32x4*)(vb + row * (C::LDV * 2) + (vch << 4)) = rv[i];
+            if ((NCH % ATT_THREADS == 0) || tid + i * ATT_THREADS < NCH) {
+                if (do_k) *(u32x4*)(kb + lk_off[i]) = rk[i];
+                if (do_v) *(u32x4*)(vb + lv_off[i]) = rv[i];
             }
         }
         if constexpr (D == 72) {
             // zero the K pad chunk (d 72..79) once per buffer fill: 64 rows
-            if (tid < ATT_BK) {
+            if (do_k && tid < ATT_BK) {
                 u32x4 z = {0u, 0u, 0u, 0u};
                 *(u32x4*)(kb + k_lds_off<D>(tid, 9)) = z;
             }
         }
     };
+    auto store_kv = [&](int buf) { store_one(buf, buf, true, true); };
 
     f32x16 o[DT];
 #pragma unroll
@@ -261,9 +280,97 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
         if (more) store_kv(BUF ^ 1);
         __syncthreads();
     };
-    for (int kt = 0; kt < nkt; kt += 2) {
-        tile(kt, std::integral_constant<int, 0>{});
-        if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, 1>{});
+    if constexpr (!PIPE) {
+        for (int kt = 0; kt < nkt; kt += 2) {
+            tile(kt, std::integral_constant<int, 0>{});
+            if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        // Software pipeline across KV tiles: the QK^T MFMAs of tile t+1 are issued BEFORE the softmax VALU work of tile t,
+        // so the matrix pipe computes the next scores while this wave exponentiates the current ones (within one wave MFMA
+        // and VALU only overlap when independent work is adjacent in program order).  K is therefore staged one tile
+        // ahead of V: iteration t reads K(t+1) [buffer BUF^1] and V(t) [buffer BUF], and fills K(t+2) -> BUF, V(t+1) -> BUF^1.
+        auto qk = [&](const char* kb, f32x16 (&s)[2]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const vec8 kf = *(const vec8*)(kb + koff[ks] + t * 32 * (C::LDK * 2));
+                    s[t] = T16<T>::mfma32(kf, qf[ks], s[t]);
+                }
+            }
+        };
+        auto tile_p = [&](int kt, auto buf_c, f32x16 (&s)[2], f32x16 (&sn)[2]) {
+            constexpr int BUF = decltype(buf_c)::value;
+            const bool has1 = kt + 1 < nkt, has2 = kt + 2 < nkt;
+            if (has2) load_one(kt + 2, true, false);
+            if (has1) load_one(kt + 1, false, true);
+            const char* vb = smem + BUF * (KT_BYTES + VT_BYTES) + KT_BYTES;
+            if (has1) qk(smem + (BUF ^ 1) * (KT_BYTES + VT_BYTES), sn);
+            if (kt * ATT_BK + ATT_BK > a.Sk) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * ATT_BK + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                        if (key >= a.Sk) s[t][r] = -INFINITY;
+                    }
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;
+            const float m_new = fmaxf(m_run, mx);
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                m_run = m_new;
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {                 // exp of one 16-key step, then its PV MFMAs: VALU of step kk+1
+                vec8 pf;                                     // issues under the MFMAs of step kk
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kk >> 1][(kk & 1) * 8 + j], a.scale_log2e, -m_run));
+                    psum += p;
+                    pf[j] = T16<T>::from_f32(p);
+                }
+                const int krow = (kk >> 1) * 32 + (kk & 1) * 16;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const char* a0 = vb + voff_dt[dt] + krow * (C::LDV * 2);
+                    const char* a1 = a0 + 8 * (C::LDV * 2);
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+                    s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = T16<T>::mfma32(bitcast<vec8>(both), pf, o[dt]);
+                }
+            }
+            l_run += psum;
+            if (has2 || has1) store_one(BUF, BUF ^ 1, has2, has1);
+            __syncthreads();
+        };
+        // prologue: K(0), V(0) are staged (above); K(1) goes to buffer 1 before the first score tile is needed
+        if (nkt > 1) {
+            load_one(1, true, false);
+            store_one(1, 1, true, false);
+            __syncthreads();
+        }
+        f32x16 sA[2], sB[2];
+        qk(smem, sA);
+        for (int kt = 0; kt < nkt; kt += 2) {
+            tile_p(kt, std::integral_constant<int, 0>{}, sA, sB);
+            if (kt + 1 < nkt) tile_p(kt + 1, std::integral_constant<int, 1>{}, sB, sA);
+        }
     }
 
     // ---- epilogue: lane (q, h) holds O[q][dt*32 + 8*(r>>2) + 4*h + (r&3)] -------------------------------
@@ -287,18 +394,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
     }
 }
 
-template <typename T, int D, bool TR, int NW, bool ABL = false>
+template <typename T, int D, bool TR, int NW, bool ABL = false, bool PIPE = false>
 static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
     const size_t lds = 2 * (ATT_BK * C::LDK * 2 + ATT_BK * C::LDV * 2);
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute((const void*)attn_kernel<T, D, TR, NW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)attn_kernel<T, D, TR, NW, ABL, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         done = true;
     }
     dim3 grid(ceil_div(a.S, NW * 32) * heads * batch);
-    hipLaunchKernelGGL((attn_kernel<T, D, TR, NW, ABL>), grid, dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_kernel<T, D, TR, NW, ABL, PIPE>), grid, dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -341,7 +448,12 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
 #define GO(T, D) (!tr ? launch_attn<T, D, false, 4>(a, batch, heads, s) : nw == 4 ? launch_attn<T, D, true, 4>(a, batch, heads, s) : launch_attn<T, D, true, 8>(a, batch, heads, s))
-    if (dtype == DT_BF16) rc = head_dim == 72 ? GO(bf16_t, 72) : GO(bf16_t, 128);
+    // hd 72: optional cross-tile software-pipelined variant (QK^T of tile t+1 issued before the softmax of tile t).  Measured
+    // equal to the plain loop (549 vs 555 TF/s, profiles/r01_attention.md), so it is opt-in: attn_pipe = 1
+    const bool pipe72 = tr && head_dim == 72 && nw == 4 && tuning().attn_pipe == 1;
+    if (pipe72) rc = dtype == DT_BF16 ? launch_attn<bf16_t, 72, true, 4, false, true>(a, batch, heads, s)
+                                      : launch_attn<f16_t, 72, true, 4, false, true>(a, batch, heads, s);
+    else if (dtype == DT_BF16) rc = head_dim == 72 ? GO(bf16_t, 72) : GO(bf16_t, 128);
     else rc = head_dim == 72 ? GO(f16_t, 72) : GO(f16_t, 128);
 #undef GO
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;

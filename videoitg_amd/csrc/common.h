@@ -84,6 +84,7 @@ struct Tuning {
     int gemm_flags;    // bit0 non-temporal stores; bits 1-3 profiling ablations (wrong results)
     int gemm_stagger;  // persistent kernel: de-phase XCDs
     int attn_waves;    // 0 auto | 4 | 8
+    int attn_pipe;     // 0 off (default) | 1 cross-tile pipelined hd-72 variant
 };
 Tuning& tuning();
 
