@@ -1,0 +1,103 @@
+"""CPU: host-side behaviour of the operator surface (builder / model object / config) — no GPU arithmetic."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from videoitg_amd import synth
+from videoitg_amd.config import ITGConfig, tiny_config
+from videoitg_amd.image_processor import SiglipImageProcessor
+from videoitg_amd.model.builder import (ByteTokenizer, load_pretrained_model, normalise_vision_keys, split_checkpoint)
+from videoitg_amd.model.grounding_qwen2 import EagleQwenG
+
+
+def test_config_defaults_and_pooled_grid():
+    cfg = ITGConfig()
+    assert (cfg.head_dim, cfg.vision.head_dim, cfg.vision.grid, cfg.vision.num_patches) == (128, 72, 27, 729)
+    assert cfg.num_vit_layers_needed() == 26                       # hidden_states[-2] of a 27-layer tower
+    assert cfg.pooled_grid(512) == 5 and cfg.pooled_grid(64) == 16 and cfg.pooled_grid(16) == 27
+
+
+def test_config_from_pretrained_applies_reference_defaults(tmp_path):
+    d = {"hidden_size": 256, "num_attention_heads": 2, "num_key_value_heads": 1, "vision_token_num": 72}
+    (tmp_path / "config.json").write_text(json.dumps(d))
+    cfg = ITGConfig.from_pretrained(str(tmp_path))
+    assert cfg.mm_use_4_vision_tokens is True                      # eagle_archv1.py:223 default when the key is absent
+    with pytest.raises(ValueError):                                # ... which is not part of the selector path
+        EagleQwenG(cfg, {}, {})
+
+
+def test_model_object_rejects_unknown_projector_and_cpu_forward():
+    cfg = tiny_config(mm_projector_type="linear")
+    with pytest.raises(ValueError):                                # multimodal_projector/builder.py:69
+        EagleQwenG(cfg, {}, {})
+    m = EagleQwenG(tiny_config(), {}, {}, device="cpu")
+    assert m.half() is m and m.eval() is m and m.to("cpu") is m and m.dtype == torch.float16
+    with pytest.raises(ValueError):
+        m.to(torch.float32)                                        # MFMA inputs are 16-bit
+    with pytest.raises(RuntimeError):                              # no CPU path, loudly
+        m(torch.tensor([[-200, 5]]), images=[torch.zeros(2, 3, 56, 56)])
+    with pytest.raises(ValueError):
+        m(None, images=None)
+
+
+def test_builder_surface_without_gpu():
+    tok, model, proc, ctx = load_pretrained_model("synthetic:tiny:0", None, "VideoITG-tiny", device_map="cuda:0")
+    assert isinstance(tok, ByteTokenizer) and ctx == 2048 and proc is model.get_vision_tower().image_processor
+    assert model.config.mm_projector_type == "seq_mlp" and str(model.device) == "cuda:0"
+    assert model.get_vision_tower().num_patches == 16 and model.tie_weights() is None
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model("synthetic:tiny", "some/base", "x")
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model("synthetic:tiny", None, "x", load_8bit=True)
+
+
+def test_checkpoint_directory_layouts(tmp_path):
+    """HF-layout directory with safetensors + a separate tower directory; tower keys in all three layouts seen in the wild."""
+    from safetensors.torch import save_file
+    cfg = tiny_config()
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    ck = tmp_path / "ckpt"
+    tw = ck / "vision_tower"
+    tw.mkdir(parents=True)
+    d = cfg.to_dict()
+    d["mm_vision_tower"] = "google/siglip-so400m-patch14-384"
+    (ck / "config.json").write_text(json.dumps(d))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ck / "model.safetensors"))
+    save_file({k: v.contiguous() for k, v in vsd.items()}, str(tw / "model.safetensors"))
+    from videoitg_amd.model.builder import _load_directory
+    cfg2, sd2, vsd2 = _load_directory(str(ck))
+    assert cfg2.hidden_size == cfg.hidden_size and set(sd2) == set(sd) and set(vsd2) == set(vsd)
+    assert torch.equal(sd2["out_proj.weight"], sd["out_proj.weight"])
+    # embedded (4.47 naming) and flattened (5.x naming) tower keys normalise to the Hub layout
+    emb = {"model.vision_tower.vision_tower." + k: v for k, v in vsd.items()}
+    flat = {"model.vision_tower.vision_tower." + k[len("vision_model."):]: v for k, v in vsd.items()}
+    for layout in (emb, flat):
+        llm, vis = split_checkpoint({**sd, **layout})
+        assert set(llm) == set(sd) and set(vis) == set(vsd)
+    assert set(normalise_vision_keys(vsd)) == set(vsd)
+    (tw / "model.safetensors").unlink()
+    os.rmdir(tw)
+    with pytest.raises(FileNotFoundError):
+        _load_directory(str(ck))
+
+
+def test_image_processor_matches_siglip_definition():
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, (3, 50, 70, 3), dtype=np.uint8)
+    p = SiglipImageProcessor(size=56)
+    out = p.preprocess(frames, return_tensors="pt")["pixel_values"]
+    assert out.shape == (3, 3, 56, 56) and out.dtype == torch.float32 and out.min() >= -1 and out.max() <= 1
+    from PIL import Image
+    ref = np.asarray(Image.fromarray(frames[1]).resize((56, 56), resample=Image.BICUBIC), dtype=np.float32) / 255.0
+    ref = ((ref - 0.5) / 0.5).transpose(2, 0, 1)
+    assert np.abs(out[1].numpy() - ref).max() < 1e-6
+    same = p.preprocess([Image.fromarray(f) for f in frames], return_tensors="pt")["pixel_values"]
+    assert torch.equal(out, same)                                   # ndarray and PIL-list inputs agree
+    sq = rng.integers(0, 256, (2, 56, 56, 3), dtype=np.uint8)
+    exact = p.preprocess(sq, return_tensors="pt")["pixel_values"]                       # already 56x56: no resize path
+    assert np.abs(exact[0].numpy() - ((sq[0].astype(np.float32) / 255 - 0.5) / 0.5).transpose(2, 0, 1)).max() < 1e-6
+    with pytest.raises(ValueError):
+        p.preprocess(frames, return_tensors="tf")

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""GEMM throughput at the per-rank row counts of the context-parallel LLM (M = N_tokens / world)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videoitg_amd import ops
+dt = torch.float16
+for M in (1660, 3260, 6460):
+    for name, N, K, mode in [("qkv", 4608, 3584, ops.GEMM_STORE16), ("o", 3584, 3584, ops.GEMM_F32), ("gateup", 37888, 3584, ops.GEMM_SWIGLU),
+                             ("down", 3584, 18944, ops.GEMM_F32)]:
+        a = (torch.rand((M, K), device="cuda") * 2 - 1).to(dt)
+        w = ((torch.rand((N, K), device="cuda") * 2 - 1) * K ** -0.5).to(dt)
+        if mode == ops.GEMM_F32:
+            out = torch.zeros((M, N), dtype=torch.float32, device="cuda"); kw = dict(res=out)
+        elif mode == ops.GEMM_SWIGLU:
+            out = torch.empty((M, N // 2), dtype=dt, device="cuda"); kw = {}
+        else:
+            out = torch.empty((M, N), dtype=dt, device="cuda"); kw = {}
+        res = []
+        for tile, cfg in [(128, 0), (256, 3), (256, 2), (256, 1)]:
+            ops.set_option("gemm_tile", tile); ops.set_option("gemm_cfg", cfg)
+            for _ in range(3): ops.gemm(a, w, out, mode=mode, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): ops.gemm(a, w, out, mode=mode, **kw)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            res.append(f"{2.0 * M * N * K / ms / 1e9:6.0f}")
+        ops.set_option("gemm_tile", 0); ops.set_option("gemm_cfg", 0)
+        print(f"M={M:5d} {name:7s} TF/s: tile128 {res[0]} | 256x256x64 {res[1]} | 256x128x32 {res[2]} | 256x256x32 {res[3]}", flush=True)

@@ -212,11 +212,10 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
     hipStream_t s = (hipStream_t)stream;
     const int force = tuning().gemm_tile;          // 0 auto | 128 | 256 (vitg_set_option / VITG_GEMM_TILE)
     int rc;
-    // 256x256 tiles need enough of them to fill 256 CUs (1 block/CU): small-M calls (e.g. the context-parallel LLM at 8
-    // GPUs, M ~ 1.6K rows) fall back to the 128x128 kernel, which has 4x the tiles and runs 2 blocks/CU.
-    const long tiles256 = (long)ceil_div(M, 256) * ceil_div(N, 256);
-    const bool big_enough = tiles256 >= 384 || force == 256;
-    if (force != 128 && big_enough && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
+    // Kernel choice by tile count (measured on the per-rank shapes of the context-parallel LLM, tools/gemm_small_m.py):
+    // >= 160 tiles of 256x256 -> 256x256x64 ring-2 (1 block/CU); fewer -> 256x128x32 ring-3 at 2 blocks/CU (twice the tiles,
+    // 512 slots) which beat both the 256x256 and the 128x128 kernel there; M < 256 / unaligned cases -> 128x128.
+    if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
     else rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
 }

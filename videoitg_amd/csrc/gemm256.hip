@@ -477,7 +477,8 @@ bool gemm256_applicable(const GemmArgs& g, int mode) {
 
 template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
-    const int cfg = tuning().gemm_cfg ? tuning().gemm_cfg : 3;                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
+    int cfg = tuning().gemm_cfg;
+    if (!cfg) cfg = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) >= 160 ? 3 : 2;     // see vitg_gemm (gemm.hip)                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);

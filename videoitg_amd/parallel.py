@@ -67,7 +67,7 @@ class RowGatherer:
         self.plan, self.rank, self.group = plan, rank, group
         self.n_max = max(plan.n_local)
         self.even = len(set(plan.n_local)) == 1
-        self._send = self._recv = self._out = None
+        self._send = self._recv = self._out = self._idx = None
 
     def __call__(self, local: torch.Tensor) -> torch.Tensor:
         p = self.plan
@@ -81,6 +81,15 @@ class RowGatherer:
         dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
         if self.even:
             return self._recv
+        if local.is_cuda:
+            # ragged shards (the prompt tokens sit on the first / last rank): ONE gather-rows launch compacts the padded
+            # receive buffer instead of `world` slice copies
+            from . import ops
+            if self._idx is None:
+                idx = torch.cat([torch.arange(p.n_local[r], dtype=torch.int32) + r * self.n_max for r in range(p.world)])
+                self._idx = idx.to(local.device)
+            ops.gather_rows(self._recv, self._idx, 0, 1, self._out, c)
+            return self._out
         for r in range(p.world):
             self._out[p.offset[r]:p.offset[r] + p.n_local[r]].copy_(self._recv[r * self.n_max:r * self.n_max + p.n_local[r]])
         return self._out
