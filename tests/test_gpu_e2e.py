@@ -164,7 +164,8 @@ def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
         dist.destroy_process_group()
 
 
-def test_full_width_reduced_depth_parity():
+@pytest.mark.parametrize("vit_layers,llm_layers", [(3, 2), (9, 8)])
+def test_full_width_reduced_depth_parity(vit_layers, llm_layers):
     """Real layer widths (SigLIP 1152/4304/16x72, Qwen2 3584/18944, 28 q / 4 kv heads x128, pos-emb interpolation to a
     non-native grid, 16->10 token pool) at reduced depth / frame count so the fp32 oracle finishes on the host: every
     production kernel instantiation (hd 72 and hd 128 attention, 256x256 persistent GEMM incl. K=4352/18944, SwiGLU,
@@ -174,8 +175,8 @@ def test_full_width_reduced_depth_parity():
     from videoitg_amd import ops, synth
     from videoitg_amd.config import ITGConfig, VisionConfig
     from videoitg_amd.engine import PackedWeights, SelectorEngine
-    cfg = ITGConfig(vocab_size=2048, num_hidden_layers=2, vision_token_num=1600,
-                    vision=VisionConfig(image_size=384, num_hidden_layers=3))
+    cfg = ITGConfig(vocab_size=2048, num_hidden_layers=llm_layers, vision_token_num=1600,
+                    vision=VisionConfig(image_size=384, num_hidden_layers=vit_layers))
     T, R = 16, 224                                               # 16x16 grid from a 27x27 table -> bicubic resample
     sd, vsd = synth.synth_llm_state_dict(cfg, 3), synth.synth_vision_state_dict(cfg, 3)
     pix = synth.synth_pixel_values(T, R, seed=77)
@@ -186,7 +187,7 @@ def test_full_width_reduced_depth_parity():
     eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
     got = eng.forward(ids, None, [pix.cuda()])[0].view(-1).float().cpu()
     d = (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item()
-    print(f"full-width: max|dscore|={d:.2e} max|dlogit|={(got - want).abs().max().item():.2e} rounding floor {floor:.2e}; "
+    print(f"full-width {vit_layers - 1}+{llm_layers} layers: max|dscore|={d:.2e} max|dlogit|={(got - want).abs().max().item():.2e} rounding floor {floor:.2e}; "
           f"logit range [{want.min():.2f}, {want.max():.2f}]")
     assert d <= max(SCORE_TOL, 2 * floor), (d, floor)
     _, order = ops.rank(got.cuda())

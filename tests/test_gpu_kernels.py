@@ -35,13 +35,16 @@ def gemm_cfg(request, ops):
     ops.set_option("gemm_cfg", 0)
 
 
-@pytest.fixture(params=[(0, 0), (4, 0), (8, 0), (4, 1)], ids=["auto", "waves4", "waves8", "waves4_pipelined"])
+@pytest.fixture(params=[(0, 0, 0), (4, 0, 2), (8, 0, 2), (4, 1, 2), (4, 0, 1), (8, 0, 1)],
+                ids=["auto", "waves4_reg", "waves8_reg", "waves4_pipelined", "waves4_dma", "waves8_dma"])
 def attn_waves(request, ops):
     ops.set_option("attn_waves", request.param[0])
     ops.set_option("attn_pipe", request.param[1])
+    ops.set_option("attn_dma", request.param[2])
     yield request.param
     ops.set_option("attn_waves", 0)
     ops.set_option("attn_pipe", 0)
+    ops.set_option("attn_dma", 0)
 
 
 def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):

@@ -47,7 +47,7 @@ template <int D> __device__ __forceinline__ int k_lds_off(int row, int chunk) { 
     else return row * 176 + (chunk << 4);
 }
 
-template <typename T, int D, bool TR, int NW, bool ABL = false, bool PIPE = false>
+template <typename T, int D, bool TR, int NW, bool ABL = false, bool PIPE = false, bool DMA = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (256,3) for hd72 spills: 548 -> 428 TF/s
     const int ablate = ABL ? a.ablate : 0;      // ablation switches exist only in the profiling instantiation
     constexpr int ATT_THREADS = NW * 64, ATT_BQ = NW * 32;
@@ -160,6 +160,56 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
     };
     auto store_kv = [&](int buf) { store_one(buf, buf, true, true); };
 
+    // ---- DMA staging (global_load_lds_dwordx4): no staging registers, no ds_write --------------------------------------
+    // One instruction fills 1 KiB of LDS lane-linearly = 64 consecutive 16-B chunks of the tile image; chunk j lives at row
+    // j / CPR, slot j % CPR.  The per-lane SOURCE address carries the layout: hd 128 reads global chunk slot ^ swizzle(row);
+    // hd 72 rows are padded in LDS (K 11 slots, V 12 slots for 9 data chunks): pad slots re-read the row's last data chunk
+    // (finite filler: the K pad only ever meets Q's zero pad, the V pad only feeds output rows that are never stored).
+    constexpr int K_CPR = C::LDK * 2 / 16, V_CPR = C::LDV * 2 / 16;       // = DMA instructions per tile (64 rows * CPR / 64 lanes)
+    constexpr int K_PW = (K_CPR + NW - 1) / NW, V_PW = (V_CPR + NW - 1) / NW;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned dk_off[K_PW], dv_off[V_PW];
+    auto dma_src = [&](int ii, int cpr, int rs, bool is_k, int row_lim) -> unsigned {
+        const int j = ii * 64 + lane;
+        int row = j / cpr, c = j % cpr;
+        if (D == 128) c = is_k ? (c ^ (row & 15)) : (c ^ ((row & 3) << 2));
+        else c = min(c, C::CH - 1);
+        row = min(row, row_lim);
+        return (unsigned)(row * rs + c * 8) * 2u;
+    };
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < K_PW; ++i) dk_off[i] = dma_src(wave_u + NW * i, K_CPR, a.k_rs, true, ATT_BK - 1);
+#pragma unroll
+        for (int i = 0; i < V_PW; ++i) dv_off[i] = dma_src(wave_u + NW * i, V_CPR, a.v_rs, false, ATT_BK - 1);
+    }
+    auto issue_dma = [&](int kt, int buf) {
+        char* kb = smem + buf * (KT_BYTES + VT_BYTES);
+        char* vb = kb + KT_BYTES;
+        const char* Kt = (const char*)(K + (long)kt * ATT_BK * a.k_rs);
+        const char* Vt = (const char*)(V + (long)kt * ATT_BK * a.v_rs);
+        const bool tail = kt * ATT_BK + ATT_BK > a.Sk;          // wave-uniform: clamp rows past the last key
+        const int lim = a.Sk - 1 - kt * ATT_BK;
+#pragma unroll
+        for (int i = 0; i < K_PW; ++i) {
+            const int ii = wave_u + NW * i;
+            if (ii < K_CPR) {
+                const unsigned off = tail ? dma_src(ii, K_CPR, a.k_rs, true, lim) : dk_off[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + off),
+                                                 (__attribute__((address_space(3))) void*)(kb + ii * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V_PW; ++i) {
+            const int ii = wave_u + NW * i;
+            if (ii < V_CPR) {
+                const unsigned off = tail ? dma_src(ii, V_CPR, a.v_rs, false, lim) : dv_off[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + off),
+                                                 (__attribute__((address_space(3))) void*)(vb + ii * 1024), 16, 0, 0);
+            }
+        }
+    };
+
     f32x16 o[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i)
@@ -168,8 +218,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
     float m_run = -1e30f, l_run = 0.f;
 
     const int nkt = ceil_div(a.Sk, ATT_BK);
-    load_kv(0);
-    store_kv(0);
+    if constexpr (DMA) issue_dma(0, 0);
+    else { load_kv(0); store_kv(0); }
     __syncthreads();
 
     // lane-dependent LDS offsets, hoisted: inside the loop every fragment address is one of these + an immediate
@@ -186,7 +236,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
     auto tile = [&](int kt, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
         const bool more = kt + 1 < nkt && !(ablate & 8);
-        if (more) load_kv(kt + 1);
+        if (more) { if constexpr (DMA) issue_dma(kt + 1, BUF ^ 1); else load_kv(kt + 1); }
         const char* kb = smem + BUF * (KT_BYTES + VT_BYTES);
         const char* vb = kb + KT_BYTES;
 
@@ -277,8 +327,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
             }
         }
 
-        if (more) store_kv(BUF ^ 1);
-        __syncthreads();
+        if constexpr (!DMA) { if (more) store_kv(BUF ^ 1); }
+        __syncthreads();                                 // with DMA in flight this also drains vmcnt (next tile landed)
     };
     if constexpr (!PIPE) {
         for (int kt = 0; kt < nkt; kt += 2) {
@@ -394,18 +444,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
     }
 }
 
-template <typename T, int D, bool TR, int NW, bool ABL = false, bool PIPE = false>
+template <typename T, int D, bool TR, int NW, bool ABL = false, bool PIPE = false, bool DMA = false>
 static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
     const size_t lds = 2 * (ATT_BK * C::LDK * 2 + ATT_BK * C::LDV * 2);
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute((const void*)attn_kernel<T, D, TR, NW, ABL, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)attn_kernel<T, D, TR, NW, ABL, PIPE, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         done = true;
     }
     dim3 grid(ceil_div(a.S, NW * 32) * heads * batch);
-    hipLaunchKernelGGL((attn_kernel<T, D, TR, NW, ABL, PIPE>), grid, dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_kernel<T, D, TR, NW, ABL, PIPE, DMA>), grid, dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -437,11 +487,12 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     variant &= 15;
     const bool tr = variant != 1;
     if (!tr) { }     // variant 1 = scalar LDS reads of V (cross-check path for the tr-read)
-    // waves per block: 8 (256 queries share one K/V stream) measured faster for the long LLM sequence, 4 for the
-    // short SigLIP sequences; VITG_ATTN_WAVES=4|8 pins it for A/B measurements
+    // Defaults from same-call A/B (profiles/r01_attention.md): 8 waves / 256 queries per block when that still yields enough
+    // blocks to fill the chip, else 4; K/V staging by LDS-DMA for hd 72 (+16 %: no staging registers -> 3-4 waves/SIMD) and
+    // through registers for hd 128 (DMA measured 3-6 % slower there).  attn_waves / attn_dma (1 = DMA, 2 = registers) pin them.
     const int nw_env = tuning().attn_waves;
-    int nw = nw_env ? nw_env : (head_dim == 128 ? 8 : 4);
-    if (!nw_env && nw == 8 && (long)ceil_div(S, 256) * heads * batch < 384) nw = 4;   // too few 256-query blocks to fill the chip
+    int nw = nw_env ? nw_env : 8;
+    if (!nw_env && (long)ceil_div(S, 256) * heads * batch < 384) nw = 4;       // too few 256-query blocks to fill the chip
     if (a.ablate) {   // profiling instantiations (fp16 only)
         if (dtype != DT_F16) return VITG_ERR_ARG;
         rc = head_dim == 72 ? launch_attn<f16_t, 72, true, 4, true>(a, batch, heads, s) : launch_attn<f16_t, 128, true, 8, true>(a, batch, heads, s);
@@ -451,9 +502,15 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     // hd 72: optional cross-tile software-pipelined variant (QK^T of tile t+1 issued before the softmax of tile t).  Measured
     // equal to the plain loop (549 vs 555 TF/s, profiles/r01_attention.md), so it is opt-in: attn_pipe = 1
     const bool pipe72 = tr && head_dim == 72 && nw == 4 && tuning().attn_pipe == 1;
+    const bool dma = tr && !pipe72 && (tuning().attn_dma == 1 || (tuning().attn_dma == 0 && head_dim == 72));
     if (pipe72) rc = dtype == DT_BF16 ? launch_attn<bf16_t, 72, true, 4, false, true>(a, batch, heads, s)
                                       : launch_attn<f16_t, 72, true, 4, false, true>(a, batch, heads, s);
-    else if (dtype == DT_BF16) rc = head_dim == 72 ? GO(bf16_t, 72) : GO(bf16_t, 128);
+    else if (dma) {
+#define GD(T) (head_dim == 72 ? (nw == 4 ? launch_attn<T, 72, true, 4, false, false, true>(a, batch, heads, s) : launch_attn<T, 72, true, 8, false, false, true>(a, batch, heads, s)) \
+                              : (nw == 4 ? launch_attn<T, 128, true, 4, false, false, true>(a, batch, heads, s) : launch_attn<T, 128, true, 8, false, false, true>(a, batch, heads, s)))
+        rc = dtype == DT_BF16 ? GD(bf16_t) : GD(f16_t);
+#undef GD
+    } else if (dtype == DT_BF16) rc = head_dim == 72 ? GO(bf16_t, 72) : GO(bf16_t, 128);
     else rc = head_dim == 72 ? GO(f16_t, 72) : GO(f16_t, 128);
 #undef GO
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;

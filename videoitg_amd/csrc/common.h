@@ -85,6 +85,7 @@ struct Tuning {
     int gemm_stagger;  // persistent kernel: de-phase XCDs
     int attn_waves;    // 0 auto | 4 | 8
     int attn_pipe;     // 0 off (default) | 1 cross-tile pipelined hd-72 variant
+    int attn_dma;      // 0 auto (DMA for hd 72, registers for hd 128) | 1 LDS-DMA K/V staging | 2 register staging
 };
 Tuning& tuning();
 
