@@ -85,6 +85,13 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
         for (int j = 0; j < LPT; ++j) issue_one(kt, j);
     };
 
+    const int frow = lane & 31, fh = lane >> 5;
+    // Accumulators start at zero -- or, for the fp32 residual update without activation, AT THE RESIDUAL: the tile's
+    // res[(m % res_mod), n] is loaded straight into the accumulator registers before the first DMA is issued, so the read
+    // half of the read-modify-write overlaps the main loop instead of sitting (latency-bound, 256 KiB per tile through the
+    // CU's vector-memory path) in the epilogue; the epilogue then only adds the bias and stores.  (These loads are older
+    // than every DMA in the vmcnt queue, so the counted DMA waits still imply them.)
+    const bool acc_from_res = MODE == MODE_F32 && g.res != nullptr && g.act == VITG_ACT_NONE;
     f32x16 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -92,8 +99,27 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (MODE == MODE_F32) {
+        if (acc_from_res) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + wr * (MT * 32) + mt * 32 + frow;
+                const int rm = g.res_mod > 0 ? m % g.res_mod : m;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int n = n0 + wc * (NT * 32) + nt * 32 + q4 * 8 + fh * 4;
+                        if (m < g.M && n < g.N) {
+                            const f32x4 v = *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[nt][mt][q4 * 4 + e] = v[e];
+                        }
+                    }
+            }
+        }
+    }
 
-    const int frow = lane & 31, fh = lane >> 5;
     // fragment byte offsets inside a tile: row*64 + ((chunk ^ ((row>>3)&3)) << 4); rows = base + 32*i + frow
     int a_off[KS], w_off[KS];
     {
@@ -200,7 +226,15 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
 #undef G2_WAIT_OLDER
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
-    if constexpr (MODE == MODE_F32) {
+    if (MODE == MODE_F32 && acc_from_res && !(g.flags & 16)) {
+        // the residual is already in the accumulator: write-only fp32 tile through the LDS transpose -> full-row stores
+        // (+1.5...4 % over per-lane 16-B stores; flags bit4 selects the direct form for A/B)
+        __builtin_amdgcn_s_barrier();
+        GemmArgs ge = g;
+        ge.res = nullptr;
+        constexpr int SB = 32 * NT * 128;
+        epilogue_staged<T, MODE_F32, MT, NT>(ge, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+    } else if constexpr (MODE == MODE_F32) {
         // fp32 residual update: a lane already owns 16 contiguous bytes per accumulator quad; direct read-modify-write
         // measured faster than staging (the staged form serialises LDS round trip + residual load latency per pass).
         const int frow_ = lane & 31, fh_ = lane >> 5;
@@ -217,7 +251,12 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][q4 * 4 + e];
-                    epilogue_quad<T, MODE>(g, m, n, v);
+                    if (acc_from_res) {                  // residual already inside the accumulator: bias + store only
+                        if (g.bias) v += *(const f32x4*)(g.bias + n);
+                        *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
+                    } else {
+                        epilogue_quad<T, MODE>(g, m, n, v);
+                    }
                 }
         }
     } else {
@@ -483,6 +522,21 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
     if (cfg == 5) return launch256<T, MODE, 256, 2, 2, 64, true>(g, s);       // 5 = inline-asm LDS reads + counted lgkmcnt (measured = cfg 3)
+    // N = k*256 + 128 (SigLIP: 1152 = 4.5 tiles, 3456 = 13.5): a 256-wide last tile would be half padding.  Run the k*256
+    // columns with the 256x256 kernel and the last 128 columns with the 256x128 kernel (two launches, same stream).
+    // Measured: qkv +-0, out-proj -4 %, fc2 +2 % -> off by default (gemm_flags bit5 enables it).
+    if (MODE != MODE_SWIGLU && g.N % 256 == 128 && g.N >= 384 && (tuning().gemm_flags & 32)) {
+        GemmArgs a = g, b = g;
+        a.N = g.N - 128;
+        b.N = 128;
+        b.W = (const char*)g.W + (size_t)a.N * g.ldw * 2;
+        if (g.bias) b.bias = g.bias + a.N;
+        b.out = (char*)g.out + (size_t)a.N * (MODE == MODE_F32 ? 4 : 2);
+        if (g.res) b.res = g.res + a.N;
+        const int rc = launch256<T, MODE, 256, 2, 2, 64, false>(a, s);
+        if (rc) return rc;
+        return launch256<T, MODE, 128, 4, 3, 32>(b, s);
+    }
     return launch256<T, MODE, 256, 2, 2, 64, false>(g, s);
 }
 
