@@ -26,7 +26,7 @@ constexpr int G2_BM = 256, G2_THREADS = 512;
 //   <BN=256, WM=2, STAGES=4>: wave tile 128x64, 128 KiB LDS, 1 block/CU  - best steady state (large K)
 //   <BN=128, WM=4, STAGES=3>: wave tile  64x64,  72 KiB LDS, 2 blocks/CU - one block's prologue/epilogue overlaps the
 //                                                                          other's main loop (small K, heavy epilogues)
-template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false>
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0>
 __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g) {
     typedef typename T16<T>::vec8 vec8;
     constexpr int WN = 8 / WM;
@@ -179,6 +179,79 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = T16<T>::mfma32(FW[nt], FA[mt], acc[nt][mt]); \
     __builtin_amdgcn_s_setprio(0);
 
+    if constexpr (PH) {
+        // ---- phased schedule (cfg 6): strict MFMA / load alternation between the two waves of every SIMD ----------------
+        // Waves 0-3 (group A, rows 0-127) and waves 4-7 (group B, rows 128-255) share the SIMDs pairwise.  Every k-step is
+        // two barrier-delimited intervals, [fragment reads + DMA issue] then [8 MFMAs]; group B runs ONE barrier behind
+        // group A, so in every interval exactly one wave per SIMD issues MFMAs back-to-back (no contention for the matrix
+        // pipe) while its sibling fills fragments / issues DMA.  Intervals (global barrier index i):
+        //   A: R_j in interval 2j, M_j in 2j+1;   B: R_j in 2j+1, M_j in 2j+2       (j = 4*kt + p)
+        // Stage (kt+1)&1 is last read by B's R_{4(kt-1)+3} in interval 8kt-1, so DMA for tile kt+1 may be issued from
+        // interval 8kt on (A: p = 0,1,2 -> 8kt+0,+2,+4; B: 8kt+1,+3,+5); it must have landed before A's R_{4(kt+1)} in interval
+        // 8kt+8: both groups drain vmcnt at the END of interval 8kt+7 (A after M_3, B after R_3).
+        static_assert(PH == 0 || (STAGES == 2 && BK == 64), "phased schedule is written for the 256x256x64 ring-2 configuration");
+        const bool grpB = wr == 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grpB) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PH == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+#pragma unroll
+            for (int pp = 0; pp < KS; ++pp) {
+                G2_READ(fa0, fw0, kt, pp)
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && pp < 3) {
+#pragma unroll
+                    for (int j = 0; j < LPT; ++j)
+                        if (j / 3 == pp) issue_one(kt + 1, j);       // pieces 0-2, 3-5, 6-7 at p = 0, 1, 2
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pp == KS - 1 && more && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                G2_MMA(fa0, fw0)
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp == KS - 1 && more && !grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        } else {
+        // PH == 2: two k-steps (16 MFMAs, ~512 pipe cycles) per interval, 4 barriers per K-tile.  A: R(kt,q) in interval
+        // 4kt+2q, M in 4kt+2q+1; B one interval later.  Stage (kt+1)&1 is free from interval 4kt on; it must be complete
+        // before interval 4kt+4: drain at the end of 4kt+3 (A after its M(kt,1), B after its R(kt,1)).  B therefore issues all
+        // its DMA in its first R phase (interval 4kt+1); A splits 4 + 4 over intervals 4kt and 4kt+2.
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+#pragma unroll
+            for (int q = 0; q < KS / 2; ++q) {
+                G2_READ(fa0, fw0, kt, 2 * q)
+                G2_READ(fa1, fw1, kt, 2 * q + 1)
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < LPT; ++j)
+                        if (grpB ? (q == 0) : (j / 4 == q)) issue_one(kt + 1, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (q == KS / 2 - 1 && more && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                G2_MMA(fa0, fw0)
+                G2_MMA(fa1, fw1)
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == KS / 2 - 1 && more && !grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        }
+        if (!grpB) __builtin_amdgcn_s_barrier();          // pair group B's extra barrier
+    } else {
     wait_tile(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -221,6 +294,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    }   // !PH
 #undef G2_READ
 #undef G2_MMA
 #undef G2_WAIT_OLDER
@@ -492,17 +566,17 @@ static int launch256p(GemmArgs g, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false>
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0>
 static int launch256(GemmArgs g, hipStream_t s) {
     constexpr int lds = STAGES * (G2_BM * BK * 2 + BN * BK * 2);
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
     g.tiles_m = ceil_div(g.M, G2_BM);
     g.tiles_n = ceil_div(g.N, BN);
-    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
+    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
 
@@ -517,10 +591,12 @@ bool gemm256_applicable(const GemmArgs& g, int mode) {
 template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     int cfg = tuning().gemm_cfg;
-    if (!cfg) cfg = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) >= 160 ? 3 : 2;     // see vitg_gemm (gemm.hip)                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
+    if (!cfg) cfg = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) >= 160 ? 6 : 2;     // see vitg_gemm (gemm.hip)                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
+    if (cfg == 6) return launch256<T, MODE, 256, 2, 2, 64, false, 1>(g, s);     // 6 = phased, 1 k-step per interval
+    if (cfg == 7) return launch256<T, MODE, 256, 2, 2, 64, false, 2>(g, s);     // 7 = phased, 2 k-steps per interval
     if (cfg == 5) return launch256<T, MODE, 256, 2, 2, 64, true>(g, s);       // 5 = inline-asm LDS reads + counted lgkmcnt (measured = cfg 3)
     // N = k*256 + 128 (SigLIP: 1152 = 4.5 tiles, 3456 = 13.5): a 256-wide last tile would be half padding.  Run the k*256
     // columns with the 256x256 kernel and the last 128 columns with the 256x128 kernel (two launches, same stream).
