@@ -21,13 +21,13 @@ def ops():
     return o
 
 
-@pytest.fixture(params=["auto", "tile128", "cfg1_256x256x32", "cfg2_256x128x32", "cfg3_256x256x64", "cfg4_persistent", "cfg5_asm_reads", "cfg6_phased", "cfg7_phased2"])
+@pytest.fixture(params=["auto", "tile128", "cfg1_256x256x32", "cfg2_256x128x32", "cfg3_256x256x64", "cfg4_persistent", "cfg5_asm_reads", "cfg6_phased", "cfg7_phased2", "cfg8_w4_128x128"])
 def gemm_cfg(request, ops):
     """Every GEMM kernel configuration is forced in turn (vitg_set_option), so the 256-tile kernels are covered at test
     sizes too (auto mode would pick the 128 tile for them)."""
     name = request.param
     tile, cfg = {"auto": (0, 0), "tile128": (128, 0), "cfg1_256x256x32": (256, 1), "cfg2_256x128x32": (256, 2),
-                 "cfg3_256x256x64": (256, 3), "cfg4_persistent": (256, 4), "cfg5_asm_reads": (256, 5), "cfg6_phased": (256, 6), "cfg7_phased2": (256, 7)}[name]
+                 "cfg3_256x256x64": (256, 3), "cfg4_persistent": (256, 4), "cfg5_asm_reads": (256, 5), "cfg6_phased": (256, 6), "cfg7_phased2": (256, 7), "cfg8_w4_128x128": (256, 8)}[name]
     ops.set_option("gemm_tile", tile)
     ops.set_option("gemm_cfg", cfg)
     yield name
@@ -35,16 +35,14 @@ def gemm_cfg(request, ops):
     ops.set_option("gemm_cfg", 0)
 
 
-@pytest.fixture(params=[(0, 0, 0), (4, 0, 2), (8, 0, 2), (4, 1, 2), (4, 0, 1), (8, 0, 1)],
-                ids=["auto", "waves4_reg", "waves8_reg", "waves4_pipelined", "waves4_dma", "waves8_dma"])
+@pytest.fixture(params=[(0, 0, 0, 0), (4, 0, 2, 2), (8, 0, 2, 2), (4, 1, 2, 2), (4, 0, 1, 2), (8, 0, 1, 2), (4, 0, 0, 1), (8, 0, 0, 1)],
+                ids=["auto", "waves4_reg", "waves8_reg", "waves4_pipelined", "waves4_dma", "waves8_dma", "waves4_swpipe", "waves8_swpipe"])
 def attn_waves(request, ops):
-    ops.set_option("attn_waves", request.param[0])
-    ops.set_option("attn_pipe", request.param[1])
-    ops.set_option("attn_dma", request.param[2])
+    for key, val in zip(("attn_waves", "attn_pipe", "attn_dma", "attn_sp"), request.param):
+        ops.set_option(key, val)
     yield request.param
-    ops.set_option("attn_waves", 0)
-    ops.set_option("attn_pipe", 0)
-    ops.set_option("attn_dma", 0)
+    for key in ("attn_waves", "attn_pipe", "attn_dma", "attn_sp"):
+        ops.set_option(key, 0)
 
 
 def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
@@ -148,9 +146,10 @@ def test_attention(ops, attn_waves, dtype, variant, B, H, HKV, S, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_spiked_key_forces_rescale(ops, dtype):
+@pytest.mark.parametrize("D", [128, 72])
+def test_attention_spiked_key_forces_rescale(ops, attn_waves, dtype, D):
     """One key far above the rest in a late tile: exercises the online-softmax rescale with a large max jump."""
-    B, H, S, D = 1, 1, 300, 128
+    B, H, S = 1, 1, 300
     q, k, v = rnd((B, H, S, D), 30, dtype=dtype), rnd((B, H, S, D), 31, dtype=dtype), rnd((B, H, S, D), 32, dtype=dtype)
     k[0, 0, 257] = (q[0, 0, 5] * 4).to(dtype).float()
     want = ref_attention(q, k, v, D ** -0.5)

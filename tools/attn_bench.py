@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Attention kernel throughput on the two production shapes (random data).  python tools/attn_bench.py [fp16|bf16]"""
+"""Attention kernel throughput on the production shapes (random data).
+python tools/attn_bench.py [fp16|bf16] [opt=value ...]     e.g.  attn_q64=1 attn_waves=8"""
 import os
 import sys
 import torch
@@ -7,8 +8,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops  # noqa: E402
 
-dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float16
-for name, B, H, HKV, S, D in [("vit448", 512, 16, 16, 1024, 72), ("vit384", 512, 16, 16, 729, 72), ("llm", 1, 28, 4, 12860, 128)]:
+dt = torch.bfloat16 if "bf16" in sys.argv[1:] else torch.float16
+for a in sys.argv[1:]:
+    if "=" in a:
+        k, v = a.split("=")
+        ops.set_option(k, int(v))
+for name, B, H, HKV, S, D in [("vit448", 512, 16, 16, 1024, 72), ("vit384", 512, 16, 16, 729, 72), ("vit448/8", 64, 16, 16, 1024, 72),
+                              ("llm", 1, 28, 4, 12860, 128)]:
     ld = (H + 2 * HKV) * D
     qkv = torch.randn((B * S, ld), device="cuda").to(dt)
     o = torch.empty((B * S, H * D), dtype=dt, device="cuda")

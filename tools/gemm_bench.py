@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-shape GEMM throughput on the GPU (random fp16/bf16 data).  VITG_GEMM_TILE=128|256 pins the kernel.
-    python tools/gemm_bench.py [fp16|bf16]"""
+    python tools/gemm_bench.py [fp16|bf16] [gemm_cfg=N ...]"""
 import os
 import sys
 import torch
@@ -8,7 +8,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops  # noqa: E402
 
-dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float16
+dt = torch.bfloat16 if "bf16" in sys.argv[1:] else torch.float16
+for arg in sys.argv[1:]:          # opt=value pairs go to vitg_set_option, e.g. gemm_cfg=8
+    if "=" in arg:
+        k_, v_ = arg.split("=")
+        ops.set_option(k_, int(v_))
 SHAPES = [  # name, M, N, K, mode
     ("vit_qkv", 524288, 3456, 1152, ops.GEMM_STORE16),
     ("vit_fc1", 524288, 4352, 1152, ops.GEMM_STORE16),

@@ -11,44 +11,15 @@
 // identically for P (B operand) and V (A operand), which a contraction is invariant to.
 //
 // Block = 4 waves x 32 queries = 128 queries; KV tile = 64 keys, double-buffered in LDS.
-#include "common.h"
+#include "attn_common.h"
 #include "../../include/videoitg_hip.h"
 #include <type_traits>
 #include <stdlib.h>
 
 namespace vitg {
 
-struct AttnArgs {
-    const void* q; const void* k; const void* v; void* o;
-    long q_bs, k_bs, v_bs, o_bs;     // batch strides (elements)
-    int q_rs, k_rs, v_rs, o_rs;      // row (token) strides (elements)
-    int q_hs, k_hs, v_hs, o_hs;      // head strides (elements)
-    int S;                           // number of queries
-    int Sk;                          // number of keys (== S unless the keys were all-gathered from other ranks)
-    int group;                       // q heads per kv head
-    int kv_heads, nqb;               // kv heads, q-blocks per head
-    int ablate;                      // profiling only (tools/attn_ablate.py): bit0 no QK^T, bit1 no exp, bit2 no PV, bit3 no K/V staging
-    float scale_log2e;               // softmax scale * log2(e)
-};
-
-constexpr int ATT_BK = 64;
-// NW waves per block, 32 queries per wave: BQ = 32*NW queries share one K/V staging stream (NW = 8: 256 queries, 1 block/CU;
-// NW = 4: 128 queries, 2 blocks/CU)
-
-template <int D> struct AttnCfg;
-template <> struct AttnCfg<128> { static constexpr int DK = 128, DV = 128, LDK = 128, LDV = 128, CH = 16; };
-// K rows: 80 used (d 72..79 zero) at a row stride of 88 elements = 176 B: 176*r mod 256 takes 16 distinct 16-B slots
-// over the rows of every ds_read_b128 lane group -> conflict-free (160 B collided rows r and r+8: measured 35 % of LDS
-// cycles).  V rows padded to 96 (192 B, conflict-free for the tr reads; the pad is never stored to the output).
-template <> struct AttnCfg<72> { static constexpr int DK = 80, DV = 96, LDK = 88, LDV = 96, CH = 9; };
-
-template <int D> __device__ __forceinline__ int k_lds_off(int row, int chunk) {   // bytes
-    if constexpr (D == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);
-    else return row * 176 + (chunk << 4);
-}
-
 template <typename T, int D, bool TR, int NW, bool ABL = false, bool PIPE = false, bool DMA = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (256,3) for hd72 spills: 548 -> 428 TF/s
+__global__ __launch_bounds__(NW * 64, (NW == 8 && D == 72 && DMA) ? 4 : 2) void attn_kernel(AttnArgs a) {   // (256,3) for hd72 spills: 548 -> 428 TF/s
     const int ablate = ABL ? a.ablate : 0;      // ablation switches exist only in the profiling instantiation
     constexpr int ATT_THREADS = NW * 64, ATT_BQ = NW * 32;
     typedef typename T16<T>::vec8 vec8;
@@ -233,6 +204,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) voff_dt[dt] = voff + (D == 128 ? ((dt ^ ((lane & 15) >> 2)) * 64) : dt * 64);
 
+    const char* kbase[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kbase[ks] = smem + koff[ks];
+    const char* vbase[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vbase[dt] = smem + voff_dt[dt];
+
     auto tile = [&](int kt, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
         const bool more = kt + 1 < nkt && !(ablate & 8);
@@ -244,13 +222,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
         f32x16 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            if (ABL && (ablate & 1)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-            if (!(ablate & 1)) {
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            } else {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const vec8 kf = *(const vec8*)(kb + koff[ks] + t * 32 * (C::LDK * 2));
-                    s[t] = T16<T>::mfma32(kf, qf[ks], s[t]);
+                    const vec8 kf = *(const vec8*)(kbase[ks] + (BUF * (KT_BYTES + VT_BYTES) + t * 32 * (C::LDK * 2)));
+                    // first k-step accumulates onto a literal zero (inline constant C operand): no 32 v_mov to clear s
+                    s[t] = ks == 0 ? T16<T>::mfma32(kf, qf[0], f32x16{}) : T16<T>::mfma32(kf, qf[ks], s[t]);
                 }
             }
         }
@@ -284,17 +264,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
                 for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             m_run = m_new;
         }
-        float psum = 0.f;
+        // The softmax block is VALU-issue bound (PMC: VALU busy > MFMA busy), so the exponent arguments and the row sum
+        // use packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two scores per issue); the 32 v_exp_f32 stay scalar.
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 sc2 = {a.scale_log2e, a.scale_log2e};
+        const f32x2 nm2 = {-m_run, -m_run};
         vec8 pf[4];                      // k-step kk = 2*t + u uses s[t][8u .. 8u+7]
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = (ablate & 2) ? s[t][r] : __builtin_amdgcn_exp2f(fmaf(s[t][r], a.scale_log2e, -m_run));
-                psum += p;
-                pf[t * 2 + (r >> 3)][r & 7] = T16<T>::from_f32(p);
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v = {s[t][r], s[t][r + 1]};
+                if (!(ABL && (ablate & 2))) {
+                    v = __builtin_elementwise_fma(v, sc2, nm2);
+                    v = f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                }
+                psum2 += v;
+                pf[t * 2 + (r >> 3)][r & 7] = T16<T>::from_f32(v[0]);
+                pf[t * 2 + (r >> 3)][(r & 7) + 1] = T16<T>::from_f32(v[1]);
             }
-        l_run += psum;
+        l_run += psum2[0] + psum2[1];
 
         // ---- O^T += V^T P^T ----------------------------------------------------------------------------
         // k-step kk (16 keys: tile t = kk>>1, half u = kk&1): slot (h, j) <-> key t*32 + u*16 + 8*(j>>2) + 4*h + (j&3)
@@ -307,12 +296,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a) {   // (25
             for (int dt = 0; dt < DT; ++dt) {
                 vec8 vf;
                 if constexpr (TR) {
-                    const char* a0 = vb + voff_dt[dt] + krow * (C::LDV * 2);
+                    // one hoisted base pointer per d-tile + compile-time offsets (they fold into the instruction's offset field)
+                    const char* a0 = vbase[dt] + (BUF * (KT_BYTES + VT_BYTES) + KT_BYTES + krow * (C::LDV * 2));
                     const char* a1 = a0 + 8 * (C::LDV * 2);
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
-                    s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    vf = bitcast<vec8>(both);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+                    vf = bitcast<vec8>(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 } else {
                     const T* vt = (const T*)vb;
                     const int d = dt * 32 + ql;
@@ -459,6 +448,8 @@ static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, hipStream_t s);   // attention_sp.hip
+
 }  // namespace vitg
 
 using namespace vitg;
@@ -493,7 +484,7 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     const int nw_env = tuning().attn_waves;
     int nw = nw_env ? nw_env : 8;
     if (!nw_env && (long)ceil_div(S, 256) * heads * batch < 384) nw = 4;       // too few 256-query blocks to fill the chip
-    if (a.ablate) {   // profiling instantiations (fp16 only)
+    if (a.ablate && tuning().attn_sp != 1) {   // profiling instantiations (fp16 only)
         if (dtype != DT_F16) return VITG_ERR_ARG;
         rc = head_dim == 72 ? launch_attn<f16_t, 72, true, 4, true>(a, batch, heads, s) : launch_attn<f16_t, 128, true, 8, true>(a, batch, heads, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
@@ -501,6 +492,12 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
 #define GO(T, D) (!tr ? launch_attn<T, D, false, 4>(a, batch, heads, s) : nw == 4 ? launch_attn<T, D, true, 4>(a, batch, heads, s) : launch_attn<T, D, true, 8>(a, batch, heads, s))
     // hd 72: optional cross-tile software-pipelined variant (QK^T of tile t+1 issued before the softmax of tile t).  Measured
     // equal to the plain loop (549 vs 555 TF/s, profiles/r01_attention.md), so it is opt-in: attn_pipe = 1
+    // Software-pipelined loop (attention_sp.hip): default for hd 128 (LLM shape 1023 vs 916 TF/s); for hd 72 the per-tile
+    // kernel at 4 waves/SIMD is still ahead (630 vs 597 TF/s), profiles/r01_attention.md.  attn_sp = 1 / 2 pins it on / off.
+    if (tr && (tuning().attn_sp == 1 || (tuning().attn_sp == 0 && head_dim == 128 && !a.ablate))) {
+        rc = attention_sp_dispatch(a, batch, heads, head_dim, dtype, nw, s);
+        return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+    }
     const bool pipe72 = tr && head_dim == 72 && nw == 4 && tuning().attn_pipe == 1;
     const bool dma = tr && !pipe72 && (tuning().attn_dma == 1 || (tuning().attn_dma == 0 && head_dim == 72));
     if (pipe72) rc = dtype == DT_BF16 ? launch_attn<bf16_t, 72, true, 4, false, true>(a, batch, heads, s)

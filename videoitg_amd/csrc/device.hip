@@ -23,7 +23,7 @@ namespace vitg {
 static int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; }
 Tuning& tuning() {
     static Tuning t = {env_int("VITG_GEMM_TILE"), env_int("VITG_GEMM_CFG"), env_int("VITG_GEMM_FLAGS"), env_int("VITG_GEMM_STAGGER"),
-                       env_int("VITG_ATTN_WAVES"), env_int("VITG_ATTN_PIPE"), env_int("VITG_ATTN_DMA")};
+                       env_int("VITG_ATTN_WAVES"), env_int("VITG_ATTN_PIPE"), env_int("VITG_ATTN_DMA"), env_int("VITG_ATTN_SP")};
     return t;
 }
 }  // namespace vitg
@@ -38,6 +38,7 @@ extern "C" int vitg_set_option(const char* key, int value) {
     else if (!strcmp(key, "attn_waves")) t.attn_waves = value;
     else if (!strcmp(key, "attn_pipe")) t.attn_pipe = value;
     else if (!strcmp(key, "attn_dma")) t.attn_dma = value;
+    else if (!strcmp(key, "attn_sp")) t.attn_sp = value;
     else return VITG_ERR_ARG;
     return 0;
 }

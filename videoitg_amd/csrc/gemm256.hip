@@ -17,6 +17,7 @@
 // consecutive output features of one token.
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace vitg {
 
@@ -592,6 +593,7 @@ template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     int cfg = tuning().gemm_cfg;
     if (!cfg) cfg = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) >= 160 ? 6 : 2;     // see vitg_gemm (gemm.hip)                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
+    if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);

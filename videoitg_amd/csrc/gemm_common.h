@@ -180,5 +180,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 
 int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s);   // gemm256.hip
 bool gemm256_applicable(const GemmArgs& g, int mode);
+int launch_gemm_w4(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_w4.hip
+bool gemm_w4_applicable(const GemmArgs& g, int mode);
 
 }  // namespace vitg
