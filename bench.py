@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="full", choices=["full", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the from-uint8-frames (GPU preprocessing) measurement")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -251,6 +252,30 @@ def main():
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)},
             "top32": sorted(order[:32]),
         }
+        if world == 1 and not args.no_secondary:
+            # SURVEY.md 8d "secondary": the same job starting from decoded uint8 NHWC frames resident in HBM (GPU
+            # preprocessing front-end, row N2, in front of the selector forward).  Reported beside `value`, never as `value`.
+            frames = torch.randint(0, 256, (T, 720, 1280, 3), dtype=torch.uint8, device=dev)
+
+            def step_u8():
+                px = ops.preprocess_u8(frames, R, dtype)
+                _, order_ = ops.rank(eng.forward(ids, None, [px])[0].view(-1))
+                return order_.cpu().tolist()
+            step_u8()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step_u8()
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.preprocess_u8(frames, R, dtype)
+            e1.record()
+            torch.cuda.synchronize()
+            out["secondary"] = {"from_uint8_frames": {"input": f"{T} x 720x1280x3 uint8 NHWC in HBM", "value": round(T / d1, 2),
+                                                      "unit": "frames/s", "ms_per_step": round(d1 * 1e3, 2),
+                                                      "preprocess_ms": round(e0.elapsed_time(e1), 3)}}
+            del frames
         if world == 1 and not args.no_cpu_baseline:
             eng.release_workspace()
             try:

@@ -116,6 +116,17 @@ int vitg_pool_score(const float* h, int ldh, int frames, int tokens_per_frame, i
  * (whose tie order is unspecified; this one is deterministic). */
 int vitg_rank(const float* logits, int n, float* scores, int* order, void* stream);
 
+/* Frame preprocessing in front of the tower.  Replaces the CPU call
+ *   image_processor.preprocess(frames, return_tensors="pt")["pixel_values"]
+ * at /root/reference/infer.py:55 and lmms_eval/models/videoitg.py:282,286 (third-party SiglipImageProcessor created at
+ * eagle/model/multimodal_encoder/clip_encoder.py:115: Pillow BICUBIC resize on uint8, x * 1/255, (x - 0.5) / 0.5, HWC -> CHW).
+ * frames: uint8 [T,H,W,3] device memory, strides in bytes (row_stride >= 3 W, frame_stride >= H row_stride);
+ * out: [T,3,S,S] contiguous of out_dtype (VITG_F32 reproduces the reference's fp32 tensor bit for bit, VITG_F16 / VITG_BF16 its
+ * .half() / .bfloat16()); tmp: scratch of vitg_preprocess_tmp_bytes bytes (may be null when that is 0). */
+int vitg_preprocess_tmp_bytes(int T, int H, int W, int S, long* bytes);
+int vitg_preprocess_u8(const void* frames, int T, int H, int W, long frame_stride, int row_stride, void* out, int S,
+                       int out_dtype, void* tmp, long tmp_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""Frame preprocessing: oracle and host twin against vectors made with the real
+SiglipImageProcessor + Pillow (tests/golden/make_preprocess_golden.py); GPU kernel against the oracle, bit-exact."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import preprocess_oracle as PO
+from videoitg_amd.synth import synth_video_frames
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SMALL = ["down", "up", "same", "odd"]
+HD = ["hd720", "hd1080"]
+
+
+def _frames(spec):
+    seed, T, H, W, S = [int(v) for v in spec]
+    return synth_video_frames(seed, T, H, W), S
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_matches_real_processor_small(name):
+    z = np.load(os.path.join(GOLD, "preprocess_small.npz"))
+    fr, S = _frames(z[f"{name}_spec"])
+    assert np.array_equal(PO.pil_bicubic_resize(fr[0], S, S), z[f"{name}_u8"])            # integer resize: bit-exact
+    got = PO.preprocess(fr, S)
+    assert got.dtype == np.float32 and np.array_equal(got, z[f"{name}_out"])               # same float32 bits
+
+
+@pytest.mark.parametrize("name", HD)
+def test_oracle_matches_real_processor_hd(name):
+    z = np.load(os.path.join(GOLD, "preprocess_hd.npz"))
+    fr, S = _frames(z[f"{name}_spec"])
+    u8 = PO.pil_bicubic_resize(fr[0], S, S)
+    assert zlib.crc32(np.ascontiguousarray(u8).tobytes()) == int(z[f"{name}_crc"][0])
+    out = PO.preprocess(fr, S)
+    assert np.array_equal(out.reshape(-1)[z[f"{name}_idx"]], z[f"{name}_val"])
+    assert out.astype(np.float64).sum() == float(z[f"{name}_sum"][0])
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_host_twin_matches_real_processor(name):
+    from videoitg_amd.image_processor import SiglipImageProcessor
+    z = np.load(os.path.join(GOLD, "preprocess_small.npz"))
+    fr, S = _frames(z[f"{name}_spec"])
+    got = SiglipImageProcessor(size=S).preprocess(fr, return_tensors="pt")["pixel_values"]
+    assert got.dtype == torch.float32 and np.array_equal(got.numpy(), z[f"{name}_out"])
+
+
+def test_resample_coeffs_properties():
+    """fixed-point rows sum to 2^22 within the per-tap rounding; windows stay inside the image; identity when sizes match"""
+    for n_in, n_out in [(1280, 384), (40, 56), (56, 56), (33, 42), (1920, 448)]:
+        b, k = PO.resample_coeffs(n_in, n_out)
+        assert (b[:, 0] >= 0).all() and (b[:, 0] + b[:, 1] <= n_in).all()
+        assert np.abs(k.sum(1) - (1 << 22)).max() <= k.shape[1]
+    img = np.random.default_rng(0).integers(0, 256, (9, 7, 3), dtype=np.uint8)
+    assert np.array_equal(PO.pil_bicubic_resize(img, 9, 7), img)
+
+
+def test_normalise_lut_is_the_transformers_arithmetic():
+    lut = PO.normalise_lut()
+    assert lut[0] == -1.0 and lut[255] == 1.0 and lut.dtype == np.float32
+    u = np.arange(256)
+    want = ((u.astype(np.float64) * (1 / 255)).astype(np.float32) - np.float32(0.5)) / np.float32(0.5)
+    assert np.array_equal(lut, want)
+
+
+# ---- GPU --------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL + HD)
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_gpu_preprocess_bit_exact(name, out_dtype):
+    from videoitg_amd import ops
+    z = np.load(os.path.join(GOLD, "preprocess_small.npz" if name in SMALL else "preprocess_hd.npz"))
+    fr, S = _frames(z[f"{name}_spec"])
+    want = torch.from_numpy(PO.preprocess(fr, S)).to(out_dtype)          # .half() of the fp32 result = what infer.py:55 feeds the model
+    got = ops.preprocess_u8(torch.from_numpy(fr).cuda(), S, out_dtype)
+    assert got.shape == (fr.shape[0], 3, S, S) and got.dtype == out_dtype
+    assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_strided_batch_and_errors():
+    from videoitg_amd import ops
+    from videoitg_amd._lib import VitgError
+    fr = synth_video_frames(5, 6, 48, 64)
+    big = torch.from_numpy(fr).cuda()
+    got = ops.preprocess_u8(big[1:5], 56, torch.float32)                # a view into a larger clip
+    assert torch.equal(got.cpu(), torch.from_numpy(PO.preprocess(fr[1:5], 56)))
+    with pytest.raises((VitgError, ValueError, TypeError)):
+        ops.preprocess_u8(big.float(), 56, torch.float32)               # not uint8
+    assert ops.preprocess_u8(big[:0], 56, torch.float32).shape == (0, 3, 56, 56)
+
+
+@pytest.mark.gpu
+def test_gpu_image_processor_front_end_matches_host_twin():
+    from videoitg_amd.image_processor import SiglipImageProcessor
+    fr = synth_video_frames(9, 4, 120, 160)
+    host = SiglipImageProcessor(size=56).preprocess(fr, return_tensors="pt")["pixel_values"]
+    dev = SiglipImageProcessor(size=56).preprocess(torch.from_numpy(fr).cuda(), return_tensors="pt")["pixel_values"]
+    assert dev.is_cuda and torch.equal(dev.cpu(), host)

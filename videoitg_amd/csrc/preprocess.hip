@@ -1,0 +1,281 @@
+// Frame preprocessing on the GPU (replaces the CPU call at /root/reference/infer.py:55):
+//   uint8 NHWC frames [T,H,W,3] -> Pillow-exact BICUBIC resize to S x S (uint8) -> x/255 -> (x - 0.5)/0.5 -> NCHW [T,3,S,S]
+// Byte/integer work, HBM-bound: the arithmetic is Pillow's 8-bit resampler restated bit for bit (oracle/preprocess_oracle.py
+// holds the CPU restatement this is tested against): separable, horizontal pass first into a uint8 intermediate, 22-bit
+// fixed-point weights, int32 accumulation from 2^21, >> 22, clip to [0,255].  The float stage has only 256 possible inputs,
+// so it is a 256-entry table computed on the host with exactly transformers' operations (float64 product, cast, float32
+// subtract / divide) and the kernel's store is table[byte] (rounded to 16 bit on request, RNE = what `.half()` does).
+#include "common.h"
+#include "../../include/videoitg_hip.h"
+#include <math.h>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace vitg {
+
+constexpr int PP_BITS = 32 - 8 - 2;        // Pillow's PRECISION_BITS
+
+struct ResampleTable {
+    int ksize = 0;
+    int* bounds = nullptr;                 // device [out][2] = (first input index, tap count)
+    int* kk = nullptr;                     // device [out][ksize] fixed-point weights
+};
+
+static double bicubic_w(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc, uploaded once per (in, out) pair and kept for the life of the library
+static int get_table(int in_size, int out_size, ResampleTable& t) {
+    static std::map<std::pair<int, int>, ResampleTable> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({in_size, out_size});
+    if (it != cache.end()) { t = it->second; return 0; }
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    std::vector<int> bounds((size_t)out_size * 2), kk((size_t)out_size * ksize, 0);
+    std::vector<double> w(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        const int n = xmax - xmin;
+        double ww = 0.0;
+        for (int x = 0; x < n; ++x) { w[x] = bicubic_w((x + xmin - center + 0.5) * ss); ww += w[x]; }
+        for (int x = 0; x < n; ++x) {
+            const double v = ww != 0.0 ? w[x] / ww : w[x];
+            kk[(size_t)xx * ksize + x] = (int)(v * (1 << PP_BITS) + (v < 0 ? -0.5 : 0.5));
+        }
+        bounds[xx * 2] = xmin;
+        bounds[xx * 2 + 1] = n;
+    }
+    ResampleTable nt;
+    nt.ksize = ksize;
+    if (hipMalloc(&nt.bounds, bounds.size() * sizeof(int)) != hipSuccess) return VITG_ERR_LAUNCH;
+    if (hipMalloc(&nt.kk, kk.size() * sizeof(int)) != hipSuccess) return VITG_ERR_LAUNCH;
+    if (hipMemcpy(nt.bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return VITG_ERR_LAUNCH;
+    if (hipMemcpy(nt.kk, kk.data(), kk.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return VITG_ERR_LAUNCH;
+    cache[{in_size, out_size}] = nt;
+    t = nt;
+    return 0;
+}
+
+static const float* get_lut() {
+    static float* d_lut = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (d_lut) return d_lut;
+    float h[256];
+    const double factor = 1.0 / 255.0;                 // transformers rescale_factor = 1/255 (a Python float)
+    for (int u = 0; u < 256; ++u) {
+        const float x = (float)((double)u * factor);   // rescale: float64 product, then the cast
+        h[u] = (x - 0.5f) / 0.5f;                       // normalize in float32
+    }
+    if (hipMalloc(&d_lut, sizeof(h)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d_lut, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d_lut;
+}
+
+__device__ __forceinline__ int clip8(int acc) {
+    const int v = acc >> PP_BITS;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// ---- pass 1: horizontal.  One block per (group of PP_ROWS input rows, frame t), one thread per output pixel x (all three
+// channels).  The pixel's window (first tap, tap count) and its fixed-point weights are loop-invariant over the rows: the
+// weights sit in LDS (loaded once per block), the window in registers.  Each row is staged in LDS with aligned 16-B loads (the
+// 16-B units that contain row bytes never leave the allocation).  tmp is [T][H][S][3] uint8.
+constexpr int PP_ROWS = 8;
+
+__global__ __launch_bounds__(512) void resample_h_kernel(const uint8_t* __restrict__ src, long frame_stride, int row_stride, int W, int S,
+                                                         const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                         uint8_t* __restrict__ tmp, int H, int row_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* row = lds;                                  // [2][row_lds]: double-buffered input row
+    int* kl = (int*)(lds + 2 * row_lds);                 // [S][ksize]
+    const int y_first = blockIdx.x * PP_ROWS, t = blockIdx.y;
+    const int rows = min(PP_ROWS, H - y_first);
+    for (int i = threadIdx.x; i < S * ksize; i += blockDim.x) kl[i] = kk[i];
+    auto stage = [&](int r) -> int {                     // returns the misalignment of the row start inside its first 16-B unit
+        const uint8_t* p = src + (size_t)t * frame_stride + (size_t)(y_first + r) * row_stride;
+        const int mis = (int)((size_t)p & 15);
+        const u32x4* a = (const u32x4*)(p - mis);
+        const int units = (mis + W * 3 + 15) >> 4;
+        u32x4* dst = (u32x4*)(row + (r & 1) * row_lds);
+        for (int i = threadIdx.x; i < units; i += blockDim.x) dst[i] = a[i];
+        return mis;
+    };
+    int mis = stage(0);
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+        const uint8_t* cur = row + (r & 1) * row_lds + mis;
+        int mis_next = 0;
+        if (r + 1 < rows) mis_next = stage(r + 1);      // next row streams in while this one is consumed
+        uint8_t* out = tmp + ((size_t)t * H + y_first + r) * S * 3;
+        for (int x = threadIdx.x; x < S; x += blockDim.x) {
+            const int x0 = bounds[2 * x], n = bounds[2 * x + 1];
+            const int* k = kl + x * ksize;
+            const uint8_t* px = cur + x0 * 3;
+            int a0 = 1 << (PP_BITS - 1), a1 = a0, a2 = a0;
+            for (int j = 0; j < n; ++j) {
+                const int kj = k[j];
+                a0 += (int)px[3 * j] * kj;
+                a1 += (int)px[3 * j + 1] * kj;
+                a2 += (int)px[3 * j + 2] * kj;
+            }
+            out[3 * x] = (uint8_t)clip8(a0);
+            out[3 * x + 1] = (uint8_t)clip8(a1);
+            out[3 * x + 2] = (uint8_t)clip8(a2);
+        }
+        mis = mis_next;
+        __syncthreads();
+    }
+}
+
+// ---- pass 2: vertical + normalise + layout.  The vertical filter is independent per byte column of the interleaved [x][c]
+// row, so one thread owns FOUR consecutive byte columns and reads one aligned dword per tap (coalesced 256 B per wave
+// instruction instead of 64 x 1 B); the four results go through an LDS row so that the NCHW planes are written contiguously.
+// One block per (output row y, frame t).  VERT = false: the height already matches (table lookup only).
+// Requires 4-byte aligned rows (in_row_stride % 4 == 0 and base % 4 == 0); the launcher falls back to the byte kernel otherwise.
+template <typename TO, bool VERT>
+__global__ __launch_bounds__(512) void resample_v4_kernel(const uint8_t* __restrict__ in, long in_frame_stride, int in_row_stride, int S,
+                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                          const float* __restrict__ lut, TO* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t vrow[];          // [S*3] resampled bytes of this output row
+    const int y = blockIdx.x, t = blockIdx.y;
+    const uint8_t* base = in + (size_t)t * in_frame_stride;
+    int y0 = y, n = 1;
+    const int* k = nullptr;
+    if (VERT) { y0 = bounds[2 * y]; n = bounds[2 * y + 1]; k = kk + (size_t)y * ksize; }
+    const int nd = (S * 3 + 3) >> 2;                     // dwords per row (the last one may run into row padding: rows are >= 4-B padded by the caller check)
+    for (int d = threadIdx.x; d < nd; d += blockDim.x) {
+        if (VERT) {
+            int a0 = 1 << (PP_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
+            for (int j = 0; j < n; ++j) {
+                const uint32_t w = *(const uint32_t*)(base + (size_t)(y0 + j) * in_row_stride + 4 * d);
+                const int kj = k[j];
+                a0 += (int)(w & 255u) * kj;
+                a1 += (int)((w >> 8) & 255u) * kj;
+                a2 += (int)((w >> 16) & 255u) * kj;
+                a3 += (int)(w >> 24) * kj;
+            }
+            // four byte stores on purpose: packing clip8(a0) | clip8(a1) << 8 | ... into one dword is pattern-matched by hipcc
+            // (ROCm 7.2) to v_ashr_pk_u8_i32 and produced wrong upper bytes on gfx950
+            vrow[4 * d] = (uint8_t)clip8(a0);
+            vrow[4 * d + 1] = (uint8_t)clip8(a1);
+            vrow[4 * d + 2] = (uint8_t)clip8(a2);
+            vrow[4 * d + 3] = (uint8_t)clip8(a3);
+        } else {
+            ((uint32_t*)vrow)[d] = *(const uint32_t*)(base + (size_t)y * in_row_stride + 4 * d);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * S; i += blockDim.x) {
+        const int c = i / S, x = i - c * S;
+        out[(((size_t)t * 3 + c) * S + y) * S + x] = (TO)lut[vrow[x * 3 + c]];
+    }
+}
+
+// byte-wise fallback for rows that are not 4-byte aligned: one block per (output row y, channel c, frame t), threads along x
+template <typename TO, bool VERT>
+__global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* __restrict__ in, long in_frame_stride, int in_row_stride, int S,
+                                                         const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                         const float* __restrict__ lut, TO* __restrict__ out) {
+    const int y = blockIdx.x, c = blockIdx.y, t = blockIdx.z;
+    const uint8_t* base = in + (size_t)t * in_frame_stride + c;
+    TO* o = out + (((size_t)t * 3 + c) * S + y) * S;
+    int y0 = y, n = 1;
+    const int* k = nullptr;
+    if (VERT) { y0 = bounds[2 * y]; n = bounds[2 * y + 1]; k = kk + (size_t)y * ksize; }
+    for (int x = threadIdx.x; x < S; x += blockDim.x) {
+        int v;
+        if (VERT) {
+            int acc = 1 << (PP_BITS - 1);
+            for (int j = 0; j < n; ++j) acc += (int)base[(size_t)(y0 + j) * in_row_stride + x * 3] * k[j];
+            v = clip8(acc);
+        } else {
+            v = base[(size_t)y * in_row_stride + x * 3];
+        }
+        o[x] = (TO)lut[v];
+    }
+}
+
+template <typename TO>
+static void launch_v(bool vert, const uint8_t* in, long fs, int rs, int S, const ResampleTable& tv, const float* lut, void* out, int T,
+                     hipStream_t s) {
+    const bool dwords = ((size_t)in % 4 == 0) && fs % 4 == 0 && rs % 4 == 0 && rs >= ((S * 3 + 3) & ~3);
+    if (dwords) {
+        const int threads = min(512, ((S * 3 + 3) / 4 + 63) / 64 * 64);
+        const size_t lds = ((size_t)S * 3 + 3 + 15) & ~(size_t)15;
+        dim3 grid(S, T);
+        if (vert) hipLaunchKernelGGL((resample_v4_kernel<TO, true>), grid, dim3(threads), lds, s, in, fs, rs, S, tv.bounds, tv.kk, tv.ksize, lut, (TO*)out);
+        else hipLaunchKernelGGL((resample_v4_kernel<TO, false>), grid, dim3(threads), lds, s, in, fs, rs, S, nullptr, nullptr, 0, lut, (TO*)out);
+        return;
+    }
+    dim3 grid(S, 3, T);
+    if (vert) hipLaunchKernelGGL((resample_v_kernel<TO, true>), grid, dim3(256), 0, s, in, fs, rs, S, tv.bounds, tv.kk, tv.ksize, lut, (TO*)out);
+    else hipLaunchKernelGGL((resample_v_kernel<TO, false>), grid, dim3(256), 0, s, in, fs, rs, S, nullptr, nullptr, 0, lut, (TO*)out);
+}
+
+}  // namespace vitg
+
+using namespace vitg;
+
+static long tmp_bytes_for(int T, int H, int W, int S) {
+    return W == S ? 0 : (long)T * H * S * 3;          // the horizontally resampled uint8 frames
+}
+
+extern "C" int vitg_preprocess_tmp_bytes(int T, int H, int W, int S, long* bytes) {
+    if (!bytes || T < 0 || H <= 0 || W <= 0 || S <= 0) return VITG_ERR_ARG;
+    *bytes = tmp_bytes_for(T, H, W, S);
+    return 0;
+}
+
+extern "C" int vitg_preprocess_u8(const void* frames, int T, int H, int W, long frame_stride, int row_stride, void* out, int S,
+                                  int out_dtype, void* tmp, long tmp_bytes, void* stream) {
+    if (T == 0) return 0;
+    if (T < 0 || H <= 0 || W <= 0 || S <= 0 || !frames || !out) return VITG_ERR_ARG;
+    if (row_stride < W * 3 || frame_stride < (long)row_stride * H) return VITG_ERR_SHAPE;
+    if (out_dtype != DT_BF16 && out_dtype != DT_F16 && out_dtype != DT_F32) return VITG_ERR_DTYPE;
+    if (T > 65535) return VITG_ERR_SHAPE;
+    const long need = tmp_bytes_for(T, H, W, S);
+    if (need > 0 && (!tmp || tmp_bytes < need)) return VITG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const float* lut = get_lut();
+    if (!lut) return VITG_ERR_LAUNCH;
+    ResampleTable th, tv;
+    const uint8_t* vin = (const uint8_t*)frames;
+    long v_fs = frame_stride;
+    int v_rs = row_stride;
+    if (W != S) {
+        if (int rc = get_table(W, S, th)) return rc;
+        const int row_lds = (int)(((size_t)W * 3 + 15 + 15) / 16 * 16 + 16);
+        const size_t lds = 2 * (size_t)row_lds + (size_t)S * th.ksize * sizeof(int);
+        if (lds > 160 * 1024) return VITG_ERR_SHAPE;      // two input rows + the weight table must fit in LDS
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)resample_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int threads = min(512, (S + 63) / 64 * 64);
+        hipLaunchKernelGGL(resample_h_kernel, dim3((H + PP_ROWS - 1) / PP_ROWS, T), dim3(threads), lds, s, (const uint8_t*)frames, frame_stride,
+                           row_stride, W, S, th.bounds, th.kk, th.ksize, (uint8_t*)tmp, H, row_lds);
+        vin = (const uint8_t*)tmp;
+        v_fs = (long)H * S * 3;
+        v_rs = S * 3;
+    }
+    const bool vert = H != S;
+    if (vert) { if (int rc = get_table(H, S, tv)) return rc; }
+    if (out_dtype == DT_F32) launch_v<float>(vert, vin, v_fs, v_rs, S, tv, lut, out, T, s);
+    else if (out_dtype == DT_F16) launch_v<f16_t>(vert, vin, v_fs, v_rs, S, tv, lut, out, T, s);
+    else launch_v<bf16_t>(vert, vin, v_fs, v_rs, S, tv, lut, out, T, s);
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}

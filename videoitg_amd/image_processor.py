@@ -51,11 +51,23 @@ class SiglipImageProcessor:
         s = self.size["height"]
         if img.size != (s, s):
             img = img.resize((s, s), resample=self.resample)
-        a = np.asarray(img, dtype=np.float32) * np.float32(self.rescale_factor)
+        # transformers image_transforms.rescale: float64 product, THEN the cast to float32 (a float32 product differs in the last
+        # bit for some byte values); normalize: (x - mean) / std in float32
+        a = (np.asarray(img).astype(np.float64) * self.rescale_factor).astype(np.float32)
         a = (a - np.asarray(self.image_mean, np.float32)) / np.asarray(self.image_std, np.float32)
         return np.ascontiguousarray(a.transpose(2, 0, 1))
 
     def preprocess(self, images: Union[np.ndarray, Sequence, Image.Image], return_tensors=None, **_):
+        # GPU front-end: decoded frames already in HBM as uint8 [T,H,W,3] are resized / normalised by the HIP
+        # kernel (bit-identical to the host path below) and stay on the device
+        if isinstance(images, torch.Tensor) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4:
+            if return_tensors != "pt":
+                raise ValueError("device frames are returned as torch tensors: pass return_tensors='pt'")
+            if (self.image_mean, self.image_std) != ([0.5, 0.5, 0.5], [0.5, 0.5, 0.5]) or self.rescale_factor != 1 / 255 \
+                    or self.resample != Image.BICUBIC:
+                raise ValueError("the device path implements the SigLIP preprocessor_config (bicubic, 1/255, mean = std = 0.5)")
+            from . import ops
+            return BatchFeature(pixel_values=ops.preprocess_u8(images, self.size["height"], torch.float32))
         if isinstance(images, Image.Image):
             images = [images]
         elif isinstance(images, (np.ndarray, torch.Tensor)) and images.ndim == 3:

@@ -163,3 +163,22 @@ def rank(logits: torch.Tensor):
     order = torch.empty(n, dtype=torch.int32, device=logits.device)
     _lib.call("vitg_rank", _ptr(logits), n, _ptr(scores), _ptr(order), _stream())
     return scores, order
+
+
+def preprocess_u8(frames: torch.Tensor, size: int, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """uint8 [T,H,W,3] device frames -> normalised [T,3,size,size] (Pillow-exact bicubic resize + SigLIP rescale/normalise)"""
+    _req(frames, torch.uint8)
+    if frames.dim() != 4 or frames.shape[-1] != 3:
+        raise _lib.VitgError(f"expected uint8 [T,H,W,3], got {tuple(frames.shape)}")
+    T, H, W, _ = frames.shape
+    if T > 0 and (frames.stride(3) != 1 or frames.stride(2) != 3):
+        frames = frames.contiguous()
+    out = torch.empty((T, 3, size, size), dtype=out_dtype, device=frames.device)
+    if T == 0:
+        return out
+    need = C.c_long(0)
+    _lib.call("vitg_preprocess_tmp_bytes", T, H, W, size, C.byref(need))
+    tmp = torch.empty(need.value, dtype=torch.uint8, device=frames.device) if need.value else None
+    _lib.call("vitg_preprocess_u8", _ptr(frames), T, H, W, frames.stride(0), frames.stride(1), _ptr(out), size, dt_code(out_dtype),
+              _ptr(tmp), need.value, _stream())
+    return out

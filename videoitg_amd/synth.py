@@ -125,3 +125,16 @@ def synth_prompt_ids(length: int, vocab_size: int, seed: int = 4321) -> torch.Te
     g = _gen(seed, f"prompt{length}")
     hi = min(vocab_size, 151_643)
     return torch.randint(0, hi, (length,), generator=g, dtype=torch.long)
+
+
+def synth_video_frames(seed: int, T: int, H: int, W: int):
+    """uint8 [T,H,W,3] decoded-frame stand-in (numpy): noise blended with a smooth gradient, plus a full-contrast band so
+    that the bicubic resize both interpolates mid-range values and overshoots into the [0, 255] clip."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    noise = rng.integers(0, 256, (T, H, W, 3), dtype=np.uint8).astype(np.int32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    grad = ((xx * 255) // max(W - 1, 1) + (yy * 255) // max(H - 1, 1)) // 2
+    out = (noise + 3 * grad[None, :, :, None]) // 4
+    out[:, : H // 4] = noise[:, : H // 4]
+    return out.astype(np.uint8)
