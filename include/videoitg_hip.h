@@ -116,6 +116,11 @@ int vitg_pool_score(const float* h, int ldh, int frames, int tokens_per_frame, i
  * (whose tie order is unspecified; this one is deterministic). */
 int vitg_rank(const float* logits, int n, float* scores, int* order, void* stream);
 
+/* Grounding loss, forward value only: out2[0] = BCE-with-logits(logits, labels) with
+ * pos_weight = min(5, sqrt(#neg / max(1, #pos))) = out2[1], mean over n (fp32).  Replaces the loss branch at
+ * /root/reference/eagle/model/language_model/grounding_qwen2.py:159-169 (nn.BCEWithLogitsLoss). */
+int vitg_bce_loss(const float* logits, const float* labels, int n, float* out2, void* stream);
+
 /* Frame preprocessing in front of the tower.  Replaces the CPU call
  *   image_processor.preprocess(frames, return_tensors="pt")["pixel_values"]
  * at /root/reference/infer.py:55 and lmms_eval/models/videoitg.py:282,286 (third-party SiglipImageProcessor created at

@@ -327,3 +327,15 @@ def forward(cfg, sd: SD, vsd: SD, input_ids: torch.Tensor, attention_mask: Optio
         return logits, dict(vit=feats, visual=visual, inputs_embeds=x, token_types=tts, mask=mask,
                             layers=layers, final=h)
     return logits
+
+
+def grounding_loss(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """BCE-with-logits with the capped positive weight of /root/reference/eagle/model/language_model/grounding_qwen2.py:159-169:
+    pos_weight = min(5, sqrt(#neg / max(1, #pos))); torch's formula (1-y) x + (1 + (pw-1) y) softplus(-x), mean, fp32."""
+    x = logits.float().view(-1)
+    y = labels.float().view(-1)
+    pos = y.sum()
+    neg = y.numel() - pos
+    pw = torch.minimum(torch.tensor(5.0), torch.sqrt(neg / torch.clamp(pos, min=1.0)))
+    sp = torch.log1p(torch.exp(-x.abs())) + torch.clamp(-x, min=0.0)
+    return ((1.0 - y) * x + (1.0 + (pw - 1.0) * y) * sp).mean()

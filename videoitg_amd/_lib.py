@@ -35,6 +35,7 @@ SIGNATURES = {
     "vitg_embed_gather": [_p, _i, _p, _i, _p, _i, _i, _p],
     "vitg_pool_score": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
     "vitg_rank": [_p, _i, _p, _p, _p],
+    "vitg_bce_loss": [_p, _p, _i, _p, _p],
     "vitg_preprocess_tmp_bytes": [_i, _i, _i, _i, C.POINTER(C.c_long)],
     "vitg_preprocess_u8": [_p, _i, _i, _i, _l, _i, _p, _i, _i, _p, _l, _p],
 }

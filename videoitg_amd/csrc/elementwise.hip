@@ -403,6 +403,48 @@ extern "C" int vitg_pool_score(const float* h, int ldh, int frames, int tokens_p
     return CHECK_LAUNCH();
 }
 
+
+// ---- grounding loss (forward value only): BCE-with-logits with the reference's capped positive weight --------------------
+// pos_weight = min(5, sqrt(neg / max(1, pos))), loss = mean_i [ (1 - y_i) x_i + (1 + (pw - 1) y_i) softplus(-x_i) ]
+// (torch's binary_cross_entropy_with_logits formula; /root/reference/eagle/model/language_model/grounding_qwen2.py:159-169).
+namespace vitg {
+__global__ __launch_bounds__(1024) void bce_loss_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ out) {
+    __shared__ float red[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float pos = 0.f;
+    for (int i = tid; i < n; i += blockDim.x) pos += y[i];
+    pos = wave_sum(pos);
+    if (lane == 0) red[wave] = pos;
+    __syncthreads();
+    pos = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) pos += red[w];
+    __syncthreads();
+    const float neg = (float)n - pos;
+    const float pw = fminf(5.0f, sqrtf(neg / fmaxf(1.0f, pos)));
+    float acc = 0.f;
+    for (int i = tid; i < n; i += blockDim.x) {
+        const float xi = x[i], yi = y[i];
+        const float sp = log1pf(expf(-fabsf(xi))) + fmaxf(-xi, 0.0f);       // softplus(-x), stable
+        acc += (1.0f - yi) * xi + (1.0f + (pw - 1.0f) * yi) * sp;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        out[0] = t / (float)n;
+        out[1] = pw;
+    }
+}
+}  // namespace vitg
+
+extern "C" int vitg_bce_loss(const float* logits, const float* labels, int n, float* out2, void* stream) {
+    if (n <= 0 || !logits || !labels || !out2) return VITG_ERR_ARG;
+    hipLaunchKernelGGL(vitg::bce_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, labels, n, out2);
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}
+
 extern "C" int vitg_rank(const float* logits, int n, float* scores, int* order, void* stream) {
     if (n <= 0) return 0;
     if (n > 8192) return VITG_ERR_SHAPE;

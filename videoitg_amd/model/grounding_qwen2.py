@@ -172,9 +172,17 @@ class EagleQwenG(nn.Module):
                 **_ignored) -> SelectorOutput:
         if images is None or input_ids is None:
             raise ValueError("the selector forward needs input_ids and images (grounding_qwen2.py:107-108)")
-        if grounding_labels is not None or dpo_forward or inputs_embeds is not None:
-            raise NotImplementedError("training / dpo / inputs_embeds branches are outside the inference hot path")
+        if dpo_forward or inputs_embeds is not None:
+            raise NotImplementedError("dpo / inputs_embeds branches are outside the inference hot path")
         eng = self.engine()
         with torch.cuda.device(self._device):
             logits = eng.forward(input_ids, attention_mask, list(images))
-        return SelectorOutput(logits=logits)
+            if grounding_labels is None:
+                return SelectorOutput(logits=logits)
+            # labelled evaluation (grounding_qwen2.py:159-181): the loss VALUE (no backward here), and - as in the reference -
+            # `logits` becomes the flat fp32 concatenation over the batch instead of the per-video list
+            from .. import ops
+            flat = torch.cat([l.float().view(-1) for l in logits])
+            lab = torch.cat([torch.as_tensor(g).view(-1) for g in grounding_labels]).to(flat.device, torch.float32)
+            loss, _ = ops.bce_loss(flat, lab)
+        return SelectorOutput(logits=flat, loss=loss)

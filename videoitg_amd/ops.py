@@ -182,3 +182,14 @@ def preprocess_u8(frames: torch.Tensor, size: int, out_dtype: torch.dtype = torc
     _lib.call("vitg_preprocess_u8", _ptr(frames), T, H, W, frames.stride(0), frames.stride(1), _ptr(out), size, dt_code(out_dtype),
               _ptr(tmp), need.value, _stream())
     return out
+
+
+def bce_loss(logits: torch.Tensor, labels: torch.Tensor):
+    """-> (loss scalar tensor fp32, pos_weight float tensor): the reference's grounding loss (grounding_qwen2.py:159-169)"""
+    _req(logits, torch.float32)
+    _req(labels, torch.float32)
+    if logits.numel() != labels.numel() or logits.numel() == 0:
+        raise _lib.VitgError("logits and labels must have the same, non-zero, number of elements")
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    _lib.call("vitg_bce_loss", _ptr(logits.contiguous()), _ptr(labels.contiguous()), logits.numel(), _ptr(out), _stream())
+    return out[0], out[1]
