@@ -193,6 +193,23 @@ def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world,frames", [(2, 9), (3, 8)])
+def test_context_parallel_multi_rank_on_one_gpu(world, frames):
+    """WORLD > 1 with the real kernels: `world` processes share cuda:0 and exchange over gloo (RCCL refuses two ranks on one
+    device).  Frame shards are ragged (9 frames / 2 ranks, prompt tokens on the first and last rank), so global positions, the
+    padded K|V all-gather + gather-rows compaction and the logits gather are all exercised.  Same arithmetic per token as the
+    single-rank forward -> identical logits."""
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)               # spawn hands sys.path to the children, which import the module by name
+    import cp_two_ranks_one_gpu as mod
+    got, want = mod.run(world, frames, port=29540 + world)
+    assert got.shape == want.shape == (frames,)
+    assert (got - want).abs().max().item() <= 1e-5
+
+
 @pytest.mark.parametrize("vit_layers,llm_layers", [(3, 2), (9, 8)])
 def test_full_width_reduced_depth_parity(vit_layers, llm_layers):
     """Real layer widths (SigLIP 1152/4304/16x72, Qwen2 3584/18944, 28 q / 4 kv heads x128, pos-emb interpolation to a

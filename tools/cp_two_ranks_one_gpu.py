@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Context-parallel forward with WORLD > 1 on a single GPU box: `world` processes share cuda:0 and talk over gloo (RCCL refuses
+two ranks on one device), so the real kernels run with the multi-rank plan (frame shards, global positions, ragged K|V
+all-gather + compaction, logits gather) and the result is compared with the single-rank forward.
+    python tools/cp_two_ranks_one_gpu.py [world] [frames]"""
+import os
+import sys
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build():
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    cfg = tiny_config(vision_token_num=72)
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    return cfg, eng
+
+
+def worker(rank, world, frames, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from videoitg_amd import synth
+        from videoitg_amd.parallel import ContextParallel
+        cfg, eng = build()
+        pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
+        ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
+        out = ContextParallel(rank, world).forward(eng, ids, pix)
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put(out.float().cpu())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def run(world=2, frames=9, port=29533):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, frames, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, p.exitcode
+    from videoitg_amd import synth
+    cfg, eng = build()
+    pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
+    ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
+    want = eng.forward(ids, None, [pix])[0].view(-1).float().cpu()
+    return got, want
+
+
+if __name__ == "__main__":
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+    got, want = run(world, frames)
+    d = (got - want).abs().max().item()
+    print(f"world={world} frames={frames}: max|dlogit| vs single rank = {d:.3e}", flush=True)
+    assert d < 5e-3, d
