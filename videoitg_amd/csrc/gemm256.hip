@@ -28,7 +28,7 @@ constexpr int G2_BM = 256, G2_THREADS = 512;
 //   <BN=128, WM=4, STAGES=3>: wave tile  64x64,  72 KiB LDS, 2 blocks/CU - one block's prologue/epilogue overlaps the
 //                                                                          other's main loop (small K, heavy epilogues)
 template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0>
-__global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g) {
+__global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g) {
     typedef typename T16<T>::vec8 vec8;
     constexpr int WN = 8 / WM;
     constexpr int MT = G2_BM / WM / 32;                  // 32-row activation tiles per wave
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
                 if (more && pp < 3) {
 #pragma unroll
                     for (int j = 0; j < LPT; ++j)
-                        if (j / 3 == pp) issue_one(kt + 1, j);       // pieces 0-2, 3-5, 6-7 at p = 0, 1, 2
+                        if (j / ((LPT + 2) / 3) == pp) issue_one(kt + 1, j);       // LPT = 8: pieces 0-2, 3-5, 6-7 at p = 0, 1, 2
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (pp == KS - 1 && more && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -338,8 +338,16 @@ __global__ __launch_bounds__(G2_THREADS, (BN == 256 ? 2 : 4)) void gemm256_kerne
         // 16-bit outputs: transposed through wave-private LDS into full-row 16-B stores (gemm_common.h)
         __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring before it is reused
         constexpr int STAGE_BYTES = MT * 32 * (MODE == MODE_SWIGLU ? 1 : NT) * 64;
-        static_assert(8 * STAGE_BYTES <= STAGES * STAGE, "epilogue staging must fit in the ring");
-        epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+        if constexpr (8 * STAGE_BYTES <= STAGES * STAGE) {
+            epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+        } else {
+            // 256x384 tile: the wave's 128x96 outputs are staged in two 64-row halves (the same wave writes and reads its
+            // private region, in order, so the second half may reuse it)
+            static_assert(MT % 2 == 0 && 4 * STAGE_BYTES <= STAGES * STAGE, "epilogue staging must fit in the ring");
+            epilogue_staged<T, MODE, MT, NT, 0, MT / 2>(g, acc, smem + wave * (STAGE_BYTES / 2), m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+            epilogue_staged<T, MODE, MT, NT, MT / 2, MT / 2>(g, acc, smem + wave * (STAGE_BYTES / 2), m0 + wr * (MT * 32) + (MT / 2) * 32,
+                                                               n0 + wc * (NT * 32), lane);
+        }
     }
 }
 
@@ -592,8 +600,18 @@ bool gemm256_applicable(const GemmArgs& g, int mode) {
 template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     int cfg = tuning().gemm_cfg;
-    if (!cfg) cfg = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) >= 160 ? 6 : 2;     // see vitg_gemm (gemm.hip)                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
+    if (!cfg) {
+        cfg = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) >= 160 ? 6 : 2;
+        // 256x384 tile (wave tile 128x96: 0.58 KiB of fragment reads per MFMA instead of 0.75, 154 instead of 128 flop per operand
+        // byte) for the fp32-residual GEMMs whose N it divides, or whose K is long enough to amortise a ragged last column tile.
+        // Same-call A/B (profiles/r01_gemm_shapes.md section 5): fc2 +17 %, down +10 %, out-proj +3 %; 16-bit-output shapes lose
+        // 1-10 % (two-pass staged epilogue, ragged N), so they stay on the 256x256 tile.
+        if (cfg == 6 && !(tuning().gemm_flags & 256) && MODE == MODE_F32 && g.N >= 384 &&      // flags bit8: A/B switch (off) (g.N % 384 == 0 || g.K >= 8192) &&
+            (long)ceil_div(g.M, 256) * ceil_div(g.N, 384) >= 160)
+            cfg = 9;
+    }     // see vitg_gemm (gemm.hip)                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
+    if (cfg == 9 && MODE != MODE_SWIGLU && g.N >= 384) return launch256<T, MODE, 384, 2, 2, 64, false, 1>(g, s);   // 256x384x64 phased (wave tile 128x96)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);

@@ -87,6 +87,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
     const int frow = lane & 31, fh = lane >> 5;
     if constexpr (MODE == MODE_F32) {
         constexpr int CH = NT * 8;                        // 16-B chunks (4 floats) per row
+        constexpr int SWZ = (CH & -CH) - 1;               // XOR mask: largest power of two dividing CH, minus 1 (keeps chunks inside the row for NT = 3)
         constexpr int RB = NT * 128;                      // row bytes
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt) {
@@ -107,14 +108,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
                     }
                     const int c = nt * 8 + q4 * 2 + fh;
-                    *(f32x4*)(stage + frow * RB + ((c ^ (frow & (CH - 1))) << 4)) = v;
+                    *(f32x4*)(stage + frow * RB + ((c ^ (frow & SWZ)) << 4)) = v;
                 }
             // same wave reads back what it wrote: LDS ops of one wave complete in order, no barrier needed
 #pragma unroll
             for (int i = 0; i < 32 * CH / 64; ++i) {
                 const int idx = i * 64 + lane;
                 const int row = idx / CH, c = idx % CH;
-                f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4));
+                f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ (row & SWZ)) << 4));
                 const int m = m_base + (mt - MT0) * 32 + row, n = n_base + c * 4;
                 if (m < g.M && n < g.N) {
                     if (g.res) {
@@ -128,6 +129,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
     } else {
         constexpr int NTO = MODE == MODE_SWIGLU ? 1 : NT;  // output 32-column tiles per wave
         constexpr int CH = NTO * 4;                        // 16-B chunks (8 halfs) per row
+        constexpr int SWZ = (CH & -CH) - 1;
         constexpr int RB = NTO * 64;
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt)
@@ -156,7 +158,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
                     const int row = (mt - MT0) * 32 + frow, c = nt * 4 + q4;
-                    *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4) + fh * 8) = o;
+                    *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ (row & SWZ)) << 4) + fh * 8) = o;
                 }
         const int n_out = MODE == MODE_SWIGLU ? n_base / 2 : n_base;
         const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
@@ -164,7 +166,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
         for (int i = 0; i < MTN * 32 * CH / 64; ++i) {
             const int idx = i * 64 + lane;
             const int row = idx / CH, c = idx % CH;
-            const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ (row & (CH - 1))) << 4));
+            const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ (row & SWZ)) << 4));
             const int m = m_base + row, n = n_out + c * 8;
             if (m < g.M) {
                 T* dst = (T*)g.out + (size_t)m * g.ldo + n;
