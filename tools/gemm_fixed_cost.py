@@ -1,6 +1,9 @@
 import os, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops
+for _a in sys.argv[1:]:
+    if '=' in _a:
+        ops.set_option(_a.split('=')[0], int(_a.split('=')[1]))
 dt = torch.float16
 for (M,N,K,mode) in [(524288,3456,64,0),(524288,3456,128,0),(524288,3456,256,0),(524288,3456,1152,0),(524288,1152,64,1),(524288,1152,1152,1),(524288,1152,64,0)]:
     a = (torch.rand((M, K), device="cuda") * 2 - 1).to(dt)
