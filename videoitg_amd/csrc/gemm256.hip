@@ -343,9 +343,10 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
         } else {
             // 256x384 tile: the wave's 128x96 outputs are staged in two 64-row halves (the same wave writes and reads its
             // private region, in order, so the second half may reuse it)
-            static_assert(MT % 2 == 0 && 4 * STAGE_BYTES <= STAGES * STAGE, "epilogue staging must fit in the ring");
-            epilogue_staged<T, MODE, MT, NT, 0, MT / 2>(g, acc, smem + wave * (STAGE_BYTES / 2), m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
-            epilogue_staged<T, MODE, MT, NT, MT / 2, MT / 2>(g, acc, smem + wave * (STAGE_BYTES / 2), m0 + wr * (MT * 32) + (MT / 2) * 32,
+            constexpr int HALF = (MT / 2) * 32 * (NT * 64 + ((NT & (NT - 1)) ? 16 : 0));     // padded rows when NT is not a power of two
+            static_assert(MT % 2 == 0 && 8 * HALF <= STAGES * STAGE, "epilogue staging must fit in the ring");
+            epilogue_staged<T, MODE, MT, NT, 0, MT / 2>(g, acc, smem + wave * HALF, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+            epilogue_staged<T, MODE, MT, NT, MT / 2, MT / 2>(g, acc, smem + wave * HALF, m0 + wr * (MT * 32) + (MT / 2) * 32,
                                                                n0 + wc * (NT * 32), lane);
         }
     }

@@ -77,7 +77,8 @@ __device__ __forceinline__ void epilogue_swiglu_quad(const GemmArgs& g, int m, i
 // lane, consecutive lanes on consecutive addresses, full 128-B lines.  Bias / activation / SwiGLU are applied in
 // registers before staging; the fp32 residual is added on the coalesced side.
 //   acc[nt][mt][r]: m = m_base + mt*32 + (lane&31), n = n_base + nt*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
-// `stage` = this wave's private LDS (>= MT*32*NT*64 bytes for 16-bit output, >= 32*NT*128 bytes for fp32 output).
+// `stage` = this wave's private LDS (>= MTN*32*(NT*64 [+16]) bytes for 16-bit output - the +16 applies when NT is not a power of
+// two - and >= 32*NT*128 bytes for fp32 output).
 // Requires out/res leading dimensions and n_base to keep 16-B alignment (checked by the host code).
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, int MODE, int MT, int NT, int MT0 = 0, int MTN = MT>
@@ -87,8 +88,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
     const int frow = lane & 31, fh = lane >> 5;
     if constexpr (MODE == MODE_F32) {
         constexpr int CH = NT * 8;                        // 16-B chunks (4 floats) per row
-        constexpr int SWZ = (CH & -CH) - 1;               // XOR mask: largest power of two dividing CH, minus 1 (keeps chunks inside the row for NT = 3)
         constexpr int RB = NT * 128;                      // row bytes
+        constexpr int SWZ = (CH & -CH) - 1;               // XOR mask: largest power of two dividing CH, minus 1 (NT = 3: 24 chunks -> 7).
+                                                          // (Padding the row instead, as the 16-bit path does, costs registers here:
+                                                          // the 256x384 fp32 kernel went from 19 to 256 spills.)
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt) {
 #pragma unroll
@@ -129,8 +132,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
     } else {
         constexpr int NTO = MODE == MODE_SWIGLU ? 1 : NT;  // output 32-column tiles per wave
         constexpr int CH = NTO * 4;                        // 16-B chunks (8 halfs) per row
-        constexpr int SWZ = (CH & -CH) - 1;
-        constexpr int RB = NTO * 64;
+        constexpr bool POW2 = (CH & (CH - 1)) == 0;
+        constexpr int RB = NTO * 64 + (POW2 ? 0 : 16);
+        constexpr int SWZ = POW2 ? CH - 1 : 0;
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt)
 #pragma unroll
