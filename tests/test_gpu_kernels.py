@@ -35,13 +35,16 @@ def gemm_cfg(request, ops):
     ops.set_option("gemm_cfg", 0)
 
 
-@pytest.fixture(params=[(0, 0, 0, 0), (4, 0, 2, 2), (8, 0, 2, 2), (4, 1, 2, 2), (4, 0, 1, 2), (8, 0, 1, 2), (4, 0, 0, 1), (8, 0, 0, 1)],
-                ids=["auto", "waves4_reg", "waves8_reg", "waves4_pipelined", "waves4_dma", "waves8_dma", "waves4_swpipe", "waves8_swpipe"])
+@pytest.fixture(params=[(0, 0, 0, 0, 0), (4, 0, 2, 2, 2), (8, 0, 2, 2, 2), (4, 1, 2, 2, 2), (4, 0, 1, 2, 2), (8, 0, 1, 2, 2), (4, 0, 0, 1, 2), (8, 0, 0, 1, 2),
+                        (0, 0, 0, 2, 1)],
+                ids=["auto", "waves4_reg", "waves8_reg", "waves4_pipelined", "waves4_dma", "waves8_dma", "waves4_swpipe", "waves8_swpipe",
+                     "half_tile_out_of_phase"])
 def attn_waves(request, ops):
-    for key, val in zip(("attn_waves", "attn_pipe", "attn_dma", "attn_sp"), request.param):
+    keys = ("attn_waves", "attn_pipe", "attn_dma", "attn_sp", "attn_ab")
+    for key, val in zip(keys, request.param):
         ops.set_option(key, val)
     yield request.param
-    for key in ("attn_waves", "attn_pipe", "attn_dma", "attn_sp"):
+    for key in keys:
         ops.set_option(key, 0)
 
 

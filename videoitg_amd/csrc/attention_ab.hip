@@ -1,0 +1,286 @@
+// Non-causal flash attention forward for gfx950 with the two waves of every SIMD running HALF A TILE OUT OF PHASE (same math,
+// layouts and transposed formulation as attention.hip; read that file's header first).
+//
+// In the per-tile kernel all eight waves of a block run  QK^T (MFMA) -> softmax (VALU) -> PV (MFMA)  between the same two tile
+// barriers, so the two waves that share a SIMD want the matrix pipe at the same time and the VALU at the same time.  Here waves
+// 0..NW/2-1 (group A) keep that order, while waves NW/2..NW-1 (group B: wave w+NW/2 sits on the SIMD of wave w) run, inside the
+// barrier interval of tile t,
+//        softmax(t-1) (VALU)  ->  PV(t-1) (MFMA)  ->  QK^T(t) (MFMA)
+// i.e. they carry the scores of a tile across the barrier and finish it one interval later:
+//        A:  MFMA | VALU | MFMA            B:  VALU | MFMA | MFMA
+// the first two slots are complementary on every SIMD.  No extra synchronisation: still one barrier per tile.
+// Cost: V(t-1) must outlive interval t, so V is a ring of THREE tiles (K stays double-buffered): 2 x 11 + 3 x 12 KiB = 58.5 KiB
+// per block at hd 72, two blocks per CU as before; group B holds its 32 score registers across the barrier, which does not
+// raise the peak (the softmax of either group is the widest point).
+#include "attn_common.h"
+#include "../../include/videoitg_hip.h"
+#include <type_traits>
+
+namespace vitg {
+
+constexpr float AB_LAZY_RESCALE_LOG2 = 8.0f;      // see attention_sp.hip: running max only moves on a > 2^8 jump
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
+    typedef typename T16<T>::vec8 vec8;
+    typedef AttnCfg<D> C;
+    constexpr int KS = C::DK / 16;           // QK^T k-steps per 32-key half
+    constexpr int DT = C::DV / 32;           // PV d-tiles
+    constexpr int KT_BYTES = ATT_BK * C::LDK * 2, VT_BYTES = ATT_BK * C::LDV * 2;
+    constexpr int V_BASE = 2 * KT_BYTES;     // LDS: [K0][K1][V0][V1][V2]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 31, h = lane >> 5;
+    const int L = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int qb = L % a.nqb;
+    const int hg = (L / a.nqb) % a.group;
+    const int kvh = (L / (a.nqb * a.group)) % a.kv_heads;
+    const int b = L / (a.nqb * a.group * a.kv_heads);
+    const int head = kvh * a.group + hg;
+    const int q0 = qb * (NW * 32) + wave * 32;
+
+    const T* Q = (const T*)a.q + b * a.q_bs + (long)head * a.q_hs;
+    const T* K = (const T*)a.k + b * a.k_bs + (long)kvh * a.k_hs;
+    const T* V = (const T*)a.v + b * a.v_bs + (long)kvh * a.v_hs;
+
+    // ---- Q fragments (B operand): lane (q = ql, h) holds d = 16 ks + 8 h .. +7 ------------------------------------------
+    vec8 qf[KS];
+    {
+        const T* qp = Q + (long)min(q0 + ql, a.S - 1) * a.q_rs;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + h * 8;
+            vec8 t;
+            if (d0 < D) t = *(const vec8*)(qp + d0);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (T)0.f;
+            }
+            qf[ks] = t;
+        }
+    }
+
+    // ---- LDS-DMA staging: one global_load_lds_dwordx4 fills 1 KiB lane-linearly; the source address carries the layout ---
+    constexpr int K_CPR = C::LDK * 2 / 16, V_CPR = C::LDV * 2 / 16;       // 16-B slots per row = DMA instructions per tile
+    constexpr int K_PW = (K_CPR + NW - 1) / NW, V_PW = (V_CPR + NW - 1) / NW;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_src = [&](int ii, int cpr, int rs, bool is_k, int row_lim) -> unsigned {
+        const int j = ii * 64 + lane;
+        int row = j / cpr, c = j % cpr;
+        if (D == 128) c = is_k ? (c ^ (row & 15)) : (c ^ ((row & 3) << 2));
+        else c = min(c, C::CH - 1);          // pad slots re-read the row's last data chunk (finite filler)
+        row = min(row, row_lim);
+        return (unsigned)(row * rs + c * 8) * 2u;
+    };
+    unsigned dk_off[K_PW], dv_off[V_PW];
+#pragma unroll
+    for (int i = 0; i < K_PW; ++i) dk_off[i] = dma_src(wave_u + NW * i, K_CPR, a.k_rs, true, ATT_BK - 1);
+#pragma unroll
+    for (int i = 0; i < V_PW; ++i) dv_off[i] = dma_src(wave_u + NW * i, V_CPR, a.v_rs, false, ATT_BK - 1);
+    auto issue_k = [&](int kt, int buf) {
+        char* kb = smem + buf * KT_BYTES;
+        const char* Kt = (const char*)(K + (long)kt * ATT_BK * a.k_rs);
+        const bool tail = kt * ATT_BK + ATT_BK > a.Sk;          // wave-uniform: clamp rows past the last key
+#pragma unroll
+        for (int i = 0; i < K_PW; ++i) {
+            const int ii = wave_u + NW * i;
+            if (ii < K_CPR) {
+                const unsigned off = tail ? dma_src(ii, K_CPR, a.k_rs, true, a.Sk - 1 - kt * ATT_BK) : dk_off[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + off),
+                                                 (__attribute__((address_space(3))) void*)(kb + ii * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_v = [&](int kt, int buf) {
+        char* vb = smem + V_BASE + buf * VT_BYTES;
+        const char* Vt = (const char*)(V + (long)kt * ATT_BK * a.v_rs);
+        const bool tail = kt * ATT_BK + ATT_BK > a.Sk;
+#pragma unroll
+        for (int i = 0; i < V_PW; ++i) {
+            const int ii = wave_u + NW * i;
+            if (ii < V_CPR) {
+                const unsigned off = tail ? dma_src(ii, V_CPR, a.v_rs, false, a.Sk - 1 - kt * ATT_BK) : dv_off[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + off),
+                                                 (__attribute__((address_space(3))) void*)(vb + ii * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // lane-dependent LDS read bases; inside the loop every fragment address is one of these + an immediate
+    const char* kbase[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kbase[ks] = smem + k_lds_off<D>(ql, ks * 2 + h);      // + t*32 rows: row & 15 unchanged
+    const int voff = (4 * h + ((lane & 15) >> 2)) * (C::LDV * 2) + ((((lane >> 4) & 1) * 16) + 4 * (lane & 3)) * 2;
+    const char* vbase[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vbase[dt] = smem + V_BASE + voff + (D == 128 ? ((dt ^ ((lane & 15) >> 2)) * 64) : dt * 64);
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const int nkt = ceil_div(a.Sk, ATT_BK);
+
+    // runtime-selected buffers (K ring of 2, V ring of 3): per-interval base pointers, fragment offsets stay immediates
+    auto qk_mfma = [&](int kbuf, f32x16 (&s)[2]) {
+        const int ko = kbuf * KT_BYTES;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const vec8 kf = *(const vec8*)(kbase[ks] + ko + t * 32 * (C::LDK * 2));
+                s[t] = ks == 0 ? T16<T>::mfma32(kf, qf[0], f32x16{}) : T16<T>::mfma32(kf, qf[ks], s[t]);
+            }
+    };
+    auto pv_mfma = [&](int vbuf, const vec8 (&p)[4]) {
+        const int vo = vbuf * VT_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* a0 = vbase[dt] + vo + ((kk >> 1) * 32 + (kk & 1) * 16) * (C::LDV * 2);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 8 * (C::LDV * 2)));
+                o[dt] = T16<T>::mfma32(bitcast<vec8>(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), p[kk], o[dt]);
+            }
+    };
+    auto mask_tail = [&](int t, f32x16 (&s)[2]) {          // last, partial tile: lane (q, h) s[tt][r] is key t*64 + tt*32 + 8*(r>>2) + 4*h + (r&3)
+        if (t * ATT_BK + ATT_BK > a.Sk) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * ATT_BK + tt * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= a.Sk) s[tt][r] = -INFINITY;
+        }
+    };
+    // online softmax of one tile (lane-local + one exchange with lane^32), lazy rescale; P -> p (16-bit, MFMA B operand layout)
+    auto softmax = [&](f32x16 (&s)[2], vec8 (&p)[4]) {
+        float mx = s[0][0];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
+        const u32x2 sw = __builtin_amdgcn_permlane32_swap(bitcast<uint32_t>(mx), bitcast<uint32_t>(mx), false, false);
+        mx = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1])) * a.scale_log2e;      // scale > 0
+        const float m_new = fmaxf(m_run, mx);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run + AB_LAZY_RESCALE_LOG2) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            m_run = m_new;
+        }
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 sc2 = {a.scale_log2e, a.scale_log2e};
+        const f32x2 nm2 = {-m_run, -m_run};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v = {s[tt][r], s[tt][r + 1]};
+                v = __builtin_elementwise_fma(v, sc2, nm2);
+                v = f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                psum2 += v;
+                p[tt * 2 + (r >> 3)][r & 7] = T16<T>::from_f32(v[0]);
+                p[tt * 2 + (r >> 3)][(r & 7) + 1] = T16<T>::from_f32(v[1]);
+            }
+        l_run += psum2[0] + psum2[1];
+    };
+
+    const bool group_b = wave_u >= NW / 2;
+    f32x16 s[2];
+    vec8 p[4];
+    issue_k(0, 0);
+    issue_v(0, 0);
+    __syncthreads();
+    // Two separate loops (not one loop with a role branch inside): with the branch inside, the register allocator keeps both
+    // roles' accumulator assignments alive across the back edge (247 VGPRs instead of 131).  Both loops execute the same
+    // number of barriers.  (sched_barriers: the phases must not be interleaved by the compiler - overlapping QK^T(t) with the
+    // softmax of the carried tile would need a second score buffer.)
+    auto issue_next = [&](int t, int vb_next) {            // K(t-1) and V(t-2) are dead for both groups since the last barrier
+        if (t + 1 < nkt) {
+            issue_k(t + 1, (t + 1) & 1);
+            issue_v(t + 1, vb_next);
+        }
+    };
+    if (!group_b) {
+        int vb_cur = 0;                                    // t % 3 without a division in the loop
+        for (int t = 0; t < nkt; ++t) {
+            const int vb_next = vb_cur == 2 ? 0 : vb_cur + 1;
+            issue_next(t, vb_next);
+            qk_mfma(t & 1, s);
+            mask_tail(t, s);
+            __builtin_amdgcn_sched_barrier(0);
+            softmax(s, p);
+            __builtin_amdgcn_sched_barrier(0);
+            pv_mfma(vb_cur, p);
+            vb_cur = vb_next;
+            __syncthreads();                               // drains vmcnt too: tile t+1 has landed
+        }
+    } else {
+        int vb_prev = 0, vb_cur = 0;
+        for (int t = 0; t < nkt; ++t) {
+            const int vb_next = vb_cur == 2 ? 0 : vb_cur + 1;
+            issue_next(t, vb_next);
+            if (t > 0) {
+                softmax(s, p);                             // scores of tile t-1, carried across the barrier
+                __builtin_amdgcn_sched_barrier(0);
+                pv_mfma(vb_prev, p);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            qk_mfma(t & 1, s);
+            mask_tail(t, s);
+            vb_prev = vb_cur;
+            vb_cur = vb_next;
+            __syncthreads();
+        }
+        softmax(s, p);                                     // finish the last tile (V(nkt-1) is still resident: nothing was issued after it)
+        __builtin_amdgcn_sched_barrier(0);
+        pv_mfma(vb_prev, p);
+    }
+
+    // ---- epilogue: lane (q, h) holds O[q][dt*32 + 8*(r>>2) + 4*h + (r&3)] -------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + ql;
+    if (qrow < a.S) {
+        T* op = (T*)a.o + b * a.o_bs + (long)head * a.o_hs + (long)qrow * a.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = dt * 32 + 8 * g4 + 4 * h;
+                if (d < D) {
+                    typename T16<T>::vec4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = T16<T>::from_f32(o[dt][g4 * 4 + e] * inv);
+                    *(typename T16<T>::vec4*)(op + d) = w;
+                }
+            }
+    }
+}
+
+template <typename T, int D, int NW>
+static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
+    a.nqb = ceil_div(a.S, NW * 32);
+    typedef AttnCfg<D> C;
+    const size_t lds = 2 * (ATT_BK * C::LDK * 2) + 3 * (ATT_BK * C::LDV * 2);
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+// called by vitg_attention (attention.hip); hd 72 only (hd 128 runs the software-pipelined kernel)
+int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, hipStream_t s) {
+    return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8>(a, batch, heads, s) : launch_ab<f16_t, 72, 8>(a, batch, heads, s);
+}
+
+}  // namespace vitg

@@ -23,7 +23,7 @@ namespace vitg {
 static int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; }
 Tuning& tuning() {
     static Tuning t = {env_int("VITG_GEMM_TILE"), env_int("VITG_GEMM_CFG"), env_int("VITG_GEMM_FLAGS"), env_int("VITG_GEMM_STAGGER"),
-                       env_int("VITG_ATTN_WAVES"), env_int("VITG_ATTN_PIPE"), env_int("VITG_ATTN_DMA"), env_int("VITG_ATTN_SP")};
+                       env_int("VITG_ATTN_WAVES"), env_int("VITG_ATTN_PIPE"), env_int("VITG_ATTN_DMA"), env_int("VITG_ATTN_AB"), env_int("VITG_ATTN_SP")};
     return t;
 }
 }  // namespace vitg
@@ -39,6 +39,7 @@ extern "C" int vitg_set_option(const char* key, int value) {
     else if (!strcmp(key, "attn_pipe")) t.attn_pipe = value;
     else if (!strcmp(key, "attn_dma")) t.attn_dma = value;
     else if (!strcmp(key, "attn_sp")) t.attn_sp = value;
+    else if (!strcmp(key, "attn_ab")) t.attn_ab = value;
     else return VITG_ERR_ARG;
     return 0;
 }
