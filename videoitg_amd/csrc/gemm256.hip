@@ -27,17 +27,17 @@ constexpr int G2_BM = 256, G2_THREADS = 512;
 //   <BN=256, WM=2, STAGES=4>: wave tile 128x64, 128 KiB LDS, 1 block/CU  - best steady state (large K)
 //   <BN=128, WM=4, STAGES=3>: wave tile  64x64,  72 KiB LDS, 2 blocks/CU - one block's prologue/epilogue overlaps the
 //                                                                          other's main loop (small K, heavy epilogues)
-template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0>
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM>
 __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g) {
     typedef typename T16<T>::vec8 vec8;
     constexpr int WN = 8 / WM;
-    constexpr int MT = G2_BM / WM / 32;                  // 32-row activation tiles per wave
+    constexpr int MT = BM / WM / 32;                  // 32-row activation tiles per wave
     constexpr int NT = BN / WN / 32;                     // 32-wide weight tiles per wave
     constexpr int KS = BK / 16;                          // 16-deep MFMA k-steps per K-tile
     constexpr int ROWB = BK * 2;                         // bytes per LDS row (64 or 128)
     constexpr int CPR = BK / 8;                          // 16-B chunks per row
     constexpr int RPI = 1024 / ROWB;                     // rows covered by one DMA instruction (1 KiB)
-    constexpr int A_BYTES = G2_BM * ROWB;
+    constexpr int A_BYTES = BM * ROWB;
     constexpr int W_BYTES = BN * ROWB;
     constexpr int STAGE = A_BYTES + W_BYTES;
     constexpr int A_INSTR = A_BYTES / 1024 / 8;          // DMA instructions per wave per K-tile
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
 
     int tm, tn;
     block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, 8, tm, tn);
-    const int m0 = tm * G2_BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA assignment: one instruction = RPI rows x ROWB bytes; lane -> (row = lane / CPR, LDS chunk slot = lane % CPR)
     // chunk swizzle: BK=32: (row>>3)&3, BK=64: (row>>1)&7 -- both invariant under row += 32 and conflict-free for the
@@ -576,17 +576,17 @@ static int launch256p(GemmArgs g, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0>
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM>
 static int launch256(GemmArgs g, hipStream_t s) {
-    constexpr int lds = STAGES * (G2_BM * BK * 2 + BN * BK * 2);
+    constexpr int lds = STAGES * (BM * BK * 2 + BN * BK * 2);
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done = true;
     }
-    g.tiles_m = ceil_div(g.M, G2_BM);
+    g.tiles_m = ceil_div(g.M, BM);
     g.tiles_n = ceil_div(g.N, BN);
-    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
+    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
 
@@ -610,8 +610,15 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
         if (cfg == 6 && !(tuning().gemm_flags & 256) && MODE == MODE_F32 && g.N >= 384 &&      // flags bit8: A/B switch (off) (g.N % 384 == 0 || g.K >= 8192) &&
             (long)ceil_div(g.M, 256) * ceil_div(g.N, 384) >= 160)
             cfg = 9;
+        // 384x256 tile (wave tile 192x64) for the SwiGLU gate/up GEMM: +6.8 % in same-call A/B (1090 -> 1164 TF/s); 16-bit-output
+        // K = 1152 shapes lose 3-4 % to the larger per-tile fixed cost and the fp32 kernels spill, so only this mode takes it -
+        // and only when the taller tile does not add padding rows (small M under context parallelism)
+        if (cfg == 6 && !(tuning().gemm_flags & 256) && MODE == MODE_SWIGLU && (long)ceil_div(g.M, 384) * ceil_div(g.N, 256) >= 160 &&
+            (long)ceil_div(g.M, 384) * 384 * 100 <= (long)ceil_div(g.M, 256) * 256 * 104)
+            cfg = 10;
     }     // see vitg_gemm (gemm.hip)                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
+    if (cfg == 10 && g.M >= 384) return launch256<T, MODE, 256, 2, 2, 64, false, 1, 384>(g, s);               // 384x256x64 phased (wave tile 192x64)
     if (cfg == 9 && MODE != MODE_SWIGLU && g.N >= 384) return launch256<T, MODE, 384, 2, 2, 64, false, 1>(g, s);   // 256x384x64 phased (wave tile 128x96)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
