@@ -84,6 +84,7 @@ struct Tuning {
     int gemm_cfg;      // 0 auto | 1 256x256x32 ring-4 | 2 256x128x32 ring-3 | 3 256x256x64 ring-2 | 4 persistent 256x256x64
     int gemm_flags;    // bit0 non-temporal stores; bits 1-3 profiling ablations (wrong results)
     int gemm_stagger;  // persistent kernel: de-phase XCDs
+    int gemm_group;    // gemm256: M-tiles per tile-order group (0 = default 4)
     int attn_waves;    // 0 auto | 4 | 8
     int attn_pipe;     // 0 off (default) | 1 cross-tile pipelined hd-72 variant
     int attn_dma;      // 0 auto (DMA for hd 72, registers for hd 128) | 1 LDS-DMA K/V staging | 2 register staging

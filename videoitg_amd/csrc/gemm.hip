@@ -207,7 +207,7 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
-    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0;
+    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4;
     g.flags = tuning().gemm_flags;
     hipStream_t s = (hipStream_t)stream;
     const int force = tuning().gemm_tile;          // 0 auto | 128 | 256 (vitg_set_option / VITG_GEMM_TILE)

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     const int wr = wave / WN, wc = wave % WN;
 
     int tm, tn;
-    block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, 8, tm, tn);
+    block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA assignment: one instruction = RPI rows x ROWB bytes; lane -> (row = lane / CPR, LDS chunk slot = lane % CPR)
@@ -586,6 +586,9 @@ static int launch256(GemmArgs g, hipStream_t s) {
     }
     g.tiles_m = ceil_div(g.M, BM);
     g.tiles_n = ceil_div(g.N, BN);
+    // M-tiles per group of the tile order (the 32 blocks resident on an XCD then cover group_m x 32/group_m tiles sharing operand
+    // panels in its L2): 4 measured best (+0.5 % on the step over 8; 16 and 32 lose 10-20 %, profiles/r01_gemm_shapes.md section 7)
+    g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
     hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }

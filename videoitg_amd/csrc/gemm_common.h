@@ -14,6 +14,7 @@ struct GemmArgs {
     void* out; int ldo;       // mode STORE16/SWIGLU: T16*, mode F32: float*
     const float* res; int ldr; int res_mod;   // mode F32: out = acc + bias + res[(m % res_mod), n] (res may be null)
     int tiles_m, tiles_n;
+    int group_m;              // gemm256: M-tiles per group of the XCD-aware tile order
     int stagger_ns;           // persistent kernel: tile period estimate for de-phasing the XCDs (0 = off)
     int flags;                // bit0: non-temporal output stores, bit1: (profiling) skip output stores
 };
