@@ -42,9 +42,19 @@ int vitg_version(void);
  * compute-unit count, or a negative error when no HIP device is usable. */
 int vitg_device_info(char* name, int name_len);
 
-/* Kernel-selection knobs for A/B measurements and tests (defaults come from the environment variables VITG_GEMM_TILE,
- * VITG_GEMM_CFG, VITG_GEMM_FLAGS, VITG_GEMM_STAGGER, VITG_ATTN_WAVES).  key: "gemm_tile" (0 auto | 128 | 256), "gemm_cfg"
- * (0 auto | 1..4), "gemm_flags", "gemm_stagger", "attn_waves" (0 auto | 4 | 8).  Host-only, no GPU needed. */
+/* Kernel-selection knobs for A/B measurements and tests; 0 = the measured default everywhere.  Defaults can also come from
+ * the environment (VITG_<KEY IN CAPS>).  Host-only, no GPU needed.  Keys:
+ *   gemm_tile   128 | 256                       force the 128x128 register-staged or the 256-wide LDS-DMA kernels
+ *   gemm_cfg    1 256x256x32 ring-4 | 2 256x128x32 | 3 256x256x64 ring-2 | 4 persistent | 5 asm LDS reads | 6 phased (default
+ *               for >= 160 tiles) | 7 phased, 2 k-steps per interval | 8 four waves x 128x128 (AGPR accumulators) |
+ *               9 256x384 (default for fp32-residual shapes) | 10 384x256 (default for SwiGLU)
+ *   gemm_group  M-tiles per group of the XCD-aware tile order (default 4)
+ *   gemm_flags  bit0 non-temporal stores, bit5 N-split launch, bit7 5-stage ring for cfg 8, bit8 disable cfg 9/10 auto-selection;
+ *               bits 1-4, 6: profiling ablations (WRONG results)
+ *   gemm_stagger  persistent kernel (cfg 4): de-phase the XCDs
+ *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
+ *   attn_ab     1 | 2  half-tile-out-of-phase hd-72 kernel on / off (default on)
+ *   attn_sp     1 | 2  software-pipelined kernel on (both head sizes) / off (default: on for hd 128) */
 int vitg_set_option(const char* key, int value);
 
 /* A0[T*G*G, Kpad] (16-bit) = im2col of pixel_values [T,3,R,R] NCHW (pix_dtype VITG_F32/F16/BF16), k ordered
