@@ -16,7 +16,7 @@ for M in (1660, 3260, 6460):
         else:
             out = torch.empty((M, N), dtype=dt, device="cuda"); kw = {}
         res = []
-        for tile, cfg in [(128, 0), (256, 3), (256, 2), (256, 1)]:
+        for tile, cfg in [(0, 0), (128, 0), (256, 6), (256, 2), (256, 9), (256, 10)]:
             ops.set_option("gemm_tile", tile); ops.set_option("gemm_cfg", cfg)
             for _ in range(3): ops.gemm(a, w, out, mode=mode, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,4 +26,4 @@ for M in (1660, 3260, 6460):
             ms = e0.elapsed_time(e1) / 10
             res.append(f"{2.0 * M * N * K / ms / 1e9:6.0f}")
         ops.set_option("gemm_tile", 0); ops.set_option("gemm_cfg", 0)
-        print(f"M={M:5d} {name:7s} TF/s: tile128 {res[0]} | 256x256x64 {res[1]} | 256x128x32 {res[2]} | 256x256x32 {res[3]}", flush=True)
+        print(f"M={M:5d} {name:7s} TF/s: auto {res[0]} | tile128 {res[1]} | cfg6 256x256 {res[2]} | cfg2 256x128 {res[3]} | cfg9 256x384 {res[4]} | cfg10 384x256 {res[5]}", flush=True)

@@ -601,25 +601,50 @@ bool gemm256_applicable(const GemmArgs& g, int mode) {
 }
 
 
+// Tile-shape selection.  Cost model: a launch runs ceil(tiles / CUs) rounds of one tile per CU (one block per CU for every
+// configuration but cfg 2), a round costs tile area / relative main-loop efficiency.  The efficiencies are same-call A/B results
+// (profiles/r01_gemm_shapes.md sections 5-8); what the model adds is the round quantisation, which decides the small-M shapes of
+// the context-parallel LLM (M = 1660 at 8 GPUs: gate/up takes 3 rounds of 384x256 instead of 5 of 256x256, +24 % measured) and
+// keeps the wide tiles off shapes where they would leave a nearly empty last round (down-proj at M = 6460: 256x384 -25 %).
+//   cfg 6  256x256 phased                      1.00
+//   cfg 2  256x128 (wave tile 64x64)           0.65 (fitted to the M = 1660 / 6460 measurements of tools/gemm_small_m.py)
+//   cfg 9  256x384 (wave tile 128x96)          fp32-residual: 1.07 for K >= 4096, else 1.00; 16-bit outputs 0.97; no SwiGLU
+//   cfg 10 384x256 (wave tile 192x64)          SwiGLU 1.07; 16-bit outputs 0.96; fp32-residual unusable (spills)
+// cfg 6 is kept unless another configuration is predicted at least 3 % faster.
+static int choose_cfg(const GemmArgs& g, int mode) {
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    auto cost = [&](int bm, int bn, double eff, int blocks_per_cu) {
+        const long tiles = (long)ceil_div(g.M, bm) * ceil_div(g.N, bn);
+        const long rounds = (tiles + (long)cus * blocks_per_cu - 1) / ((long)cus * blocks_per_cu);
+        return (double)rounds * blocks_per_cu * bm * bn / eff;
+    };
+    const bool wide_ok = !(tuning().gemm_flags & 256);               // flags bit8: A/B switch (wide tiles off)
+    double best = cost(256, 256, 1.00, 1);
+    int cfg = 6;
+    if (g.N < 256) return 2;
+    const double c2 = cost(256, 128, 0.65, 1);
+    if (c2 < 0.97 * best) { best = c2; cfg = 2; }
+    if (wide_ok && mode != MODE_SWIGLU && g.N >= 384) {
+        const double e = mode == MODE_F32 ? (g.K >= 4096 ? 1.07 : 1.00) : 0.97;
+        const double c9 = cost(256, 384, e, 1);
+        if (c9 < 0.97 * best) { best = c9; cfg = 9; }
+    }
+    if (wide_ok && mode != MODE_F32 && g.M >= 384) {
+        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : 0.96, 1);
+        if (c10 < 0.97 * best) { best = c10; cfg = 10; }
+    }
+    return cfg;
+}
+
 template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     int cfg = tuning().gemm_cfg;
-    if (!cfg) {
-        cfg = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) >= 160 ? 6 : 2;
-        // 256x384 tile (wave tile 128x96: 0.58 KiB of fragment reads per MFMA instead of 0.75, 154 instead of 128 flop per operand
-        // byte) for the fp32-residual GEMMs whose N it divides, or whose K is long enough to amortise a ragged last column tile.
-        // Same-call A/B (profiles/r01_gemm_shapes.md section 5): fc2 +17 %, down +10 %, out-proj +3 %; 16-bit-output shapes lose
-        // 1-10 % (two-pass staged epilogue, ragged N), so they stay on the 256x256 tile.
-        if (cfg == 6 && !(tuning().gemm_flags & 256) && MODE == MODE_F32 && g.N >= 384 &&      // flags bit8: A/B switch (off) (g.N % 384 == 0 || g.K >= 8192) &&
-            (long)ceil_div(g.M, 256) * ceil_div(g.N, 384) >= 160)
-            cfg = 9;
-        // 384x256 tile (wave tile 192x64) for the SwiGLU gate/up GEMM: +6.8 % in same-call A/B (1090 -> 1164 TF/s); 16-bit-output
-        // K = 1152 shapes lose 3-4 % to the larger per-tile fixed cost and the fp32 kernels spill, so only this mode takes it -
-        // and only when the taller tile does not add padding rows (small M under context parallelism)
-        if (cfg == 6 && !(tuning().gemm_flags & 256) && MODE == MODE_SWIGLU && (long)ceil_div(g.M, 384) * ceil_div(g.N, 256) >= 160 &&
-            (long)ceil_div(g.M, 384) * 384 * 100 <= (long)ceil_div(g.M, 256) * 256 * 104)
-            cfg = 10;
-    }     // see vitg_gemm (gemm.hip)                  // 3 = 256x256x64 ring-2 (default); 4 = persistent variant (measured 3-8 % slower)
+    if (!cfg) cfg = choose_cfg(g, MODE);
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
     if (cfg == 10 && g.M >= 384) return launch256<T, MODE, 256, 2, 2, 64, false, 1, 384>(g, s);               // 384x256x64 phased (wave tile 192x64)
     if (cfg == 9 && MODE != MODE_SWIGLU && g.N >= 384) return launch256<T, MODE, 384, 2, 2, 64, false, 1>(g, s);   // 256x384x64 phased (wave tile 128x96)
