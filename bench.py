@@ -276,6 +276,24 @@ def main():
                                                       "unit": "frames/s", "ms_per_step": round(d1 * 1e3, 2),
                                                       "preprocess_ms": round(e0.elapsed_time(e1), 3)}}
             del frames
+            # B0 = 512 frames at the reference-native 384^2 (27x27 grid, no position-embedding interpolation): SURVEY.md 8d
+            g0 = torch.Generator().manual_seed(1234)
+            pix0 = (torch.rand((T, 3, 384, 384), generator=g0) * 2 - 1).to(dtype).to(dev)
+
+            def step_b0():
+                _, order_ = ops.rank(eng.forward(ids, None, [pix0])[0].view(-1))
+                return order_.cpu().tolist()
+            step_b0()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            step_b0()
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t2
+            fl0 = algorithmic_flops(cfg, T, 384, ids.shape[1] - 1)
+            out["secondary"]["b0_384"] = {"input": f"{T} x 384^2 (reference-native resolution), N={fl0['N']}", "value": round(T / d2, 2),
+                                          "unit": "frames/s", "ms_per_step": round(d2 * 1e3, 2),
+                                          "algorithmic_tflop_per_video": round(fl0["total"] / 1e12, 1)}
+            del pix0
         if world == 1 and not args.no_cpu_baseline:
             eng.release_workspace()
             try:

@@ -138,6 +138,9 @@ CASES = {
                        ids=[[-200, 5, 6, 7, 8, 9], [-200, 30, 31, 0, 0, 0]], pad=0),
     # T > 512 -> chunked ViT (384) and chunked pool (512) branches; 2x2 grid pooled to 1x1
     "chunk520": dict(cfg=dict(vision_token_num=600, vision=dict(image_size=28)), T=[520], ids=[[-200, 5, 6, 7]]),
+    # image side not a multiple of the patch (62 = 4*14 + 6, like SigLIP-so400m's 384 = 27*14 + 6): the stride-14 VALID
+    # convolution ignores the last 6 rows / columns
+    "ragged_image": dict(cfg=dict(vision_token_num=72, vision=dict(image_size=62)), T=[7], ids=[[-200, 5, 6, 7, 8]]),
 }
 
 

@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520"]
+CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image"]
 SCORE_TOL = 1e-3
 
 
@@ -266,8 +266,20 @@ def test_dead_row_skipping_does_not_change_results(golden_dir, name):
         assert (x - y).abs().max().item() < 2e-3
 
 
-def test_full_size_invariants():
-    """BASELINE.json configs[1] at FULL size (512 frames x 448^2, 26 + 28 layers, N = 12 860): the fp32 oracle cannot run
+@pytest.fixture(scope="module")
+def full_engine():
+    from videoitg_amd.config import ITGConfig
+    from videoitg_amd.engine import SelectorEngine
+    from videoitg_amd.synth_device import packed_random_weights
+    eng = SelectorEngine(packed_random_weights(ITGConfig(), torch.float16, "cuda:0", seed=0))
+    yield eng
+
+
+# BASELINE.json configs: [1] 512 x 448^2 (the bench workload), B0 512 x 384^2 (the only reference-native shape: 27x27 grid, no
+# pos-emb interpolation, 5x5 pool), [0] = C1 64 x 384^2 (16x16 pool, N = 16 445: the LLM-heavy case)
+@pytest.mark.parametrize("T,R", [(512, 448), (512, 384), (64, 384)])
+def test_full_size_invariants(full_engine, T, R):
+    """BASELINE.json configurations at FULL size (all 26 + 28 layers, real widths): the fp32 oracle cannot run
     this on a host in test time, so parity is carried by size-independent properties:
       * run-to-run bit-identical logits (no atomics, no order-dependent reductions anywhere on the path);
       * the same video through DIFFERENT kernels (128x128 register-staged GEMM instead of the 256-wide LDS-DMA ones; per-tile
@@ -276,13 +288,9 @@ def test_full_size_invariants():
       * frame order of the ranking is a permutation, scores sorted, Top-32 stable across the kernel sets wherever the score
         gap exceeds the tolerance."""
     from videoitg_amd import ops
-    from videoitg_amd.config import ITGConfig
-    from videoitg_amd.engine import SelectorEngine
-    from videoitg_amd.synth_device import packed_random_weights
     from videoitg_amd import synth
-    cfg = ITGConfig()
-    T, R = 512, 448
-    eng = SelectorEngine(packed_random_weights(cfg, torch.float16, "cuda:0", seed=0))
+    eng = full_engine
+    cfg = eng.cfg
     g = torch.Generator().manual_seed(1234)
     pix = (torch.rand((T, 3, R, R), generator=g) * 2 - 1).to(torch.float16).cuda()
     ids = torch.cat([torch.tensor([-200]), synth.synth_prompt_ids(60, cfg.vocab_size)]).view(1, -1)
@@ -314,7 +322,6 @@ def test_full_size_invariants():
     assert (ranked[:-1] >= ranked[1:]).all()
     srt, oa = torch.sort(a, descending=True, stable=True)
     ob = torch.sort(b, descending=True, stable=True)[1]
-    for k in (1, 8, 32, 128):
-        if (srt[k - 1] - srt[k]).item() > 2 * dl + 1e-6:
+    for k in (1, 8, 32):
+        if k < T and (srt[k - 1] - srt[k]).item() > 2 * dl + 1e-6:
             assert set(oa[:k].tolist()) == set(ob[:k].tolist()), k
-    eng.release_workspace()

@@ -11,7 +11,7 @@ from oracle import videoitg_oracle as O
 from videoitg_amd import synth
 from videoitg_amd.config import ITGConfig
 
-CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520"]
+CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image"]
 TOL = 2e-5
 
 

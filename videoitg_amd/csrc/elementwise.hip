@@ -295,7 +295,8 @@ using namespace vitg;
 extern "C" int vitg_patchify(const void* pix, int pix_dtype, void* out, int T, int R, int patch, int Kpad, int dtype,
                              void* stream) {
     if (T <= 0) return 0;
-    if (R % patch) return VITG_ERR_SHAPE;
+    if (R < patch) return VITG_ERR_SHAPE;          // R need not be a multiple of the patch: like the stride-14 VALID convolution it replaces,
+                                                   // the kernel ignores the last R % patch rows and columns (SigLIP-so400m: 384 = 27 * 14 + 6)
     if (Kpad < 3 * patch * patch) return VITG_ERR_SHAPE;
     const int G = R / patch;
     const long rows = (long)T * G * G;
