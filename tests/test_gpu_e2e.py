@@ -325,3 +325,34 @@ def test_full_size_invariants(full_engine, T, R):
     for k in (1, 8, 32):
         if k < T and (srt[k - 1] - srt[k]).item() > 2 * dl + 1e-6:
             assert set(oa[:k].tolist()) == set(ob[:k].tolist()), k
+
+
+@pytest.mark.parametrize("T,R,prompt", [(1, 384, 60), (7, 448, 1), (22, 384, 0), (23, 384, 17), (200, 384, 60), (513, 384, 5), (600, 392, 60)])
+def test_full_width_shape_sweep(full_engine, T, R, prompt):
+    """Frame counts on both sides of every branch of the pooled-grid rule (T <= 22: no pooling at 27x27; 23: 26x26; 200: 9x9;
+    > 512: chunked tower / pool, grid 5 -> 4 at 600), a lone frame, an empty prompt, and a resolution whose grid is not the
+    checkpoint's (392 = 28 * 14: position embeddings interpolated).  Real widths and depths; checks shape, finiteness,
+    run-to-run determinism and agreement of the two kernel sets."""
+    from videoitg_amd import ops, synth
+    eng = full_engine
+    cfg = eng.cfg
+    g = torch.Generator().manual_seed(77 + T)
+    pix = (torch.rand((T, 3, R, R), generator=g) * 2 - 1).to(torch.float16).cuda()
+    ids = torch.cat([torch.tensor([-200]), synth.synth_prompt_ids(prompt, cfg.vocab_size)]).view(1, -1) if prompt else torch.tensor([[-200]])
+
+    def run():
+        out = eng.forward(ids, None, [pix])[0]
+        torch.cuda.synchronize()
+        return out.float().cpu()
+    a = run()
+    assert a.shape == (T, 1) and torch.isfinite(a).all()
+    assert torch.equal(a, run())
+    ops.set_option("gemm_tile", 128)
+    ops.set_option("attn_sp", 2)
+    ops.set_option("attn_ab", 2)
+    try:
+        b = run()
+    finally:
+        for k in ("gemm_tile", "attn_sp", "attn_ab"):
+            ops.set_option(k, 0)
+    assert (a - b).abs().max().item() <= 4e-3
