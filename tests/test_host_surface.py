@@ -78,6 +78,16 @@ def test_checkpoint_directory_layouts(tmp_path):
         llm, vis = split_checkpoint({**sd, **layout})
         assert set(llm) == set(sd) and set(vis) == set(vsd)
     assert set(normalise_vision_keys(vsd)) == set(vsd)
+    # the Hub repo google/siglip-so400m-patch14-384 is the full two-tower model: its text tower has layers of the SAME shapes
+    # (text_model.encoder.layers.N...) plus logit_scale / logit_bias; none of it may leak into (or overwrite) the vision tower
+    two_tower = dict(vsd)
+    for k, v in vsd.items():
+        if ".encoder.layers." in k or ".embeddings." in k:
+            two_tower["text_model." + k[len("vision_model."):]] = torch.full_like(v, 1e9)
+    two_tower["logit_scale"] = torch.zeros(1)
+    two_tower["logit_bias"] = torch.zeros(1)
+    picked = normalise_vision_keys(two_tower)
+    assert set(picked) == set(vsd) and all(torch.equal(picked[k], vsd[k]) for k in vsd)
     (tw / "model.safetensors").unlink()
     os.rmdir(tw)
     with pytest.raises(FileNotFoundError):

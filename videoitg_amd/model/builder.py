@@ -70,6 +70,10 @@ def normalise_vision_keys(sd: SD) -> SD:
     flattened form without the ``vision_model.`` level."""
     out: SD = {}
     for k, v in sd.items():
+        # the Hub SigLIP repo is the full two-tower model: its text tower has the same widths as the so400m vision tower
+        # (text_model.encoder.layers.N...), so it must be dropped by NAME or it would silently overwrite the vision layers
+        if k.startswith("text_model.") or ".text_model." in k or k in ("logit_scale", "logit_bias"):
+            continue
         for anchor in ("embeddings.", "encoder.layers.", "post_layernorm.", "head."):
             i = k.find(anchor)
             if i >= 0 and (i == 0 or k[i - 1] == "."):
