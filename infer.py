@@ -26,15 +26,16 @@ DEVICE = torch.device("cuda:0")
 def read_video(path, num_frm=512, target_fps=2):
     if path != "synthetic":
         return read_video_decord(path, num_frm=num_frm, target_fps=target_fps)
-    total, fps = 18000, 29.97                                   # a 10-minute clip
+    fps = 29.97
+    total = int(num_frm * fps / target_fps * 1.17)              # a clip a bit longer than num_frm samples at target_fps (512 -> ~10 min)
     idx = get_frame_indices(total, fps, target_fps, num_frm)
     rng = np.random.default_rng(1234)
     frames = rng.integers(0, 256, (len(idx), 120, 160, 3), dtype=np.uint8)
     return frames, idx, round(total / fps)
 
 
-def topk_selection(model, tokenizer, image_processor, prompt, video_path, num_topk, dtype):
-    video, frame_idx, _ = read_video(video_path, num_frm=512, target_fps=2)                       # infer.py:54
+def topk_selection(model, tokenizer, image_processor, prompt, video_path, num_topk, dtype, num_frm=512):
+    video, frame_idx, _ = read_video(video_path, num_frm=num_frm, target_fps=2)                   # infer.py:54
     video_tensor = image_processor.preprocess(video, return_tensors="pt")["pixel_values"].to(dtype).to(DEVICE)
     prompt = DEFAULT_IMAGE_TOKEN + prompt + "\n"                                                   # infer.py:60
     input_ids = tokenizer_image_token(prompt, tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt")
@@ -55,11 +56,14 @@ def main():
                                         "Knight; D. Oppenheimer; E. Dune \n Please respond with only the letter of the correct answer.")
     ap.add_argument("--topk", type=int, default=32)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--num-frames", type=int, default=0, help="frames to sample (reference: 512; default 32 for synthetic:tiny, whose "
+                                                              "72-token visual budget pools 512 frames down to nothing)")
     a = ap.parse_args()
+    num_frm = a.num_frames or (32 if a.model.startswith("synthetic:tiny") or a.model == "synthetic" else 512)
     dtype = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     tok, model, proc, _ = load_pretrained_model(a.model, None, get_model_name_from_path(a.model), device_map="cuda:0", torch_dtype=dtype)
     model.eval().to(DEVICE)
-    selected, _ = topk_selection(model, tok, proc, a.prompt, a.video, a.topk, dtype)
+    selected, _ = topk_selection(model, tok, proc, a.prompt, a.video, min(a.topk, num_frm), dtype, num_frm)
     print(selected)
 
 

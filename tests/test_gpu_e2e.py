@@ -356,3 +356,17 @@ def test_full_width_shape_sweep(full_engine, T, R, prompt):
         for k in ("gemm_tile", "attn_sp", "attn_ab"):
             ops.set_option(k, 0)
     assert (a - b).abs().max().item() <= 4e-3
+
+
+def test_infer_entry_point_runs_offline():
+    """python infer.py --model synthetic:tiny --video synthetic: the reference's entry-point flow (sample -> preprocess ->
+    prompt -> model -> sigmoid/sort -> Top-K ascending) end to end on the GPU with the synthetic decoder stand-in."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--model", "synthetic:tiny", "--video", "synthetic", "--topk", "8"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    sel = eval(out.stdout.strip().splitlines()[-1])
+    assert len(sel) == 8 and sel == sorted(sel) and len(set(sel)) == 8
