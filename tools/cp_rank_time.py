@@ -50,3 +50,24 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 print(f"world={world}: rank-local step {dt * 1e3:.1f} ms (tower part {e[0].elapsed_time(e[1]):.1f} ms); "
       f"n_local={plan.n_local[rank]} of {plan.total} tokens, {len(fr)} frames")
+
+# the same step replayed from a captured graph: what the launch gaps between the ~850 kernels of a step cost
+try:
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        step()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    dg = (time.perf_counter() - t0) / 3
+    print(f"world={world}: graph replay {dg * 1e3:.1f} ms  (stream launches {dt * 1e3:.1f} ms)")
+except Exception as ex:  # noqa: BLE001
+    print("graph capture failed:", type(ex).__name__, str(ex)[:300])
