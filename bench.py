@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--res", type=int, default=448)
     ap.add_argument("--prompt-len", type=int, default=60)
-    # fp16 = the reference's inference dtype (builder.py:59) and the dtype the parity tests hold to 1e-3; bf16 (BASELINE.json's
-    # wording) runs at the same MFMA rate and is available with --dtype bf16
-    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
+    # bf16 = the dtype of BASELINE.json's bench configuration; fp16 = the reference's inference dtype (builder.py:59) and the dtype
+    # the parity tests hold to 1e-3.  Same kernels, same rate class.
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="MFMA input type; bf16 = the configuration BASELINE.json names, fp16 = what the reference itself runs (model.half())")
     ap.add_argument("--config", default="full", choices=["full", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the from-uint8-frames (GPU preprocessing) measurement")
