@@ -21,13 +21,13 @@ def ops():
     return o
 
 
-@pytest.fixture(params=["auto", "tile128", "cfg1_256x256x32", "cfg2_256x128x32", "cfg3_256x256x64", "cfg4_persistent", "cfg5_asm_reads", "cfg6_phased", "cfg7_phased2", "cfg8_w4_128x128", "cfg9_256x384", "cfg10_384x256"])
+@pytest.fixture(params=["auto", "tile128", "cfg1_256x256x32", "cfg2_256x128x32", "cfg3_256x256x64", "cfg4_persistent", "cfg5_asm_reads", "cfg6_phased", "cfg7_phased2", "cfg8_w4_128x128", "cfg9_256x384", "cfg10_384x256", "cfg11_regstaged"])
 def gemm_cfg(request, ops):
     """Every GEMM kernel configuration is forced in turn (vitg_set_option), so the 256-tile kernels are covered at test
     sizes too (auto mode would pick the 128 tile for them)."""
     name = request.param
     tile, cfg = {"auto": (0, 0), "tile128": (128, 0), "cfg1_256x256x32": (256, 1), "cfg2_256x128x32": (256, 2),
-                 "cfg3_256x256x64": (256, 3), "cfg4_persistent": (256, 4), "cfg5_asm_reads": (256, 5), "cfg6_phased": (256, 6), "cfg7_phased2": (256, 7), "cfg8_w4_128x128": (256, 8), "cfg9_256x384": (256, 9), "cfg10_384x256": (256, 10)}[name]
+                 "cfg3_256x256x64": (256, 3), "cfg4_persistent": (256, 4), "cfg5_asm_reads": (256, 5), "cfg6_phased": (256, 6), "cfg7_phased2": (256, 7), "cfg8_w4_128x128": (256, 8), "cfg9_256x384": (256, 9), "cfg10_384x256": (256, 10), "cfg11_regstaged": (256, 11)}[name]
     ops.set_option("gemm_tile", tile)
     ops.set_option("gemm_cfg", cfg)
     yield name

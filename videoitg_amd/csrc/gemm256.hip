@@ -72,6 +72,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     }
     constexpr int LPT = A_INSTR + W_INSTR;               // DMA instructions per thread per K-tile
     auto issue_one = [&](int kt, int j) {                // j-th DMA instruction of K-tile kt (j compile-time after unroll)
+        if (kt > 0 && (g.flags & 64)) return;            // profiling only (wrong results): operand stream off after the first K-tile
         char* st = smem + (kt % STAGES) * STAGE;
         const size_t koff = (size_t)kt * ROWB;
         if (j < A_INSTR)
@@ -84,6 +85,21 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     auto issue = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < LPT; ++j) issue_one(kt, j);
+    };
+    // Register-staged operand stream (PH == 3): the same 1-KiB pieces, but global_load_dwordx4 -> VGPR -> ds_write_b128 instead
+    // of LDS-DMA.  Why: with the DMA the main loop loses 40 % (cfg 6 reaches 1858 TF/s on 8192^3 with the operand stream switched
+    // off after the first K-tile, 1128 with it), and tools/ubench/lds_port_share.hip shows LDS-DMA writes starving behind
+    // ds_read traffic; a ds_write_b128 moves 1 KiB in 8 LDS cycles.  Two register sets: tile kt+2 is in flight from global memory
+    // (a whole tile of latency budget) while tile kt+1 is being written into the free LDS stage.
+    u32x4 stg[PH == 3 ? 2 : 1][PH == 3 ? LPT : 1];
+    auto load_one = [&](int kt, int j, u32x4 (&set)[PH == 3 ? LPT : 1]) {
+        const size_t koff = (size_t)kt * ROWB;
+        set[j] = *(const u32x4*)((j < A_INSTR ? a_src[j] : w_src[j - A_INSTR]) + koff);
+    };
+    auto store_one = [&](int kt, int j, const u32x4 (&set)[PH == 3 ? LPT : 1]) {
+        char* st = smem + (kt % STAGES) * STAGE;
+        char* dst = j < A_INSTR ? st + (wave * A_INSTR + j) * 1024 : st + A_BYTES + (wave * W_INSTR + j - A_INSTR) * 1024;
+        *(u32x4*)(dst + lane * 16) = set[j];
     };
 
     const int frow = lane & 31, fh = lane >> 5;
@@ -135,9 +151,25 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
 
     const int nk = g.K / BK;
     constexpr int DIST = STAGES - 1;                     // prefetch distance in K-tiles
+    if constexpr (PH == 3) {
+        // tile 0 -> LDS through registers, tile 1 -> register set 1 (in flight)
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) load_one(0, j, stg[0]);
+        if (nk > 1) {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) load_one(1, j, stg[1]);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) store_one(0, j, stg[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
     issue(0);
     if (DIST > 1 && nk > 1) issue(1);
     if (DIST > 2 && nk > 2) issue(2);
+    }
 
     // Software pipeline at 16-deep k-step granularity with two named fragment sets: the MFMAs of one k-step run while
     // the ds_read_b128 of the next k-step are in flight (LDS latency off the MFMA critical path).
@@ -190,13 +222,53 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
         // Stage (kt+1)&1 is last read by B's R_{4(kt-1)+3} in interval 8kt-1, so DMA for tile kt+1 may be issued from
         // interval 8kt on (A: p = 0,1,2 -> 8kt+0,+2,+4; B: 8kt+1,+3,+5); it must have landed before A's R_{4(kt+1)} in interval
         // 8kt+8: both groups drain vmcnt at the END of interval 8kt+7 (A after M_3, B after R_3).
-        static_assert(PH == 0 || (STAGES == 2 && BK == 64), "phased schedule is written for the 256x256x64 ring-2 configuration");
+        static_assert(PH == 0 || (STAGES == 2 && BK == 64), "phased schedule is written for the ring-2, 64-deep configurations");
         const bool grpB = wr == 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PH != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grpB) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PH == 1) {
+        if constexpr (PH == 3) {
+        // Same interval structure as PH == 1; in its first three R phases of tile kt a wave writes its pieces of tile kt+1 from
+        // the register set that was loaded during tile kt-1 into stage (kt+1)&1 (free since interval 8kt, see above), after having
+        // re-armed the OTHER set with the global loads of tile kt+2.  The LDS writes are drained (lgkmcnt) before the barrier that
+        // ends the tile; global loads stay in flight across it.
+        auto tile = [&](int kt, auto par_c) {
+            constexpr int PAR = decltype(par_c)::value;                 // kt & 1: tile kt+1 lives in stg[PAR ^ 1], tile kt+2 goes to stg[PAR]
+            const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+#pragma unroll
+            for (int pp = 0; pp < KS; ++pp) {
+                G2_READ(fa0, fw0, kt, pp)
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp == 0 && more) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile kt+1 has been in flight for a whole tile
+                    if (more2) {
+#pragma unroll
+                        for (int j = 0; j < LPT; ++j) load_one(kt + 2, j, stg[PAR]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more && pp < 3) {
+#pragma unroll
+                    for (int j = 0; j < LPT; ++j)
+                        if (j / ((LPT + 2) / 3) == pp) store_one(kt + 1, j, stg[PAR ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pp == KS - 1 && more && grpB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS writes of tile kt+1 are done
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                G2_MMA(fa0, fw0)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            tile(kt, std::integral_constant<int, 0>{});
+            if (kt + 1 < nk) tile(kt + 1, std::integral_constant<int, 1>{});
+        }
+        } else if constexpr (PH == 1) {
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
 #pragma unroll
@@ -651,6 +723,7 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
+    if (cfg == 11) return launch256<T, MODE, 256, 2, 2, 64, false, 3>(g, s);    // 11 = phased, operands staged through registers instead of LDS-DMA
     if (cfg == 6) return launch256<T, MODE, 256, 2, 2, 64, false, 1>(g, s);     // 6 = phased, 1 k-step per interval
     if (cfg == 7) return launch256<T, MODE, 256, 2, 2, 64, false, 2>(g, s);     // 7 = phased, 2 k-steps per interval
     if (cfg == 5) return launch256<T, MODE, 256, 2, 2, 64, true>(g, s);       // 5 = inline-asm LDS reads + counted lgkmcnt (measured = cfg 3)
