@@ -281,13 +281,13 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
                         if (j / ((LPT + 2) / 3) == pp) issue_one(kt + 1, j);       // LPT = 8: pieces 0-2, 3-5, 6-7 at p = 0, 1, 2
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (pp == KS - 1 && more && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (pp == KS - 1 && more && grpB && !(g.flags & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (flags bit2: profiling, wrong results)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 G2_MMA(fa0, fw0)
                 __builtin_amdgcn_sched_barrier(0);
-                if (pp == KS - 1 && more && !grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (pp == KS - 1 && more && !grpB && !(g.flags & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
