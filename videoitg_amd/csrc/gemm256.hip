@@ -276,9 +276,13 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
                 G2_READ(fa0, fw0, kt, pp)
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && pp < 3) {
+                    // Pieces of tile kt+1: spread over the first three R phases (LPT = 8: 3 + 3 + 2).  Front-loading them (all in the first
+                    // R phase, 7 + 3 for the 10-piece tiles; flags bit9) wins 2-10 % on every shape when one GEMM is timed in a loop, but
+                    // LOSES 1 % inside the real step (GEMM 1027 -> 1014 TF/s, alternating runs, both dtypes), so the spread stays.
+                    const bool front = g.flags & 512;
 #pragma unroll
                     for (int j = 0; j < LPT; ++j)
-                        if (j / ((LPT + 2) / 3) == pp) issue_one(kt + 1, j);       // LPT = 8: pieces 0-2, 3-5, 6-7 at p = 0, 1, 2
+                        if (front ? (LPT <= 8 ? pp == 0 : (j < 7 ? pp == 0 : pp == 1)) : (j / ((LPT + 2) / 3) == pp)) issue_one(kt + 1, j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (pp == KS - 1 && more && grpB && !(g.flags & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (flags bit2: profiling, wrong results)
