@@ -686,7 +686,8 @@ bool gemm256_applicable(const GemmArgs& g, int mode) {
 //   cfg 2  256x128 (wave tile 64x64)           0.65 (fitted to the M = 1660 / 6460 measurements of tools/gemm_small_m.py)
 //   cfg 9  256x384 (wave tile 128x96)          fp32-residual: 1.07 for K >= 4096, else 1.00; 16-bit outputs 1.00 (qkv: -1.3 % in an
 //                                              isolated loop, +3.5 % inside the step - the step decides); no SwiGLU
-//   cfg 10 384x256 (wave tile 192x64)          SwiGLU 1.07; 16-bit outputs 0.96; fp32-residual unusable (spills)
+//   cfg 10 384x256 (wave tile 192x64)          SwiGLU 1.07; 16-bit outputs 1.08 (fc1 / qkv: -3 % in an isolated loop but +1.3 % of the
+//                                              WHOLE step in alternating bench.py runs - the step decides); fp32-residual unusable (spills)
 // cfg 6 is kept unless another configuration is predicted at least 3 % faster.
 static int choose_cfg(const GemmArgs& g, int mode) {
     static int cus = 0;
@@ -707,12 +708,12 @@ static int choose_cfg(const GemmArgs& g, int mode) {
     const double c2 = cost(256, 128, 0.65, 1);
     if (c2 < 0.97 * best) { best = c2; cfg = 2; }
     if (wide_ok && mode != MODE_SWIGLU && g.N >= 384) {
-        const double e = mode == MODE_F32 ? (g.K >= 4096 ? 1.07 : 1.00) : ((tuning().gemm_flags & 2048) ? 0.90 : 1.00);   // flags bit11: A/B (16-bit outputs off the wide tile)
+        const double e = mode == MODE_F32 ? ((g.K >= 4096 || (tuning().gemm_flags & 8192)) ? 1.07 : 1.00) : ((tuning().gemm_flags & 2048) ? 0.90 : 1.00);   // flags bit11: A/B (16-bit outputs off the wide tile)
         const double c9 = cost(256, 384, e, 1);
         if (c9 < 0.97 * best) { best = c9; cfg = 9; }
     }
     if (wide_ok && mode != MODE_F32 && g.M >= 384) {
-        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : 0.96, 1);
+        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : ((tuning().gemm_flags & 4096) ? 0.96 : 1.08), 1);    // flags bit12: A/B (16-bit outputs off the tall tile); bit13: o-proj on the wide tile
         if (c10 < 0.97 * best) { best = c10; cfg = 10; }
     }
     return cfg;
