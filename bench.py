@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
                     help="MFMA input type; bf16 = the configuration BASELINE.json names, fp16 = what the reference itself runs (model.half())")
     ap.add_argument("--config", default="full", choices=["full", "tiny"])
+    ap.add_argument("--graph", action="store_true", help="replay the single-GPU step from a captured HIP graph (same kernels; no gain measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the from-uint8-frames (GPU preprocessing) measurement")
     ap.add_argument("--seed", type=int, default=0)
@@ -189,8 +190,15 @@ def main():
     timer = GemmTimer()
     ops.gemm = timer.wrap(ops.gemm)
 
+    graphed = None
+    if args.graph and cp is None:
+        from videoitg_amd.engine import GraphedForward
+        graphed = GraphedForward(eng, ids, pix)
+
     def step():
-        if cp is None:
+        if graphed is not None:
+            logits = graphed(ids, pix)
+        elif cp is None:
             logits = eng.forward(ids, None, [pix])[0].view(-1)
         else:
             logits = cp.forward(eng, ids, pix)

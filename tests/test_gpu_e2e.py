@@ -370,3 +370,27 @@ def test_infer_entry_point_runs_offline():
     assert out.returncode == 0, out.stderr[-2000:]
     sel = eval(out.stdout.strip().splitlines()[-1])
     assert len(sel) == 8 and sel == sorted(sel) and len(set(sel)) == 8
+
+
+def test_graph_captured_forward_replays_bit_identically(golden_dir):
+    """HIP-graph capture of the per-video forward (BASELINE.json configs[3]): replay with NEW pixel values and NEW prompt
+    token values (same layout) must equal the eager forward bit for bit; a different layout is refused."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import GraphedForward, PackedWeights, SelectorEngine
+    cfg = tiny_config(vision_token_num=72)
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    ids0 = torch.tensor([[11, 12, -200, 5, 6, 7]])
+    pix0 = synth.synth_pixel_values(8, cfg.vision.image_size, seed=1).half().cuda()
+    gf = GraphedForward(eng, ids0, pix0)
+    for seed, ids in [(1, ids0), (2, torch.tensor([[30, 31, -200, 40, 41, 42]])), (3, torch.tensor([[9, 8, -200, 7, 6, 5]]))]:
+        pix = synth.synth_pixel_values(8, cfg.vision.image_size, seed=seed).half().cuda()
+        got = gf(ids, pix)
+        want = eng.forward(ids, None, [pix])[0].view(-1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), seed
+    with pytest.raises(ValueError):
+        gf(torch.tensor([[11, -200, 5, 6, 7, 8]]), pix0)                 # <image> moved
+    with pytest.raises(ValueError):
+        gf(ids0, pix0[:6])                                               # fewer frames

@@ -334,9 +334,10 @@ class SelectorEngine:
 
     # ---- whole path for one sample whose frames are already encoded ---------------------------------
     def score_video(self, feats: torch.Tensor, T: int, G: int, ids: torch.Tensor, cmap: Optional[torch.Tensor] = None,
-                    pc: int = 0) -> torch.Tensor:
+                    pc: int = 0, ids_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         """feats fp32 [T*P, Dv] (this video's rows), ids HOST int64 [L] (unpadded, one IMAGE_TOKEN_INDEX) ->
-        logits fp32 [T]."""
+        logits fp32 [T].  ids_dev: the same ids already on the device (graph capture: no host-to-device copy may be
+        recorded; only the text VALUES are read from it, the layout comes from the host copy)."""
         cfg = self.cfg
         ids = ids.cpu()
         pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
@@ -355,10 +356,12 @@ class SelectorEngine:
             n = keep
         x = self._buf("llm_x", (n, cfg.hidden_size), torch.float32)
         if pre.numel():
-            ops.embed_gather(pre.contiguous().to(self.device), self.w.embed, x[:pre.numel()])
+            src = ids_dev[:pos[0]] if ids_dev is not None else pre.contiguous().to(self.device)
+            ops.embed_gather(src, self.w.embed, x[:pre.numel()])
         self.project_into(feats, T, G, hw, x[pre.numel():pre.numel() + nv], cmap, pc)
         if post.numel():
-            ops.embed_gather(post.contiguous().to(self.device), self.w.embed, x[pre.numel() + nv:])
+            src = ids_dev[pos[0] + 1:pos[0] + 1 + post.numel()] if ids_dev is not None else post.contiguous().to(self.device)
+            ops.embed_gather(src, self.w.embed, x[pre.numel() + nv:])
         hfin = self.llm_forward(x)
         logits = torch.empty(T, dtype=torch.float32, device=self.device)
         ops.pool_score(hfin[pre.numel():], T, hw * hw, cfg.hidden_size, self.w.head_w, self.w.head_b, logits)
@@ -397,3 +400,53 @@ class SelectorEngine:
             out.append(lg.reshape(T, 1))
             row += T
         return out
+
+
+class GraphedForward:
+    """One video's selector forward captured in a HIP graph (torch.cuda.CUDAGraph) and replayed: ~850 kernel launches become
+    one graph launch.  The capture is keyed by what fixes the launch geometry - frame count, resolution, prompt length and
+    the position of <image> - while the pixel values and the prompt token VALUES are read from static device buffers that
+    are refreshed before every replay.  (BASELINE.json's batch-of-videos configuration asks for a graph-captured per-video
+    forward; at one video per GPU the launch gaps are not what limits the step - tools/cp_rank_time.py measures replay =
+    stream launches within 0.3 % - so this is an option, not the default path.)"""
+
+    def __init__(self, eng: "SelectorEngine", input_ids: torch.Tensor, pix: torch.Tensor):
+        self.eng = eng
+        ids = input_ids.reshape(-1).cpu()
+        self.layout = (tuple((ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()), ids.numel(), tuple(pix.shape))
+        self.ids_host = ids.clone()
+        self.ids_dev = ids.clamp(min=0).to(eng.device)                   # <image> slot is never read
+        self.pix = pix.to(eng.device).clone()
+        T = pix.shape[0]
+        self._run()                                                       # eager warm-up: allocates every workspace buffer
+        torch.cuda.synchronize(eng.device)
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=eng.device)
+        side.wait_stream(torch.cuda.current_stream(eng.device))
+        with torch.cuda.stream(side):
+            self._run()
+        torch.cuda.current_stream(eng.device).wait_stream(side)
+        with torch.cuda.graph(self.graph):
+            self.out = self._run()
+        assert self.out.shape == (T,)
+
+    def _run(self) -> torch.Tensor:
+        eng = self.eng
+        T = self.pix.shape[0]
+        G0 = self.pix.shape[-1] // eng.cfg.vision.patch_size
+        hw = min(eng.cfg.pooled_grid(T), G0)
+        feats, G, cmap, pc = eng.vit_forward(self.pix, hw)
+        return eng.score_video(feats, T, G, self.ids_host, cmap, pc, ids_dev=self.ids_dev)
+
+    def matches(self, input_ids: torch.Tensor, pix: torch.Tensor) -> bool:
+        ids = input_ids.reshape(-1).cpu()
+        return self.layout == (tuple((ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()), ids.numel(), tuple(pix.shape))
+
+    def __call__(self, input_ids: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
+        """-> logits fp32 [T] (a fresh tensor); the layout must be the captured one"""
+        if not self.matches(input_ids, pix):
+            raise ValueError("GraphedForward: frame count, resolution, prompt length and <image> position must equal the captured ones")
+        self.ids_dev.copy_(input_ids.reshape(-1).clamp(min=0), non_blocking=True)
+        self.pix.copy_(pix, non_blocking=True)
+        self.graph.replay()
+        return self.out.clone()
