@@ -279,7 +279,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
                     // Pieces of tile kt+1: spread over the first three R phases (LPT = 8: 3 + 3 + 2).  Front-loading them (all in the first
                     // R phase, 7 + 3 for the 10-piece tiles; flags bit9) wins 2-10 % on every shape when one GEMM is timed in a loop, but
                     // LOSES 1 % inside the real step (GEMM 1027 -> 1014 TF/s, alternating runs, both dtypes), so the spread stays.
-                    const bool front = g.flags & 512;
+                    const bool front = (g.flags & 512) || ((g.flags & 32768) && g.K >= 2048);       // bit15: front-load long-K shapes only (A/B)
 #pragma unroll
                     for (int j = 0; j < LPT; ++j)
                         if (front ? (LPT <= 8 ? pp == 0 : (j < 7 ? pp == 0 : pp == 1)) : (j / ((LPT + 2) / 3) == pp)) issue_one(kt + 1, j);
