@@ -101,3 +101,36 @@ def test_gpu_image_processor_front_end_matches_host_twin():
     host = SiglipImageProcessor(size=56).preprocess(fr, return_tensors="pt")["pixel_values"]
     dev = SiglipImageProcessor(size=56).preprocess(torch.from_numpy(fr).cuda(), return_tensors="pt")["pixel_values"]
     assert dev.is_cuda and torch.equal(dev.cpu(), host)
+
+
+# ---- property test: the restatement against Pillow itself on arbitrary sizes (Pillow is the third-party library the reference's
+# processor calls; it ships in this image, so beyond the committed vectors the oracle can be pinned on the fly) ----------------
+try:
+    from hypothesis import given, settings, strategies as st
+    from PIL import Image as _PILImage
+    _HAVE = True
+except Exception:                                       # pragma: no cover
+    _HAVE = False
+
+
+@pytest.mark.skipif(not _HAVE, reason="hypothesis / Pillow not importable")
+def test_oracle_resize_equals_pillow_on_random_sizes():
+    @settings(max_examples=40, deadline=None)
+    @given(h=st.integers(1, 97), w=st.integers(1, 97), oh=st.integers(1, 80), ow=st.integers(1, 80), seed=st.integers(0, 2 ** 16))
+    def prop(h, w, oh, ow, seed):
+        img = np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(_PILImage.fromarray(img).resize((ow, oh), resample=_PILImage.BICUBIC))
+        assert np.array_equal(PO.pil_bicubic_resize(img, oh, ow), ref)
+    prop()
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_equals_oracle_on_odd_sizes():
+    """sizes the fixtures do not hold: 1-pixel inputs, extreme down-scaling (long filter windows), widths whose rows are not 4-byte
+    aligned, output sides that are not multiples of 4 (byte-wise vertical pass)"""
+    from videoitg_amd import ops
+    for (T, H, W, S) in [(2, 1, 1, 8), (1, 5, 301, 9), (3, 211, 7, 33), (2, 64, 64, 30), (1, 17, 1000, 28), (2, 33, 35, 34)]:
+        fr = synth_video_frames(100 + H + W, T, H, W)
+        want = torch.from_numpy(PO.preprocess(fr, S))
+        got = ops.preprocess_u8(torch.from_numpy(fr).cuda(), S, torch.float32)
+        assert torch.equal(got.cpu(), want), (T, H, W, S)
