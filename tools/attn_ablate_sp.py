@@ -7,7 +7,7 @@ for name, B, H, HKV, S, D in [("vit448", 512, 16, 16, 1024, 72), ("llm", 1, 28, 
     ld = (H + 2 * HKV) * D
     qkv = torch.randn((B * S, ld), device="cuda").to(dt)
     o = torch.empty((B * S, H * D), dtype=dt, device="cuda")
-    for abl, label in [(0, "full"), (8, "no DMA in loop")]:
+    for abl, label in [(0, "full"), (8, "no DMA in loop"), (16, "V^T fragments not re-read"), (24, "neither")]:
         args = dict(batch=B, heads=H, kv_heads=HKV, seq=S, head_dim=D, q_strides=(S * ld, ld, D), k_strides=(S * ld, ld, D),
                     v_strides=(S * ld, ld, D), o_strides=(S * H * D, H * D, D), scale=D ** -0.5, variant=abl << 4)
         f = lambda: ops.attention(qkv, qkv[:, H * D:], qkv[:, (H + HKV) * D:], o, **args)

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
             fr[1] = frag(1);
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
-                if (i + 2 < NM) fr[(i + 2) % 3] = frag(i + 2);
+                if (i + 2 < NM && !((a.ablate & 16) && i + 2 > NQK)) fr[(i + 2) % 3] = frag(i + 2);      // (ablate bit4: profiling - V^T fragments not re-read)
                 mfma_step(i, fr[i % 3]);
                 if (i < 2) row_max(i);
                 else {
