@@ -50,7 +50,7 @@ int vitg_device_info(char* name, int name_len);
  *               9 256x384 (default for fp32-residual shapes) | 10 384x256 (default for SwiGLU)
  *   gemm_group  M-tiles per group of the XCD-aware tile order (default 4)
  *   gemm_flags  bit0 non-temporal stores, bit5 N-split launch, bit7 5-stage ring for cfg 8, bit8 disable cfg 9/10 auto-selection;
- *               bits 1-4, 6: profiling ablations (WRONG results)
+ *               bits 1-4, 6: profiling ablations (WRONG results; ignored unless the process set VITG_PROFILING=1)
  *   gemm_stagger  persistent kernel (cfg 4): de-phase the XCDs
  *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
  *   attn_ab     1 | 2  half-tile-out-of-phase hd-72 kernel on / off (default on)

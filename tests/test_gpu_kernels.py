@@ -264,3 +264,27 @@ def test_rank_stable_descending(ops, n):
     assert torch.equal(order.cpu().long(), torch.sort(got_scores, descending=True, stable=True).indices)
     if torch.equal(got_scores, s):
         assert torch.equal(order.cpu().long(), want)
+
+
+def test_profiling_ablations_are_inert_in_a_product_process(ops):
+    """The library carries profiling switches that skip work on purpose (wrong results).  Without VITG_PROFILING=1 in the
+    environment of the process they must do nothing (GEMM) or be refused (attention)."""
+    import os
+    from videoitg_amd._lib import VitgError
+    assert os.environ.get("VITG_PROFILING", "0") in ("", "0")
+    M, N, K = 512, 512, 256
+    a, w = rnd((M, K), 1).half(), (rnd((N, K), 2) * K ** -0.5).half()
+    want = a.float() @ w.float().t()
+    for flags in (2, 4, 8, 64):
+        ops.set_option("gemm_flags", flags)
+        try:
+            out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+            ops.gemm(a.cuda(), w.cuda(), out, mode=ops.GEMM_STORE16)
+        finally:
+            ops.set_option("gemm_flags", 0)
+        assert (out.float().cpu() - want).abs().max().item() < 0.05, flags
+    qkv = torch.randn((64, 3 * 128), device="cuda").half()
+    o = torch.empty((64, 128), dtype=torch.float16, device="cuda")
+    with pytest.raises(VitgError):
+        ops.attention(qkv, qkv[:, 128:], qkv[:, 256:], o, batch=1, heads=1, kv_heads=1, seq=64, head_dim=128, q_strides=(0, 384, 128),
+                      k_strides=(0, 384, 128), v_strides=(0, 384, 128), o_strides=(0, 128, 128), scale=128 ** -0.5, variant=8 << 4)

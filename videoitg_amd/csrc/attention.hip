@@ -475,8 +475,12 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    a.ablate = variant >> 4;
+    a.ablate = variant >> 4;             // profiling ablations (WRONG results): only in a process that set VITG_PROFILING=1
     variant &= 15;
+    if (a.ablate) {
+        static const bool profiling = [] { const char* e = getenv("VITG_PROFILING"); return e && atoi(e) != 0; }();
+        if (!profiling) return VITG_ERR_ARG;
+    }
     const bool tr = variant != 1;
     if (!tr) { }     // variant 1 = scalar LDS reads of V (cross-check path for the tr-read)
     // Defaults from same-call A/B (profiles/r01_attention.md): 8 waves / 256 queries per block when that still yields enough

@@ -208,7 +208,10 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
     g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4;
-    g.flags = tuning().gemm_flags;
+    // bits 1-4 and 6 of gemm_flags are profiling ablations that produce WRONG results; they only take effect in a process that
+    // opted in with VITG_PROFILING=1 (tools/ set it), so a stray option or environment variable cannot corrupt a product run
+    static const bool profiling = [] { const char* e = getenv("VITG_PROFILING"); return e && atoi(e) != 0; }();
+    g.flags = profiling ? tuning().gemm_flags : (tuning().gemm_flags & ~(2 | 4 | 8 | 16 | 64));
     hipStream_t s = (hipStream_t)stream;
     const int force = tuning().gemm_tile;          // 0 auto | 128 | 256 (vitg_set_option / VITG_GEMM_TILE)
     int rc;
