@@ -438,10 +438,12 @@ static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
     const size_t lds = 2 * (ATT_BK * C::LDK * 2 + ATT_BK * C::LDV * 2);
-    static bool done = false;
-    if (!done) {
+    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev != done_dev) {
         hipFuncSetAttribute((const void*)attn_kernel<T, D, TR, NW, ABL, PIPE, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
+        done_dev = cur_dev;
     }
     dim3 grid(ceil_div(a.S, NW * 32) * heads * batch);
     hipLaunchKernelGGL((attn_kernel<T, D, TR, NW, ABL, PIPE, DMA>), grid, dim3(NW * 64), lds, s, a);

@@ -453,8 +453,10 @@ extern "C" int vitg_rank(const float* logits, int n, float* scores, int* order, 
     if (n > 8192) return VITG_ERR_SHAPE;
     int p2 = 1;
     while (p2 < n) p2 <<= 1;
-    static bool done = false;
-    if (!done) { hipFuncSetAttribute((const void*)rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8); done = true; }
+    static int done_dev = -1;
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev != done_dev) { (void)hipFuncSetAttribute((const void*)rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8); done_dev = cur_dev; }
     hipLaunchKernelGGL(rank_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, (hipStream_t)stream, logits, n, p2, scores, order);
     return CHECK_LAUNCH();
 }

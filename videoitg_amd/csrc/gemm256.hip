@@ -632,14 +632,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256p_kernel(GemmArgs g) {
 template <typename T, int MODE>
 static int launch256p(GemmArgs g, hipStream_t s) {
     constexpr int lds = 2 * (G2_BM * 128 + 256 * 128);
-    static bool done = false;
+    static int done_dev = -1;
     static int cus = 256;
-    if (!done) {
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev != done_dev) {
         (void)hipFuncSetAttribute((const void*)gemm256p_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        int dev = 0;
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount & ~7;
-        done = true;
+        if (hipGetDeviceProperties(&p, cur_dev) == hipSuccess) cus = p.multiProcessorCount & ~7;
+        done_dev = cur_dev;
     }
     g.tiles_m = ceil_div(g.M, G2_BM);
     g.tiles_n = ceil_div(g.N, 256);
@@ -655,10 +656,12 @@ static int launch256p(GemmArgs g, hipStream_t s) {
 template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM>
 static int launch256(GemmArgs g, hipStream_t s) {
     constexpr int lds = STAGES * (BM * BK * 2 + BN * BK * 2);
-    static bool done = false;
-    if (!done) {
+    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev != done_dev) {
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        done = true;
+        done_dev = cur_dev;
     }
     g.tiles_m = ceil_div(g.M, BM);
     g.tiles_n = ceil_div(g.N, BN);

@@ -203,10 +203,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(GemmArgs g) {
 template <typename T, int MODE, int STAGES>
 static int launch_w4_tms(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = STAGES * (W4_BM + W4_BN) * W4_BK * 2;
-    static bool done = false;
-    if (!done) {
+    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev != done_dev) {
         (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<T, MODE, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        done = true;
+        done_dev = cur_dev;
     }
     hipLaunchKernelGGL((gemm_w4_kernel<T, MODE, STAGES>), dim3(g.tiles_m * g.tiles_n), dim3(W4_THREADS), LDS, s, g);
     return (int)hipGetLastError();
