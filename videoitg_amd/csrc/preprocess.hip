@@ -33,10 +33,12 @@ static double bicubic_w(double x) {
 
 // Pillow precompute_coeffs + normalize_coeffs_8bpc, uploaded once per (in, out) pair and kept for the life of the library
 static int get_table(int in_size, int out_size, ResampleTable& t) {
-    static std::map<std::pair<int, int>, ResampleTable> cache;
+    static std::map<std::pair<int, std::pair<int, int>>, ResampleTable> cache;      // keyed by (device, in, out): the tables live in that device's memory
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find({in_size, out_size});
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto it = cache.find({dev, {in_size, out_size}});
     if (it != cache.end()) { t = it->second; return 0; }
     const double scale = (double)in_size / out_size;
     const double filterscale = scale < 1.0 ? 1.0 : scale;
@@ -67,24 +69,29 @@ static int get_table(int in_size, int out_size, ResampleTable& t) {
     if (hipMalloc(&nt.kk, kk.size() * sizeof(int)) != hipSuccess) return VITG_ERR_LAUNCH;
     if (hipMemcpy(nt.bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return VITG_ERR_LAUNCH;
     if (hipMemcpy(nt.kk, kk.data(), kk.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return VITG_ERR_LAUNCH;
-    cache[{in_size, out_size}] = nt;
+    cache[{dev, {in_size, out_size}}] = nt;
     t = nt;
     return 0;
 }
 
 static const float* get_lut() {
-    static float* d_lut = nullptr;
+    static std::map<int, float*> luts;                     // one copy per device
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    if (d_lut) return d_lut;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto it = luts.find(dev);
+    if (it != luts.end()) return it->second;
     float h[256];
     const double factor = 1.0 / 255.0;                 // transformers rescale_factor = 1/255 (a Python float)
     for (int u = 0; u < 256; ++u) {
         const float x = (float)((double)u * factor);   // rescale: float64 product, then the cast
         h[u] = (x - 0.5f) / 0.5f;                       // normalize in float32
     }
+    float* d_lut = nullptr;
     if (hipMalloc(&d_lut, sizeof(h)) != hipSuccess) return nullptr;
     if (hipMemcpy(d_lut, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    luts[dev] = d_lut;
     return d_lut;
 }
 
