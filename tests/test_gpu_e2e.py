@@ -368,7 +368,8 @@ def test_infer_entry_point_runs_offline():
     out = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--model", "synthetic:tiny", "--video", "synthetic", "--topk", "8"],
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
-    sel = eval(out.stdout.strip().splitlines()[-1])
+    import ast
+    sel = ast.literal_eval(out.stdout.strip().splitlines()[-1])
     assert len(sel) == 8 and sel == sorted(sel) and len(set(sel)) == 8
 
 
