@@ -303,6 +303,27 @@ def main():
                                           "unit": "frames/s", "ms_per_step": round(d2 * 1e3, 2),
                                           "algorithmic_tflop_per_video": round(fl0["total"] / 1e12, 1)}
             del pix0
+            # the other 16-bit type on the same workload: bf16 is what BASELINE.json's configuration names, fp16 what the reference
+            # itself runs (model.half()); both go through the same kernels
+            other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
+            eng.release_workspace()
+            eng_o = SelectorEngine(packed_random_weights(cfg, other, dev, seed=args.seed))
+            pix_o = pix.to(other)
+
+            def step_o():
+                _, order_ = ops.rank(eng_o.forward(ids, None, [pix_o])[0].view(-1))
+                return order_.cpu().tolist()
+            step_o()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            step_o()
+            step_o()
+            torch.cuda.synchronize()
+            d3 = (time.perf_counter() - t3) / 2
+            out["secondary"]["fp16" if other == torch.float16 else "bf16"] = {"value": round(T / d3, 2), "unit": "frames/s",
+                                                                               "ms_per_step": round(d3 * 1e3, 2)}
+            eng_o.release_workspace()
+            del eng_o, pix_o
         if world == 1 and not args.no_cpu_baseline:
             eng.release_workspace()
             try:
