@@ -262,6 +262,13 @@ def main():
             "top32": sorted(order[:32]),
         }
         if world == 1 and not args.no_secondary:
+            # What the matrix pipe sustains on this box with NO memory traffic, on zero and on random operands: the shader clock under
+            # MFMA load is power managed and data dependent (probe.hip; profiles/r01_gemm_shapes.md section 13), so `peak` (nominal)
+            # is not reachable on real data by any kernel.  Reported for reading `frac`; `peak`/`frac` stay on the nominal figure.
+            out["roofline"]["mfma_only_probe"] = {
+                "zero_operands": round(ops.mfma_probe_tflops(dtype, False), 1),
+                "random_operands": round(ops.mfma_probe_tflops(dtype, True), 1), "unit": "TFLOP/s",
+                "what": "MFMA-only kernel, 8 waves/CU, no memory traffic; power-managed clock"}
             # SURVEY.md 8d "secondary": the same job starting from decoded uint8 NHWC frames resident in HBM (GPU
             # preprocessing front-end, row N2, in front of the selector forward).  Reported beside `value`, never as `value`.
             frames = torch.randint(0, 256, (T, 720, 1280, 3), dtype=torch.uint8, device=dev)

@@ -75,6 +75,24 @@ int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int 
               const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
               void* stream);
 
+/* Static-weight fast path of vitg_gemm.  Weights never change between forwards, so they can be stored a second time in the order
+ * the MFMA consumes them: vitg_pack_weight_fragments writes, for every (32-row weight tile, 16-deep k-step), one contiguous 1-KiB
+ * block whose 16-byte chunk l is W[tile*32 + (l & 31)][kstep*16 + 8*(l >> 5) .. +7] (rows >= N zero; N rounded up to 64).
+ * vitg_gemm_wf then fetches whole fragments with coalesced global loads and keeps the weight operand out of LDS
+ * (videoitg_amd/csrc/gemm_wf.hip).  Same contract, same results as vitg_gemm (same MFMA, same accumulation order); shapes the
+ * fast path does not cover (M or N < 256) run vitg_gemm on W.  Wf may be NULL (= vitg_gemm).  Same reference call sites as
+ * vitg_gemm: the weights are the nn.Linear parameters of [3P] modeling_siglip / modeling_qwen2 and mlp_proj.py:31-35. */
+int vitg_weight_fragments_bytes(int N, int K, long* bytes);
+int vitg_pack_weight_fragments(const void* W, int ldw, int N, int K, void* out, void* stream);
+int vitg_gemm_wf(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype, int mode,
+                 const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod, void* stream);
+
+/* Profiling aid (no reference counterpart, not on the product path): launches an MFMA-only kernel (blocks x 512 threads, 16
+ * v_mfma_f32_32x32x16 per wave and iteration) whose operands are the 8 fragments of `pool` (8 x 64 lanes x 16 bytes, caller
+ * filled: zeros, random, ...); *flops receives the flop count of the launch.  bench.py times it to report the MFMA rate the
+ * device sustains on zero and on random operands (power-managed clock; videoitg_amd/csrc/probe.hip).  out: blocks*512 floats. */
+int vitg_mfma_probe(const void* pool, int dtype, int blocks, int iters, float* out, double* flops, void* stream);
+
 /* out[m, 0..ldo) = LayerNorm(x[m, 0..D)) * w + b  (fp32 stats, eps inside rsqrt), columns D..ldo-1 zeroed.
  * out_dtype VITG_BF16/F16/F32.  Replaces [3P] SigLIP layer_norm1/2 (clip_encoder.py:146). */
 int vitg_layernorm(const float* x, int ldx, const float* w, const float* b, void* out, int ldo, int out_dtype,

@@ -288,3 +288,57 @@ def test_profiling_ablations_are_inert_in_a_product_process(ops):
     with pytest.raises(VitgError):
         ops.attention(qkv, qkv[:, 128:], qkv[:, 256:], o, batch=1, heads=1, kv_heads=1, seq=64, head_dim=128, q_strides=(0, 384, 128),
                       k_strides=(0, 384, 128), v_strides=(0, 384, 128), o_strides=(0, 128, 128), scale=128 ** -0.5, variant=8 << 4)
+
+
+# ---- static-weight fast path: fragment-packed weights (gemm_wf.hip) ---------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_weight_fragments_layout(ops, dtype):
+    """block (tile, kstep), chunk l = W[tile*32 + (l & 31)][kstep*16 + 8*(l >> 5) : +8]; rows past N are zero; N rounds up to 64"""
+    N, K = 200, 96
+    w = rnd((N, K), 21, dtype=dtype).to(dtype)
+    got = ops.pack_weight_fragments(w.cuda()).cpu()
+    np_ = 256                                                                   # ceil(200 / 64) * 64
+    wp = F.pad(w, (0, 0, 0, np_ - N))
+    want = wp.view(np_ // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+    assert got.numel() == want.numel() and torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(512, 512, 64), (512, 512, 128), (640, 320, 192), (777, 520, 256), (1024, 768, 1152), (300, 1152, 4352),
+                                   (2048, 3456, 1152), (200, 512, 128), (512, 200, 128)])
+def test_gemm_fragment_packed_weights_store16_bit_identical(ops, dtype, M, N, K):
+    """same MFMA, same accumulation order as the LDS kernel: identical bits (shapes the fast path does not cover fall back to it)"""
+    a, w, b = rnd((M, K), 1, dtype=dtype).to(dtype).cuda(), rnd((N, K), 2, K ** -0.5, dtype=dtype).to(dtype).cuda(), rnd((N,), 3, 0.1, torch.float32).cuda()
+    wf = ops.pack_weight_fragments(w)
+    ops.set_option("gemm_cfg", 6)                                               # the kernel with the same k-order and wave tile
+    try:
+        ref = ops.gemm(a, w, torch.empty((M, N), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=ops.ACT_GELU_TANH)
+    finally:
+        ops.set_option("gemm_cfg", 0)
+    got = ops.gemm(a, w, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=ops.ACT_GELU_TANH, wf=wf)
+    assert torch.equal(got, ref)
+    want = F.gelu(a.float() @ w.float().t() + b, approximate="tanh")
+    assert (got.float() - want).abs().max().item() <= EPS16[dtype] * want.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_fragment_packed_weights_f32_and_swiglu(ops, dtype):
+    M, N, K = 1000, 1152, 4352
+    a, w, b = rnd((M, K), 4, dtype=dtype).to(dtype).cuda(), rnd((N, K), 5, K ** -0.5, dtype=dtype).to(dtype).cuda(), rnd((N,), 6, 0.1, torch.float32).cuda()
+    x = rnd((M, N), 8, 1.0, torch.float32).cuda()
+    want = a.float() @ w.float().t() + b + x
+    out = x.clone()
+    ops.gemm(a, w, out, mode=ops.GEMM_F32, bias=b, res=out, wf=ops.pack_weight_fragments(w))
+    assert (out - want).abs().max().item() < 2e-4 * math.sqrt(K)
+    M, F2, K = 1300, 1024, 512
+    a, gu = rnd((M, K), 9, dtype=dtype).to(dtype).cuda(), rnd((2 * F2, K), 10, K ** -0.5, dtype=dtype).to(dtype).cuda()
+    ref = ops.gemm(a, gu, torch.empty((M, F2), dtype=dtype, device="cuda"), mode=ops.GEMM_SWIGLU)
+    got = ops.gemm(a, gu, torch.empty((M, F2), dtype=dtype, device="cuda"), mode=ops.GEMM_SWIGLU, wf=ops.pack_weight_fragments(gu))
+    assert (got.float() - ref.float()).abs().max().item() <= EPS16[dtype] * ref.float().abs().max().item()
+
+
+def test_mfma_probe_runs_and_zero_operands_are_not_slower(ops):
+    """profiling aid: the MFMA-only rate is data dependent on MI355X (power-managed clock); zeros must not be the slower case"""
+    z = ops.mfma_probe_tflops(torch.bfloat16, False, ms_target=20.0)
+    r = ops.mfma_probe_tflops(torch.bfloat16, True, ms_target=20.0)
+    assert 500.0 < r <= z * 1.05 and z < 2700.0, (z, r)

@@ -29,6 +29,10 @@ SHAPES = [  # name, M, N, K, mode
 for name, M, N, K, mode in SHAPES:
     a = (torch.rand((M, K), device="cuda") * 2 - 1).to(dt)
     w = ((torch.rand((N, K), device="cuda") * 2 - 1) * K ** -0.5).to(dt)
+    if "zeros" in sys.argv[1:]:       # data-dependent power: all-zero operands toggle no multiplier inputs
+        a.zero_(); w.zero_()
+    if "ones" in sys.argv[1:]:
+        a.fill_(1.0); w.fill_(1.0)
     if mode == ops.GEMM_F32:
         out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
         kw = dict(res=out)
@@ -38,6 +42,13 @@ for name, M, N, K, mode in SHAPES:
     else:
         out = torch.empty((M, N), dtype=dt, device="cuda")
         kw = dict(bias=torch.zeros(N, device="cuda"), act=ops.ACT_GELU_TANH if "fc1" in name else ops.ACT_NONE)
+    if "wf" in sys.argv[1:]:          # fragment-packed weights (gemm_wf.hip); first check against the LDS kernel
+        ref = ops.gemm(a, w, out.clone(), mode=mode, **({**kw, "res": torch.zeros_like(out)} if "res" in kw else kw))
+        kw["wf"] = ops.pack_weight_fragments(w)
+        got = ops.gemm(a, w, out.clone(), mode=mode, **({**kw, "res": torch.zeros_like(out)} if "res" in kw else kw))
+        d = (got.float() - ref.float()).abs().max().item()
+        print(f"  wf vs lds: max|diff| {d:.3e}  ref max {ref.float().abs().max().item():.3e}", flush=True)
+        del ref, got
     for _ in range(2):
         ops.gemm(a, w, out, mode=mode, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -26,6 +26,10 @@ SIGNATURES = {
     "vitg_set_option": [C.c_char_p, _i],
     "vitg_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "vitg_gemm": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
+    "vitg_gemm_wf": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
+    "vitg_weight_fragments_bytes": [_i, _i, C.POINTER(C.c_long)],
+    "vitg_pack_weight_fragments": [_p, _i, _i, _i, _p, _p],
+    "vitg_mfma_probe": [_p, _i, _i, _i, _p, C.POINTER(C.c_double), _p],
     "vitg_layernorm": [_p, _i, _p, _p, _p, _i, _i, _l, _i, _f, _p],
     "vitg_rmsnorm": [_p, _i, _p, _p, _i, _i, _l, _i, _f, _p],
     "vitg_rope": [_p, _i, _p, _p, _l, _i, _i, _i, _p],

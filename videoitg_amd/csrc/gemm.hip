@@ -193,9 +193,9 @@ static void set_attrs() {
 #undef SETA
 }
 
-extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype,
-                         int mode, const float* bias, int act, void* out, int ldo,
-                         const float* res, int ldr, int res_mod, void* stream) {
+static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype,
+                      int mode, const float* bias, int act, void* out, int ldo,
+                      const float* res, int ldr, int res_mod, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || K % BK != 0) return VITG_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8)) return VITG_ERR_ALIGN;
@@ -207,18 +207,31 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
-    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4;
+    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4; g.Wf = Wf;
     // bits 1-4 and 6 of gemm_flags are profiling ablations that produce WRONG results; they only take effect in a process that
     // opted in with VITG_PROFILING=1 (tools/ set it), so a stray option or environment variable cannot corrupt a product run
     static const bool profiling = [] { const char* e = getenv("VITG_PROFILING"); return e && atoi(e) != 0; }();
-    g.flags = profiling ? tuning().gemm_flags : (tuning().gemm_flags & ~(2 | 4 | 8 | 16 | 64));
+    g.flags = profiling ? tuning().gemm_flags : (tuning().gemm_flags & ~(2 | 4 | 8 | 16 | 64 | 0xF0000));
     hipStream_t s = (hipStream_t)stream;
     const int force = tuning().gemm_tile;          // 0 auto | 128 | 256 (vitg_set_option / VITG_GEMM_TILE)
     int rc;
     // Kernel choice by tile count (measured on the per-rank shapes of the context-parallel LLM, tools/gemm_small_m.py):
     // >= 160 tiles of 256x256 -> 256x256x64 ring-2 (1 block/CU); fewer -> 256x128x32 ring-3 at 2 blocks/CU (twice the tiles,
     // 512 slots) which beat both the 256x256 and the 128x128 kernel there; M < 256 / unaligned cases -> 128x128.
-    if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
+    if (Wf && force != 128 && gemm_wf_applicable(g, mode)) rc = launch_gemm_wf(g, dtype, mode, s);
+    else if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
     else rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+}
+
+extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype,
+                         int mode, const float* bias, int act, void* out, int ldo,
+                         const float* res, int ldr, int res_mod, void* stream) {
+    return gemm_entry(A, lda, W, ldw, nullptr, M, N, K, dtype, mode, bias, act, out, ldo, res, ldr, res_mod, stream);
+}
+
+extern "C" int vitg_gemm_wf(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype,
+                            int mode, const float* bias, int act, void* out, int ldo,
+                            const float* res, int ldr, int res_mod, void* stream) {
+    return gemm_entry(A, lda, W, ldw, Wf, M, N, K, dtype, mode, bias, act, out, ldo, res, ldr, res_mod, stream);
 }

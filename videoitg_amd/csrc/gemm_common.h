@@ -17,6 +17,7 @@ struct GemmArgs {
     int group_m;              // gemm256: M-tiles per group of the XCD-aware tile order
     int stagger_ns;           // persistent kernel: tile period estimate for de-phasing the XCDs (0 = off)
     int flags;                // bit0: non-temporal output stores, bit1: (profiling) skip output stores
+    const void* Wf;           // fragment-packed copy of W (vitg_pack_weight_fragments) or null
 };
 
 enum { MODE_STORE16 = 0, MODE_F32 = 1, MODE_SWIGLU = 2 };
@@ -189,5 +190,7 @@ int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s);   // 
 bool gemm256_applicable(const GemmArgs& g, int mode);
 int launch_gemm_w4(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_w4.hip
 bool gemm_w4_applicable(const GemmArgs& g, int mode);
+int launch_gemm_wf(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_wf.hip
+bool gemm_wf_applicable(const GemmArgs& g, int mode);
 
 }  // namespace vitg

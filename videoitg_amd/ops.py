@@ -64,9 +64,9 @@ def patchify(pix: torch.Tensor, patch: int, kpad: int, dtype: torch.dtype) -> to
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: Optional[int] = None,
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
-         res_mod: int = 0, m: Optional[int] = None) -> torch.Tensor:
+         res_mod: int = 0, m: Optional[int] = None, wf: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epilogue(a[:m] @ w[:n].T).  a [M,K] and w [N,K] 16-bit 2-D (row stride may exceed K),
-    out 2-D (16-bit for STORE16/SWIGLU, fp32 for F32)."""
+    out 2-D (16-bit for STORE16/SWIGLU, fp32 for F32).  wf: pack_weight_fragments(w[:n]) or None."""
     _req(a)
     _req(w, a.dtype)
     M = a.shape[0] if m is None else m
@@ -81,9 +81,50 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: O
         _req(bias, torch.float32)
     if res is not None:
         _req(res, torch.float32)
+    if wf is not None:
+        _lib.call("vitg_gemm_wf", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(wf), M, N, K, dt_code(a.dtype), mode, _ptr(bias),
+                  act, _ptr(out), out.stride(0), _ptr(res), 0 if res is None else res.stride(0), res_mod, _stream())
+        return out
     _lib.call("vitg_gemm", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, N, K, dt_code(a.dtype), mode, _ptr(bias), act,
               _ptr(out), out.stride(0), _ptr(res), 0 if res is None else res.stride(0), res_mod, _stream())
     return out
+
+
+def pack_weight_fragments(w: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+    """MFMA-fragment-ordered copy of w[:n] [N,K] for gemm(..., wf=...) (vitg_pack_weight_fragments)"""
+    import ctypes
+    _req(w)
+    N = w.shape[0] if n is None else n
+    K = w.shape[1]
+    nb = ctypes.c_long(0)
+    _lib.call("vitg_weight_fragments_bytes", N, K, ctypes.byref(nb))
+    out = torch.empty(nb.value // 2, dtype=w.dtype, device=w.device)
+    _lib.call("vitg_pack_weight_fragments", _ptr(w), w.stride(0), N, K, _ptr(out), _stream())
+    return out
+
+
+def mfma_probe_tflops(dtype: torch.dtype, random_operands: bool, ms_target: float = 60.0) -> float:
+    """MFMA-only rate the device sustains (profiling aid, vitg_mfma_probe): zeros vs random operands differ because the shader
+    clock under MFMA load is power managed.  Runs for ~3 x ms_target; returns the last measurement in TFLOP/s."""
+    import ctypes
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pool = torch.zeros(8 * 64 * 8, dtype=dtype, device=dev)
+    if random_operands:
+        pool = (torch.rand(pool.shape, device=dev) * 2 - 1).to(dtype)
+    blocks = torch.cuda.get_device_properties(dev).multi_processor_count
+    out = torch.empty(blocks * 512, dtype=torch.float32, device=dev)
+    fl = ctypes.c_double(0.0)
+    iters, tf = 2000, 0.0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call("vitg_mfma_probe", _ptr(pool), dt_code(dtype), blocks, iters, _ptr(out), ctypes.byref(fl), _stream())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        tf = fl.value / ms / 1e9
+        iters = max(1000, int(iters * ms_target / max(ms, 1e-3)))
+    return tf
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, d: int, eps: float) -> torch.Tensor:
