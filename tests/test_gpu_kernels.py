@@ -275,7 +275,7 @@ def test_profiling_ablations_are_inert_in_a_product_process(ops):
     M, N, K = 512, 512, 256
     a, w = rnd((M, K), 1).half(), (rnd((N, K), 2) * K ** -0.5).half()
     want = a.float() @ w.float().t()
-    for flags in (2, 4, 8, 64):
+    for flags in (2, 4, 8, 64, 0x10000, 0x20000, 0x40000):
         ops.set_option("gemm_flags", flags)
         try:
             out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")

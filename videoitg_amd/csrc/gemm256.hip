@@ -415,7 +415,10 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
         __builtin_amdgcn_s_barrier();                    // every wave is done reading the ring before it is reused
         constexpr int STAGE_BYTES = MT * 32 * (MODE == MODE_SWIGLU ? 1 : NT) * 64;
         if constexpr (8 * STAGE_BYTES <= STAGES * STAGE) {
-            epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+            // flags bit18 (profiling, wrong results): every tile stores over tile (0,0) - same store instructions, but the output
+            // stays in L2 (no HBM write-back stream, no eviction of operand panels): separates issue cost from memory-side cost
+            const int m0e = (g.flags & 0x40000) ? 0 : m0, n0e = (g.flags & 0x40000) ? 0 : n0;
+            epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0e + wr * (MT * 32), n0e + wc * (NT * 32), lane);
         } else {
             // 256x384 tile: the wave's 128x96 outputs are staged in two 64-row halves (the same wave writes and reads its
             // private region, in order, so the second half may reuse it)
