@@ -21,13 +21,13 @@ def ops():
     return o
 
 
-@pytest.fixture(params=["auto", "tile128", "cfg1_256x256x32", "cfg2_256x128x32", "cfg3_256x256x64", "cfg4_persistent", "cfg5_asm_reads", "cfg6_phased", "cfg7_phased2", "cfg8_w4_128x128", "cfg9_256x384", "cfg10_384x256", "cfg11_regstaged"])
+@pytest.fixture(params=["auto", "tile128", "cfg1_256x256x32", "cfg2_256x128x32", "cfg3_256x256x64", "cfg4_persistent", "cfg5_asm_reads", "cfg6_phased", "cfg7_phased2", "cfg8_w4_128x128", "cfg9_256x384", "cfg10_384x256", "cfg11_regstaged", "cfg13_persistent_deferred"])
 def gemm_cfg(request, ops):
     """Every GEMM kernel configuration is forced in turn (vitg_set_option), so the 256-tile kernels are covered at test
     sizes too (auto mode would pick the 128 tile for them)."""
     name = request.param
     tile, cfg = {"auto": (0, 0), "tile128": (128, 0), "cfg1_256x256x32": (256, 1), "cfg2_256x128x32": (256, 2),
-                 "cfg3_256x256x64": (256, 3), "cfg4_persistent": (256, 4), "cfg5_asm_reads": (256, 5), "cfg6_phased": (256, 6), "cfg7_phased2": (256, 7), "cfg8_w4_128x128": (256, 8), "cfg9_256x384": (256, 9), "cfg10_384x256": (256, 10), "cfg11_regstaged": (256, 11)}[name]
+                 "cfg3_256x256x64": (256, 3), "cfg4_persistent": (256, 4), "cfg5_asm_reads": (256, 5), "cfg6_phased": (256, 6), "cfg7_phased2": (256, 7), "cfg8_w4_128x128": (256, 8), "cfg9_256x384": (256, 9), "cfg10_384x256": (256, 10), "cfg11_regstaged": (256, 11), "cfg13_persistent_deferred": (256, 13)}[name]
     ops.set_option("gemm_tile", tile)
     ops.set_option("gemm_cfg", cfg)
     yield name
@@ -342,3 +342,21 @@ def test_mfma_probe_runs_and_zero_operands_are_not_slower(ops):
     z = ops.mfma_probe_tflops(torch.bfloat16, False, ms_target=20.0)
     r = ops.mfma_probe_tflops(torch.bfloat16, True, ms_target=20.0)
     assert 500.0 < r <= z * 1.05 and z < 2700.0, (z, r)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(512, 512, 768), (4096, 1024, 1152), (70000, 3456, 1152), (12860, 4608, 3584), (5000, 520, 832), (300, 264, 768)])
+def test_gemm_persistent_deferred_epilogue_bit_identical(ops, dtype, M, N, K):
+    """cfg 13: one block per CU walks many tiles and stores tile i underneath the main loop of tile i+1 - same bits as cfg 6"""
+    a, w, b = rnd((M, K), 31, dtype=dtype).to(dtype).cuda(), rnd((N, K), 32, K ** -0.5, dtype=dtype).to(dtype).cuda(), rnd((N,), 33, 0.1, torch.float32).cuda()
+    outs = {}
+    for cfg in (6, 13):
+        ops.set_option("gemm_cfg", cfg)
+        try:
+            outs[cfg] = [ops.gemm(a, w, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=act)
+                         for act in (ops.ACT_NONE, ops.ACT_GELU_TANH, ops.ACT_GELU_ERF)]
+        finally:
+            ops.set_option("gemm_cfg", 0)
+    for got, ref in zip(outs[13], outs[6]):
+        assert torch.isfinite(got.float()).all()
+        assert torch.equal(got, ref)

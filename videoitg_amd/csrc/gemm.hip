@@ -219,6 +219,12 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     // >= 160 tiles of 256x256 -> 256x256x64 ring-2 (1 block/CU); fewer -> 256x128x32 ring-3 at 2 blocks/CU (twice the tiles,
     // 512 slots) which beat both the 256x256 and the 128x128 kernel there; M < 256 / unaligned cases -> 128x128.
     if (Wf && force != 128 && gemm_wf_applicable(g, mode)) rc = launch_gemm_wf(g, dtype, mode, s);
+    // 16-bit-output GEMMs with at least two 256x256 tiles per CU: the persistent kernel with the deferred epilogue (gemm_pe.hip; cfg 13
+    // forces it, gemm_flags bit20 keeps auto mode off it for A/B runs).  Same bits as the other 256-tile kernels.
+    else if ((tuning().gemm_cfg == 13 ||
+              (tuning().gemm_cfg == 0 && !(tuning().gemm_flags & 0x100000) && ceil_div(M, 256) * ceil_div(N, 256) >= 512)) &&
+             force != 128 && gemm_pe_applicable(g, mode))
+        rc = launch_gemm_pe(g, dtype, s);
     else if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
     else rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
