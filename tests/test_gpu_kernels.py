@@ -360,3 +360,17 @@ def test_gemm_persistent_deferred_epilogue_bit_identical(ops, dtype, M, N, K):
     for got, ref in zip(outs[13], outs[6]):
         assert torch.isfinite(got.float()).all()
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,F2,K", [(1300, 1024, 768), (12860, 2048, 3584), (600, 320, 832)])
+def test_gemm_persistent_deferred_epilogue_swiglu_bit_identical(ops, dtype, M, F2, K):
+    a, gu = rnd((M, K), 41, dtype=dtype).to(dtype).cuda(), rnd((2 * F2, K), 42, K ** -0.5, dtype=dtype).to(dtype).cuda()
+    outs = {}
+    for cfg in (6, 13):
+        ops.set_option("gemm_cfg", cfg)
+        try:
+            outs[cfg] = ops.gemm(a, gu, torch.full((M, F2), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_SWIGLU)
+        finally:
+            ops.set_option("gemm_cfg", 0)
+    assert torch.isfinite(outs[13].float()).all() and torch.equal(outs[13], outs[6])

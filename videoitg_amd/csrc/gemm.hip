@@ -220,11 +220,13 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     // 512 slots) which beat both the 256x256 and the 128x128 kernel there; M < 256 / unaligned cases -> 128x128.
     if (Wf && force != 128 && gemm_wf_applicable(g, mode)) rc = launch_gemm_wf(g, dtype, mode, s);
     // 16-bit-output GEMMs with at least two 256x256 tiles per CU: the persistent kernel with the deferred epilogue (gemm_pe.hip; cfg 13
-    // forces it, gemm_flags bit20 keeps auto mode off it for A/B runs).  Same bits as the other 256-tile kernels.
+    // forces it, gemm_flags bit20 keeps auto mode off it for A/B runs).  Same bits as the other 256-tile kernels.  In-step A/B
+    // (alternating bench.py runs): qkv + fc1 + llm qkv 671 -> 690 frames/s; SwiGLU gate/up on it 690 -> 686 (the 384x256 tile of
+    // cfg 10 is worth more there), so SwiGLU only with gemm_flags bit21; erf-GELU (projector, spills in erff) only when forced.
     else if ((tuning().gemm_cfg == 13 ||
-              (tuning().gemm_cfg == 0 && !(tuning().gemm_flags & 0x100000) && ceil_div(M, 256) * ceil_div(N, 256) >= 512)) &&
+              (tuning().gemm_cfg == 0 && !(tuning().gemm_flags & 0x100000) && act != VITG_ACT_GELU_ERF && (mode != VITG_GEMM_SWIGLU || (tuning().gemm_flags & 0x200000)) && ceil_div(M, 256) * ceil_div(N, 256) >= 512)) &&
              force != 128 && gemm_pe_applicable(g, mode))
-        rc = launch_gemm_pe(g, dtype, s);
+        rc = launch_gemm_pe(g, dtype, mode, s);
     else if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
     else rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;

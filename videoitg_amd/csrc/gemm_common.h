@@ -192,7 +192,7 @@ int launch_gemm_w4(const GemmArgs& g, int dtype, int mode, hipStream_t s);      
 bool gemm_w4_applicable(const GemmArgs& g, int mode);
 int launch_gemm_wf(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_wf.hip
 bool gemm_wf_applicable(const GemmArgs& g, int mode);
-int launch_gemm_pe(const GemmArgs& g, int dtype, hipStream_t s);                // gemm_pe.hip
+int launch_gemm_pe(const GemmArgs& g, int dtype, int mode, hipStream_t s);               // gemm_pe.hip
 bool gemm_pe_applicable(const GemmArgs& g, int mode);
 
 }  // namespace vitg

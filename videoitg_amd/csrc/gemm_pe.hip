@@ -20,6 +20,7 @@
 namespace vitg {
 
 constexpr int PE_THREADS = 512, PE_BM = 256, PE_BN = 256, PE_BK = 64, PE_UNROLL_KT = 12;
+constexpr int PE_ACT_SWIGLU = 100;                    // ACT value: SwiGLU mode (silu(gate) * up on the [32 gate | 32 up] row interleave, no bias)
 
 template <typename T, int ACT>
 __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
@@ -27,6 +28,8 @@ __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
     typedef typename T16<T>::vec4 vec4;
     constexpr int MT = 4, NT = 2, KS = 4, ROWB = 128, CPR = 8, RPI = 8;
     constexpr int A_BYTES = PE_BM * ROWB, STAGE = 2 * A_BYTES, PIECES = 4;        // 4 A + 4 W DMA pieces per wave per K-tile
+    constexpr bool SW = ACT == PE_ACT_SWIGLU;
+    constexpr int NTO = SW ? 1 : NT, CH = NTO * 4, RB = NTO * 64;                 // output 32-column tiles per wave, 16-B chunks / bytes per staged row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,11 +88,11 @@ __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     vec8 fa[MT], fw[NT];
-    u32x2 pk[MT - 1][NT][4];                             // row-tiles 1..3 of the previous tile, packed 16-bit (row-tile 0 goes straight to LDS)
+    u32x2 pk[MT - 1][NTO][4];                            // row-tiles 1..3 of the previous tile, packed 16-bit (row-tile 0 goes straight to LDS)
 #pragma unroll
     for (int i = 0; i < MT - 1; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTO; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) pk[i][j][q] = u32x2{0u, 0u};
 
@@ -106,19 +109,20 @@ __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- trickle steps (wave-private LDS window: LDS operations of one wave execute in order, no barrier needed) -----------------
-    auto stage_write = [&](const u32x2 (&p)[NT][4]) {    // one 32-row tile of packed outputs -> staging, 16-B chunks XOR-swizzled by row
+    auto stage_write = [&](const u32x2 (&p)[NTO][4]) {   // one 32-row tile of packed outputs -> staging, 16-B chunks XOR-swizzled by row
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NTO; ++nt)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) *(u32x2*)(stg + frow * 128 + (((nt * 4 + q4) ^ (frow & 7)) << 4) + fh * 8) = p[nt][q4];
+            for (int q4 = 0; q4 < 4; ++q4) *(u32x2*)(stg + frow * RB + (((nt * 4 + q4) ^ (frow & (CH - 1))) << 4) + fh * 8) = p[nt][q4];
     };
-    auto stage_store = [&](int mt) {                     // staging -> global, full 128-B rows
+    const int n_lim = SW ? g.N / 2 : g.N;
+    auto stage_store = [&](int mt) {                     // staging -> global, full rows of the wave's output (128 B, SwiGLU 64 B)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = i * 64 + lane, row = idx >> 3, c = idx & 7;
-            const u32x4 v = *(const u32x4*)(stg + row * 128 + ((c ^ (row & 7)) << 4));
+        for (int i = 0; i < 32 * CH / 64; ++i) {
+            const int idx = i * 64 + lane, row = idx / CH, c = idx % CH;
+            const u32x4 v = *(const u32x4*)(stg + row * RB + ((c ^ (row & (CH - 1))) << 4));
             const int m = pm_base + mt * 32 + row, n = pn_base + c * 8;
-            if (m < pM && n < g.N) *(u32x4*)((T*)g.out + (size_t)m * g.ldo + n) = v;
+            if (m < pM && n < n_lim) *(u32x4*)((T*)g.out + (size_t)m * g.ldo + n) = v;
         }
     };
 
@@ -185,24 +189,30 @@ __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int n = cn0 + wc * 64 + nt * 32 + q4 * 8 + fh * 4;
-                bq[nt][q4] = (g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bq[nt][q4] = (!SW && g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         for (int kt = PE_UNROLL_KT; kt < nk; ++kt) ktile(std::integral_constant<int, -1>{}, kt);
 
         // ---- tile boundary: bias, round, pack; row-tile 0 straight into the staging window; accumulators back to zero --------------
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            u32x2 p[NT][4];
+            u32x2 p[NTO][4];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NTO; ++nt)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     vec4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[nt][mt][q4 * 4 + e] + bq[nt][q4][e];
-                        if (ACT == VITG_ACT_GELU_TANH) v = gelu_tanh_f(v);
-                        else if (ACT == VITG_ACT_GELU_ERF) v = gelu_erf_f(v);
+                        float v;
+                        if constexpr (SW) {
+                            v = silu_f(acc[0][mt][q4 * 4 + e]) * acc[1][mt][q4 * 4 + e];
+                            acc[1][mt][q4 * 4 + e] = 0.f;
+                        } else {
+                            v = acc[nt][mt][q4 * 4 + e] + bq[nt][q4][e];
+                            if (ACT == VITG_ACT_GELU_TANH) v = gelu_tanh_f(v);
+                            else if (ACT == VITG_ACT_GELU_ERF) v = gelu_erf_f(v);
+                        }
                         o[e] = T16<T>::from_f32(v);
                         acc[nt][mt][q4 * 4 + e] = 0.f;
                     }
@@ -211,13 +221,13 @@ __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
             if (mt == 0) stage_write(p);
             else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NTO; ++nt)
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) pk[mt - 1][nt][q4] = p[nt][q4];
             }
         }
         pm_base = cm0 + wr * 128;
-        pn_base = cn0 + wc * 64;
+        pn_base = SW ? (cn0 + wc * 64) / 2 : cn0 + wc * 64;
         pM = g.M;
         cm0 = nm0;
         cn0 = nn0;
@@ -234,7 +244,8 @@ __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
 }
 
 bool gemm_pe_applicable(const GemmArgs& g, int mode) {
-    if (mode != MODE_STORE16) return false;
+    if (mode != MODE_STORE16 && mode != MODE_SWIGLU) return false;
+    if (mode == MODE_SWIGLU && g.N % 64) return false;
     if (g.K % PE_BK || g.K / PE_BK < PE_UNROLL_KT) return false;
     if (g.M < 256 || g.N < 256 || g.lda % 8 || g.ldw % 8 || g.ldo % 8 || g.N % 8) return false;
     return true;
@@ -256,13 +267,13 @@ static int launch_pe_t(const GemmArgs& g, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-int launch_gemm_pe(const GemmArgs& g_in, int dtype, hipStream_t s) {
+int launch_gemm_pe(const GemmArgs& g_in, int dtype, int mode, hipStream_t s) {
     GemmArgs g = g_in;
     g.tiles_m = ceil_div(g.M, PE_BM);
     g.tiles_n = ceil_div(g.N, PE_BN);
     g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
 #define PE_GO(T)                                                                                         \
-    (g.act == VITG_ACT_GELU_TANH ? launch_pe_t<T, VITG_ACT_GELU_TANH>(g, s)                              \
+    (mode == MODE_SWIGLU ? launch_pe_t<T, PE_ACT_SWIGLU>(g, s) : g.act == VITG_ACT_GELU_TANH ? launch_pe_t<T, VITG_ACT_GELU_TANH>(g, s)                              \
                                  : g.act == VITG_ACT_GELU_ERF ? launch_pe_t<T, VITG_ACT_GELU_ERF>(g, s) : launch_pe_t<T, VITG_ACT_NONE>(g, s))
     return dtype == DT_BF16 ? PE_GO(bf16_t) : PE_GO(f16_t);
 #undef PE_GO
