@@ -374,3 +374,28 @@ def test_gemm_persistent_deferred_epilogue_swiglu_bit_identical(ops, dtype, M, F
         finally:
             ops.set_option("gemm_cfg", 0)
     assert torch.isfinite(outs[13].float()).all() and torch.equal(outs[13], outs[6])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [6, 9, 10])
+def test_gemm_software_tile_loop_bit_identical(ops, dtype, cfg):
+    """gemm_flags bit24: one block per CU walks the tile list instead of one hardware block per tile - same bits, all three epilogues"""
+    M, N, K = 40000, 1152, 640                                                  # 157 x 5 (x 3 for the 384-wide tile) >= 2 tiles per CU
+    a, w, b = rnd((M, K), 51, dtype=dtype).to(dtype).cuda(), rnd((N, K), 52, K ** -0.5, dtype=dtype).to(dtype).cuda(), rnd((N,), 53, 0.1, torch.float32).cuda()
+    x = rnd((M, N), 54, 1.0, torch.float32).cuda()
+    gu = rnd((2 * N, K), 55, K ** -0.5, dtype=dtype).to(dtype).cuda()
+    res = {}
+    for flags in (0, 1 << 24):
+        ops.set_option("gemm_cfg", cfg)
+        ops.set_option("gemm_flags", flags)
+        try:
+            o16 = ops.gemm(a, w, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=ops.ACT_GELU_TANH)
+            o32 = x.clone()
+            ops.gemm(a, w, o32, mode=ops.GEMM_F32, bias=b, res=o32)
+            osw = ops.gemm(a, gu, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_SWIGLU)
+            res[flags] = (o16, o32, osw)
+        finally:
+            ops.set_option("gemm_cfg", 0)
+            ops.set_option("gemm_flags", 0)
+    for got, ref in zip(res[1 << 24], res[0]):
+        assert torch.isfinite(got.float()).all() and torch.equal(got, ref)

@@ -27,9 +27,14 @@ constexpr int G2_BM = 256, G2_THREADS = 512;
 //   <BN=256, WM=2, STAGES=4>: wave tile 128x64, 128 KiB LDS, 1 block/CU  - best steady state (large K)
 //   <BN=128, WM=4, STAGES=3>: wave tile  64x64,  72 KiB LDS, 2 blocks/CU - one block's prologue/epilogue overlaps the
 //                                                                          other's main loop (small K, heavy epilogues)
+#ifndef VITG_PROFILING_BUILD
+#define VITG_PROFILING_BUILD 0     // build.sh -DVITG_PROFILING_BUILD=1 compiles the ablation switches (gemm_flags bits 1-4, 6, 9, 15, 18) into the
+#endif                             // main loop; in the product build they are compiled out: every test of g.flags in an interval is a scalar
+                                   // branch, and eight of them per read interval cost the phased loop 5-10 % (profiles/r01_gemm_shapes.md section 16)
 template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM>
 __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g) {
     typedef typename T16<T>::vec8 vec8;
+    constexpr bool PROF = VITG_PROFILING_BUILD != 0;
     constexpr int WN = 8 / WM;
     constexpr int MT = BM / WM / 32;                  // 32-row activation tiles per wave
     constexpr int NT = BN / WN / 32;                     // 32-wide weight tiles per wave
@@ -43,12 +48,21 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     constexpr int A_INSTR = A_BYTES / 1024 / 8;          // DMA instructions per wave per K-tile
     constexpr int W_INSTR = W_BYTES / 1024 / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    // Tile loop.  Launched with one block per tile this runs once; launched with one block per CU (launch256: "software relaunch",
+    // gemm_flags bit24 / auto for long tile lists) the block walks every gridDim.x-th tile of the same XCD-aware order and
+    // simply starts over - sources, accumulators, first DMA - where the hardware would have launched a fresh block.  Measured on
+    // the persistent kernel of gemm_pe.hip: this alone is worth +8-11 % on long-K shapes (profiles/r01_gemm_shapes.md section 15).
+    const int nwg_ = g.tiles_m * g.tiles_n;
+    for (int vb = blockIdx.x; vb < nwg_; vb += gridDim.x) {
+    // per-lane quantities are re-derived from an opaque copy of the thread id in every pass: hoisted out of the loop they would all
+    // stay live through the main loop (72-90 spilled registers on the wide tiles)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
-
     int tm, tn;
-    block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    block_to_tile(vb, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA assignment: one instruction = RPI rows x ROWB bytes; lane -> (row = lane / CPR, LDS chunk slot = lane % CPR)
@@ -56,30 +70,31 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     // ds_read_b128 lane groups with the 32x32x16 fragment pattern.
     auto swz = [](int row) { return BK == 32 ? ((row >> 3) & 3) : ((row >> 1) & 7); };
     const int drow = lane / CPR, dslot = lane % CPR;
-    const char* a_src[A_INSTR];
-    const char* w_src[W_INSTR];
+    // source = wave-uniform tile base (SGPR pair) + per-lane 32-bit byte offset: the DMA takes the saddr + voffset form and the
+    // K-tile advance is one scalar add (per-lane 64-bit pointers cost two v_lshl_add_u64 per piece in every read interval)
+    const char* const a_base = (const char*)g.A + (size_t)m0 * g.lda * 2;
+    const char* const w_base = (const char*)g.W + (size_t)n0 * g.ldw * 2;
+    unsigned a_cur[A_INSTR], w_cur[W_INSTR];
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-        const int R = (wave * A_INSTR + j) * RPI + drow;                // row within the 256-row activation tile
-        const int am = min(m0 + R, g.M - 1);
-        a_src[j] = (const char*)g.A + ((size_t)am * g.lda + ((dslot ^ swz(R)) << 3)) * 2;
+        const int R = (wave * A_INSTR + j) * RPI + drow;                // row within the activation tile
+        a_cur[j] = ((unsigned)(min(R, g.M - 1 - m0) * g.lda) + (unsigned)((dslot ^ swz(R)) << 3)) * 2u;
     }
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j) {
         const int R = (wave * W_INSTR + j) * RPI + drow;
-        const int wn = min(n0 + R, g.N - 1);
-        w_src[j] = (const char*)g.W + ((size_t)wn * g.ldw + ((dslot ^ swz(R)) << 3)) * 2;
+        w_cur[j] = ((unsigned)(min(R, g.N - 1 - n0) * g.ldw) + (unsigned)((dslot ^ swz(R)) << 3)) * 2u;
     }
     constexpr int LPT = A_INSTR + W_INSTR;               // DMA instructions per thread per K-tile
     auto issue_one = [&](int kt, int j) {                // j-th DMA instruction of K-tile kt (j compile-time after unroll)
-        if (kt > 0 && (g.flags & 64)) return;            // profiling only (wrong results): operand stream off after the first K-tile
+        if (PROF && kt > 0 && (g.flags & 64)) return;            // profiling only (wrong results): operand stream off after the first K-tile
         char* st = smem + (kt % STAGES) * STAGE;
         const size_t koff = (size_t)kt * ROWB;
         if (j < A_INSTR)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + koff + a_cur[j]),
                                              (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j - A_INSTR] + koff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + koff + w_cur[j - A_INSTR]),
                                              (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * W_INSTR + j - A_INSTR) * 1024), 16, 0, 0);
     };
     auto issue = [&](int kt) {
@@ -94,7 +109,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     u32x4 stg[PH == 3 ? 2 : 1][PH == 3 ? LPT : 1];
     auto load_one = [&](int kt, int j, u32x4 (&set)[PH == 3 ? LPT : 1]) {
         const size_t koff = (size_t)kt * ROWB;
-        set[j] = *(const u32x4*)((j < A_INSTR ? a_src[j] : w_src[j - A_INSTR]) + koff);
+        set[j] = *(const u32x4*)(j < A_INSTR ? a_base + koff + a_cur[j] : w_base + koff + w_cur[j - A_INSTR]);
     };
     auto store_one = [&](int kt, int j, const u32x4 (&set)[PH == 3 ? LPT : 1]) {
         char* st = smem + (kt % STAGES) * STAGE;
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     // the ds_read_b128 of the next k-step are in flight (LDS latency off the MFMA critical path).
     vec8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
     auto wait_tile = [&](int kt) {                       // this wave's DMA of tile kt has landed
-        if (g.flags & 4) return;                         // profiling only: results are wrong, shows the DMA-wait share
+        if (PROF && (g.flags & 4)) return;                         // profiling only: results are wrong, shows the DMA-wait share
         const int newer = min(nk - 1 - kt, DIST - 1);    // tiles issued after kt that may still be in flight
         if (DIST > 2 && newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
         else if (DIST > 1 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
@@ -269,6 +284,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
             if (kt + 1 < nk) tile(kt + 1, std::integral_constant<int, 1>{});
         }
         } else if constexpr (PH == 1) {
+#pragma unroll 1
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
 #pragma unroll
@@ -279,19 +295,19 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
                     // Pieces of tile kt+1: spread over the first three R phases (LPT = 8: 3 + 3 + 2).  Front-loading them (all in the first
                     // R phase, 7 + 3 for the 10-piece tiles; flags bit9) wins 2-10 % on every shape when one GEMM is timed in a loop, but
                     // LOSES 1 % inside the real step (GEMM 1027 -> 1014 TF/s, alternating runs, both dtypes), so the spread stays.
-                    const bool front = (g.flags & 512) || ((g.flags & 32768) && g.K >= 2048);       // bit15: front-load long-K shapes only (A/B)
+                    const bool front = PROF && ((g.flags & 512) || ((g.flags & 32768) && g.K >= 2048));       // bit15: front-load long-K shapes only (A/B)
 #pragma unroll
                     for (int j = 0; j < LPT; ++j)
                         if (front ? (LPT <= 8 ? pp == 0 : (j < 7 ? pp == 0 : pp == 1)) : (j / ((LPT + 2) / 3) == pp)) issue_one(kt + 1, j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (pp == KS - 1 && more && grpB && !(g.flags & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (flags bit2: profiling, wrong results)
+                if (pp == KS - 1 && more && grpB && !(PROF && (g.flags & 4))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (flags bit2: profiling, wrong results)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 G2_MMA(fa0, fw0)
                 __builtin_amdgcn_sched_barrier(0);
-                if (pp == KS - 1 && more && !grpB && !(g.flags & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (pp == KS - 1 && more && !grpB && !(PROF && (g.flags & 4))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
                 wait_tile(kt + 1);
                 // every ds_read of stage kt (incl. F1 above) must have completed before another wave may overwrite it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!(g.flags & 8)) __builtin_amdgcn_s_barrier();      // flags&8: profiling only (wrong results)
+                if (!(PROF && (g.flags & 8))) __builtin_amdgcn_s_barrier();      // flags&8: profiling only (wrong results)
                 __builtin_amdgcn_sched_barrier(0);
                 if (early && kt + 1 + DIST < nk) issue(kt + 1 + DIST);   // into stage (kt+1+DIST) % STAGES == kt % STAGES
                 G2_READ(fa0, fw0, kt + 1, 0)
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
 #undef G2_WAIT_OLDER
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
-    if (MODE == MODE_F32 && acc_from_res && !(g.flags & 16)) {
+    if (MODE == MODE_F32 && acc_from_res && !(PROF && (g.flags & 16))) {
         // the residual is already in the accumulator: write-only fp32 tile through the LDS transpose -> full-row stores
         // (+1.5...4 % over per-lane 16-B stores; flags bit4 selects the direct form for A/B)
         __builtin_amdgcn_s_barrier();
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
         if constexpr (8 * STAGE_BYTES <= STAGES * STAGE) {
             // flags bit18 (profiling, wrong results): every tile stores over tile (0,0) - same store instructions, but the output
             // stays in L2 (no HBM write-back stream, no eviction of operand panels): separates issue cost from memory-side cost
-            const int m0e = (g.flags & 0x40000) ? 0 : m0, n0e = (g.flags & 0x40000) ? 0 : n0;
+            const int m0e = (PROF && (g.flags & 0x40000)) ? 0 : m0, n0e = (PROF && (g.flags & 0x40000)) ? 0 : n0;
             epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0e + wr * (MT * 32), n0e + wc * (NT * 32), lane);
         } else {
             // 256x384 tile: the wave's 128x96 outputs are staged in two 64-row halves (the same wave writes and reads its
@@ -429,6 +445,12 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
                                                                n0 + wc * (NT * 32), lane);
         }
     }
+    if (vb + (int)gridDim.x < nwg_) {                    // another tile follows: every wave is done with the ring / its staging region
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    }   // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -671,7 +693,12 @@ static int launch256(GemmArgs g, hipStream_t s) {
     // M-tiles per group of the tile order (the 32 blocks resident on an XCD then cover group_m x 32/group_m tiles sharing operand
     // panels in its L2): 4 measured best (+0.5 % on the step over 8; 16 and 32 lose 10-20 %, profiles/r01_gemm_shapes.md section 7)
     g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
-    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>), dim3(g.tiles_m * g.tiles_n), dim3(G2_THREADS), lds, s, g);
+    // one block per CU walking the tile list ("software relaunch") when there are at least two tiles per CU and one block fills a CU
+    static int cus = 0;
+    if (!cus) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur_dev);
+    const int nwg = g.tiles_m * g.tiles_n;
+    const bool loop = BN >= 256 && nwg >= 2 * cus && (tuning().gemm_flags & 0x1000000);   // bit24: opt-in until the in-step A/B says otherwise
+    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>), dim3(loop ? cus : nwg), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
         auto kstep = [&](auto kt_c, auto pp_c, int kt) {
             constexpr int KT = decltype(kt_c)::value, PP = decltype(pp_c)::value;
             const unsigned so = (s & 1u) * STAGE, sn = ((s + 1u) & 1u) * STAGE;
-            const bool more = kt + 1 < nk || has_next;
+            const bool more = kt + 1 < nk || (has_next && !(g.flags & 0x800000));   // bit23 (A/B): no prefetch across the tile boundary
             // ---- read interval ----------------------------------------------------------------------------------------------
             if constexpr (KT >= 1 && KT % 3 == 1 && PP == 0) {          // K-tiles 1, 4, 7, 10: row-tile (KT-1)/3 leaves for global memory
                 stage_store((KT - 1) / 3);
@@ -229,8 +229,26 @@ __global__ __launch_bounds__(PE_THREADS, 2) void gemm_pe_kernel(GemmArgs g) {
         pm_base = cm0 + wr * 128;
         pn_base = SW ? (cn0 + wc * 64) / 2 : cn0 + wc * 64;
         pM = g.M;
+        if (g.flags & 0x400000) {                        // A/B switch: persistent, but the tile is stored at the boundary (no trickle)
+            stage_store(0);
+#pragma unroll
+            for (int mt = 1; mt < MT; ++mt) {
+                stage_write(pk[mt - 1]);
+                stage_store(mt);
+            }
+            pM = 0;
+        }
         cm0 = nm0;
         cn0 = nn0;
+        if ((g.flags & 0x800000) && has_next) {          // A/B: "software relaunch" - the next tile starts like a fresh block would
+            if (!grpB) __builtin_amdgcn_s_barrier();     // re-align the two wave groups
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2 * PIECES; ++j) issue_piece((s & 1u) * STAGE, 0, j);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (grpB) __builtin_amdgcn_s_barrier();
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     // ---- last tile of this block: flush synchronously ------------------------------------------------------------------------------
