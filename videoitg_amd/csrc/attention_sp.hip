@@ -28,6 +28,11 @@
 #include "../../include/videoitg_hip.h"
 #include <type_traits>
 
+#ifndef VITG_PROFILING_BUILD
+#define VITG_PROFILING_BUILD 0     // the ablation switches below (tools/attn_ablate_sp.py) are compiled in only with -DVITG_PROFILING_BUILD=1:
+#endif                             // a run-time test inside the tile loop is a scalar branch per fragment read
+static constexpr bool PROF_BUILD = VITG_PROFILING_BUILD != 0;
+
 namespace vitg {
 
 constexpr float LAZY_RESCALE_LOG2 = 8.0f;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
                         const vec8 (&p_prv)[4]) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool HAS_QK = decltype(qk_c)::value, HAS_PV = decltype(pv_c)::value;
-        if (!(a.ablate & 8)) {                             // (ablate: profiling only, tools/attn_ablate.py)
+        if (!(PROF_BUILD && (a.ablate & 8))) {                             // (ablate: profiling only, tools/attn_ablate.py)
             issue_v(t, PAR);                               // V(t)   -> read in interval t+1
             if (t + 2 < nkt) issue_k(t + 2, PAR);          // K(t+2) -> read in interval t+1   (K(t) in that buffer is dead)
         }
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
             fr[1] = frag(1);
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
-                if (i + 2 < NM && !((a.ablate & 16) && i + 2 > NQK)) fr[(i + 2) % 3] = frag(i + 2);      // (ablate bit4: profiling - V^T fragments not re-read)
+                if (i + 2 < NM && !(PROF_BUILD && (a.ablate & 16) && i + 2 > NQK)) fr[(i + 2) % 3] = frag(i + 2);      // (ablate bit4: profiling - V^T fragments not re-read)
                 mfma_step(i, fr[i % 3]);
                 if (i < 2) row_max(i);
                 else {

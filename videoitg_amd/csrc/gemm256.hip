@@ -90,11 +90,17 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
         if (PROF && kt > 0 && (g.flags & 64)) return;            // profiling only (wrong results): operand stream off after the first K-tile
         char* st = smem + (kt % STAGES) * STAGE;
         const size_t koff = (size_t)kt * ROWB;
+        // the lane offset goes through an opaque copy: otherwise the compiler hoists base + lane offset out of the K loop as a 64-bit
+        // per-lane pointer and pays a v_lshl_add_u64 per piece instead of using the saddr form
+        const char* ka = a_base + koff;
+        const char* kw = w_base + koff;
+        unsigned off = j < A_INSTR ? a_cur[j] : w_cur[j - A_INSTR];
+        asm volatile("" : "+v"(off));
         if (j < A_INSTR)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + koff + a_cur[j]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ka + off),
                                              (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + koff + w_cur[j - A_INSTR]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kw + off),
                                              (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * W_INSTR + j - A_INSTR) * 1024), 16, 0, 0);
     };
     auto issue = [&](int kt) {
