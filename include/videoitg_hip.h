@@ -48,11 +48,13 @@ int vitg_device_info(char* name, int name_len);
  *   gemm_cfg    1 256x256x32 ring-4 | 2 256x128x32 | 3 256x256x64 ring-2 | 4 persistent | 5 asm LDS reads | 6 phased (default
  *               for >= 160 tiles) | 7 phased, 2 k-steps per interval | 8 four waves x 128x128 (AGPR accumulators) |
  *               9 256x384 (default for fp32-residual shapes) | 10 384x256 (default for SwiGLU) | 11 register-staged operands |
- *               13 persistent, deferred epilogue (default for 16-bit-output GEMMs with >= 2 tiles per CU: qkv, fc1)
+ *               13 persistent blocks with a deferred epilogue (16-bit-output and SwiGLU GEMMs; opt-in)
  *   gemm_group  M-tiles per group of the XCD-aware tile order (default 4)
  *   gemm_flags  bit0 non-temporal stores, bit5 N-split launch, bit7 5-stage ring for cfg 8, bit8 disable cfg 9/10 auto-selection;
- *               bit20 keep auto mode off cfg 13, bit21 cfg 13 also for SwiGLU;
- *               bits 1-4, 6, 16-19: profiling ablations (WRONG results; ignored unless the process set VITG_PROFILING=1)
+ *               bit20 auto mode uses cfg 13 for 16-bit-output GEMMs with >= 2 tiles per CU, bit21 also for SwiGLU; bit24 one block
+ *               per CU walks the tile list inside gemm256 ("software relaunch");
+ *               bits 1-4, 6, 9, 15-19, 22-23: profiling ablations (WRONG results or A/B only; need VITG_PROFILING=1, and for the
+ *               gemm256 main-loop ones a library built with -DVITG_PROFILING_BUILD=1)
  *   gemm_stagger  persistent kernel (cfg 4): de-phase the XCDs
  *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
  *   attn_ab     1 | 2  half-tile-out-of-phase hd-72 kernel on / off (default on)

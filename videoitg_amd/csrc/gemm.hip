@@ -219,12 +219,14 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     // >= 160 tiles of 256x256 -> 256x256x64 ring-2 (1 block/CU); fewer -> 256x128x32 ring-3 at 2 blocks/CU (twice the tiles,
     // 512 slots) which beat both the 256x256 and the 128x128 kernel there; M < 256 / unaligned cases -> 128x128.
     if (Wf && force != 128 && gemm_wf_applicable(g, mode)) rc = launch_gemm_wf(g, dtype, mode, s);
-    // 16-bit-output GEMMs with at least two 256x256 tiles per CU: the persistent kernel with the deferred epilogue (gemm_pe.hip; cfg 13
-    // forces it, gemm_flags bit20 keeps auto mode off it for A/B runs).  Same bits as the other 256-tile kernels.  In-step A/B
-    // (alternating bench.py runs): qkv + fc1 + llm qkv 671 -> 690 frames/s; SwiGLU gate/up on it 690 -> 686 (the 384x256 tile of
-    // cfg 10 is worth more there), so SwiGLU only with gemm_flags bit21; erf-GELU (projector, spills in erff) only when forced.
+    // gemm_pe.hip (cfg 13: persistent blocks, deferred epilogue; same bits as the other 256-tile kernels) is opt-in: gemm_cfg 13
+    // forces it, gemm_flags bit20 puts auto mode on it for 16-bit-output GEMMs with >= 2 tiles per CU (bit21: SwiGLU too).  It was
+    // briefly the default for qkv / fc1 (+2.9 % on the step) until its real advantage - saddr DMA addressing and no run-time
+    // switches inside an interval - was ported to gemm256.hip; since then the 384x256 tile wins again (721.6 vs 713.9 frames/s,
+    // alternating runs; profiles/r01_gemm_shapes.md section 16).
     else if ((tuning().gemm_cfg == 13 ||
-              (tuning().gemm_cfg == 0 && !(tuning().gemm_flags & 0x100000) && act != VITG_ACT_GELU_ERF && (mode != VITG_GEMM_SWIGLU || (tuning().gemm_flags & 0x200000)) && ceil_div(M, 256) * ceil_div(N, 256) >= 512)) &&
+              (tuning().gemm_cfg == 0 && (tuning().gemm_flags & 0x100000) && act != VITG_ACT_GELU_ERF &&
+               (mode != VITG_GEMM_SWIGLU || (tuning().gemm_flags & 0x200000)) && ceil_div(M, 256) * ceil_div(N, 256) >= 512)) &&
              force != 128 && gemm_pe_applicable(g, mode))
         rc = launch_gemm_pe(g, dtype, mode, s);
     else if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
