@@ -3,7 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops
-dt = torch.float16
+dt = torch.bfloat16 if "bf16" in sys.argv[1:] else torch.float16
 for M in (1660, 3260, 6460):
     for name, N, K, mode in [("qkv", 4608, 3584, ops.GEMM_STORE16), ("o", 3584, 3584, ops.GEMM_F32), ("gateup", 37888, 3584, ops.GEMM_SWIGLU),
                              ("down", 3584, 18944, ops.GEMM_F32)]:

@@ -751,8 +751,11 @@ static int choose_cfg(const GemmArgs& g, int mode) {
         const double c9 = cost(256, 384, e, 1);
         if (c9 < 0.97 * best) { best = c9; cfg = 9; }
     }
-    if (wide_ok && mode != MODE_F32 && g.M >= 384) {
-        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : ((tuning().gemm_flags & 4096) ? 0.96 : 1.08), 1);    // flags bit12: A/B (16-bit outputs off the tall tile); bit13: o-proj on the wide tile
+    if (wide_ok && g.M >= 384 && !(mode == MODE_F32 && (tuning().gemm_flags & 16384))) {
+        // fp32-residual GEMMs on the tall tile since the saddr addressing freed its registers (it used to spill): o-proj at M = 12860
+        // +6 %, and at M = 6460 (two context-parallel ranks) o / down fit ONE round of 384x256 tiles: +24 % / +48 % (tools/gemm_small_m.py).
+        // flags bit12: A/B (16-bit outputs off the tall tile); bit14: A/B (fp32-residual GEMMs off it)
+        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : mode == MODE_F32 ? 1.05 : ((tuning().gemm_flags & 4096) ? 0.96 : 1.08), 1);
         if (c10 < 0.97 * best) { best = c10; cfg = 10; }
     }
     return cfg;
