@@ -50,7 +50,7 @@ int vitg_device_info(char* name, int name_len);
  *               9 256x384 (default for fp32-residual shapes) | 10 384x256 (default for SwiGLU) | 11 register-staged operands |
  *               13 persistent blocks with a deferred epilogue (16-bit-output and SwiGLU GEMMs; opt-in)
  *   gemm_group  M-tiles per group of the XCD-aware tile order (default 4)
- *   gemm_flags  bit0 non-temporal stores, bit5 N-split launch, bit7 5-stage ring for cfg 8, bit8 disable cfg 9/10 auto-selection;
+ *   gemm_flags  bit0 non-temporal stores (profiling build only: measured +-0), bit5 N-split launch, bit7 5-stage ring for cfg 8, bit8 disable cfg 9/10 auto-selection;
  *               bit20 auto mode uses cfg 13 for 16-bit-output GEMMs with >= 2 tiles per CU, bit21 also for SwiGLU; bit24 one block
  *               per CU walks the tile list inside gemm256 ("software relaunch");
  *               bits 1-4, 6, 9, 15-19, 22-23: profiling ablations (WRONG results or A/B only; need VITG_PROFILING=1, and for the

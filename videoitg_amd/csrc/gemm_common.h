@@ -3,6 +3,10 @@
 #include "common.h"
 #include "../../include/videoitg_hip.h"
 
+#ifndef VITG_PROFILING_BUILD
+#define VITG_PROFILING_BUILD 0     // build.sh -DVITG_PROFILING_BUILD=1: compile the ablation / A-B switches into the kernels (see gemm256.hip)
+#endif
+
 namespace vitg {
 
 struct GemmArgs {
@@ -127,7 +131,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                         const int rm = g.res_mod > 0 ? m % g.res_mod : m;
                         v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
                     }
-                    *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
+                    // wave-uniform tile origin (64-bit, scalar) + 32-bit in-tile offset: saddr store, no 64-bit VALU per row
+                    char* const ob = (char*)((float*)g.out + (size_t)m_base * g.ldo + n_base);
+                    *(f32x4*)(ob + (unsigned)(((mt - MT0) * 32 + row) * g.ldo + c * 4) * 4u) = v;
                 }
             }
         }
@@ -175,12 +181,15 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
             const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ (row & SWZ)) << 4));
             const int m = m_base + row, n = n_out + c * 8;
             if (m < g.M) {
-                T* dst = (T*)g.out + (size_t)m * g.ldo + n;
-                if (g.flags & 2) continue;
+                // wave-uniform tile origin (64-bit, scalar) + 32-bit byte offset: saddr stores, no 64-bit VALU per row.  The non-temporal
+                // variant (gemm_flags bit0, measured +-0) and the store-skipping ablation (bit1) exist only in a profiling build.
+                char* const ob = (char*)((T*)g.out + (size_t)m_base * g.ldo + n_out);
+                const unsigned boff = (unsigned)(row * g.ldo + c * 8) * 2u;
+                if (VITG_PROFILING_BUILD && (g.flags & 2)) continue;
                 if (n + 8 <= n_lim) {
-                    if (g.flags & 1) __builtin_nontemporal_store(v, (u32x4*)dst);
-                    else *(u32x4*)dst = v;
-                } else if (n + 4 <= n_lim) *(u32x2*)dst = u32x2{v[0], v[1]};
+                    if (VITG_PROFILING_BUILD && (g.flags & 1)) __builtin_nontemporal_store(v, (u32x4*)(ob + boff));
+                    else *(u32x4*)(ob + boff) = v;
+                } else if (n + 4 <= n_lim) *(u32x2*)(ob + boff) = u32x2{v[0], v[1]};
             }
         }
     }
