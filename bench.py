@@ -62,7 +62,7 @@ def algorithmic_flops(cfg, T, R, n_text):
     G = R // v.patch_size
     P = G * G
     Dv, Fv, Lv = v.hidden_size, v.intermediate_size, cfg.num_vit_layers_needed()
-    hw = min(cfg.pooled_grid(T), G)
+    hw = cfg.pooled_grid(T, G)
     N = T * hw * hw + n_text
     D, Fl, Ll = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
     kvw = cfg.num_key_value_heads * cfg.head_dim

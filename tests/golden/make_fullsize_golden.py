@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Complete fp32 oracle passes over the FULL architecture (26 SigLIP-so400m layers + 28 Qwen2-7B layers) at BASELINE sizes.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fullsize_golden.py CASE [CASE ...]
+
+Runs in the build container (CPU only, 8 vCPU / 62 GB; minutes to half an hour per case) and writes
+``tests/golden/full_<case>.json``: seeds, the T oracle logits, sigmoid scores, the descending order, the Top-32 set, the
+rank-32/33 score gap, a few intermediate checksums and the oracle's wall time.  Weights are
+``videoitg_amd.synth.counter_tensor`` (a stateless integer hash: bit-identical on CPU and GPU), inputs come from
+``oracle.fullsize.workload_inputs`` — so the `-m gpu` tests and ``bench.py`` rebuild exactly the same model and inputs on the
+MI355X and compare the HIP path with these logits (max |dscore|, Top-32 set), with no oracle run and no reference on the box.
+
+The oracle is pinned to the reference itself at small sizes (make_golden.py -> test_oracle_golden.py, <= 2e-5); this script
+extends the same oracle functions, unchanged, to full width and depth (oracle/fullsize.py only streams the weights).
+"""
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import fullsize  # noqa: E402
+from videoitg_amd.config import ITGConfig  # noqa: E402
+
+# name -> (frames, resolution, prompt tokens).  c2 = BASELINE.json configs[1] (the bench workload), b0 = the reference-native
+# 512 x 384^2, c1 = configs[0]'s size (64 frames, N = 16 445), depth16 = full depth/width on few small frames (fast GPU test)
+CASES = {
+    "c2_512x448": (512, 448, 60),
+    "b0_512x384": (512, 384, 60),
+    "c1_64x384": (64, 384, 60),
+    "depth16_224": (16, 224, 60),
+}
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name in sys.argv[1:]:
+        T, R, L = CASES[name]
+        cfg = ITGConfig()
+        ids, pix = fullsize.workload_inputs(cfg, T, R, L)
+        t0 = time.time()
+        with torch.inference_mode():
+            out = fullsize.streaming_forward(cfg, ids, pix, seed=0, log=lambda m: print(f"[{name} +{time.time() - t0:.0f}s] {m}", flush=True))
+        rk = fullsize.ranking_summary(out["logits"], 32)
+        rec = dict(case=name, frames=T, resolution=R, prompt_len=L, weight_seed=0, pixel_seed=1234, prompt_seed=4321,
+                   llm_tokens=out["N"], logits=[float(x) for x in out["logits"].tolist()], **rk, checks=out["checks"],
+                   oracle=dict(kind="oracle/videoitg_oracle.py streamed by oracle/fullsize.py, torch CPU fp32",
+                               torch=torch.__version__, threads=torch.get_num_threads(), seconds=out["seconds"]))
+        path = os.path.join(HERE, f"full_{name}.json")
+        with open(path, "w") as f:
+            json.dump(rec, f)
+        print(f"wrote {path}: logits[:4]={rec['logits'][:4]} gap32/33={rec['gap_k_k1']} seconds={out['seconds']}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -45,7 +45,7 @@ def _worker(rank, world, port, ids, T, out):
     pix = synth.synth_pixel_values(T, cfg.vision.image_size, seed=1234)
     v = cfg.vision
     G = v.grid
-    hw = min(cfg.pooled_grid(T), G)                                   # GLOBAL T
+    hw = cfg.pooled_grid(T, G)                                        # GLOBAL T
     pos = (ids == -200).nonzero().flatten().tolist()[0]
     pre, post = ids[:pos], ids[pos + 1:]
     plan = make_plan(world, T, hw * hw, pre.numel(), post.numel())

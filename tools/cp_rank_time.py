@@ -17,7 +17,7 @@ cfg = ITGConfig()
 dev = torch.device("cuda:0")
 eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev))
 G = R // cfg.vision.patch_size
-hw = min(cfg.pooled_grid(T), G)
+hw = cfg.pooled_grid(T, G)
 plan = make_plan(world, T, hw * hw, 0, 60)
 rank = world - 1                                    # the rank that also owns the prompt tokens
 fr = plan.frames[rank]

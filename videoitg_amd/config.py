@@ -86,10 +86,11 @@ class ITGConfig:
             raise ValueError(f"mm_vision_select_layer {sl} out of range for {L} layers")
         return n
 
-    def pooled_grid(self, num_frames: int) -> int:
-        """HW = min(floor(sqrt(vision_token_num / T)), G)   (mlp_proj.py:48,54, eval branch)."""
+    def pooled_grid(self, num_frames: int, grid: Optional[int] = None) -> int:
+        """HW = min(floor(sqrt(vision_token_num / T)), ori_HW) with ori_HW the ACTUAL token grid of the input
+        (mlp_proj.py:46-54, eval branch: ori_HW = int(P ** 0.5)); `grid` defaults to the tower's native one."""
         hw = math.floor((self.vision_token_num / num_frames) ** 0.5)
-        return min(hw, self.vision.grid)
+        return min(hw, self.vision.grid if grid is None else grid)
 
     def to_dict(self) -> dict:
         return asdict(self)

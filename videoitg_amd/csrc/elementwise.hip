@@ -159,7 +159,9 @@ __global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict
     const int t = (int)(orow / (HW * HW)), o = (int)(orow % (HW * HW));
     const int oy = o / HW, ox = o % HW;
     const float sc = (float)G / (float)HW;
-    float sy = (oy + 0.5f) * sc - 0.5f, sx = (ox + 0.5f) * sc - 0.5f;
+    // separately rounded multiply and subtract (no FMA contraction): SelectorEngine.pool_sources evaluates the same expression
+    // with torch fp32 ops on the host to decide which rows exist in a compact input, and the two must agree at integer boundaries
+    float sy = __fsub_rn(__fmul_rn(oy + 0.5f, sc), 0.5f), sx = __fsub_rn(__fmul_rn(ox + 0.5f, sc), 0.5f);
     sy = sy < 0.f ? 0.f : sy;
     sx = sx < 0.f ? 0.f : sx;
     const int y0 = (int)sy, x0 = (int)sx;
@@ -168,10 +170,20 @@ __global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict
     // dense input: G*G rows per frame; compact input (cmap != null): only the Pc rows the pool reads, at cmap[y*G+x]
     const float* base = x + (long)t * (cmap ? Pc : G * G) * ldx;
     const int i00 = y0 * G + x0, i01 = y0 * G + x1, i10 = y1 * G + x0, i11 = y1 * G + x1;
-    const float* p00 = base + (long)(cmap ? cmap[i00] : i00) * ldx;
-    const float* p01 = base + (long)(cmap ? cmap[i01] : i01) * ldx;
-    const float* p10 = base + (long)(cmap ? cmap[i10] : i10) * ldx;
-    const float* p11 = base + (long)(cmap ? cmap[i11] : i11) * ldx;
+    int r00 = i00, r01 = i01, r10 = i10, r11 = i11;
+    if (cmap) {
+        // a token the host did not list (cmap -1) must never be dereferenced: read row 0 instead and poison the output row with
+        // NaN so that the disagreement is loud rather than silent
+        r00 = cmap[i00]; r01 = cmap[i01]; r10 = cmap[i10]; r11 = cmap[i11];
+        if ((r00 | r01 | r10 | r11) < 0) {
+            for (int c = threadIdx.x; c < ldo; c += blockDim.x) out[orow * ldo + c] = T16<TO>::from_f32(__builtin_nanf(""));
+            return;
+        }
+    }
+    const float* p00 = base + (long)r00 * ldx;
+    const float* p01 = base + (long)r01 * ldx;
+    const float* p10 = base + (long)r10 * ldx;
+    const float* p11 = base + (long)r11 * ldx;
     for (int c = threadIdx.x * 4; c < ldo; c += blockDim.x * 4) {
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (c < D) {

@@ -182,10 +182,12 @@ static int launch(const GemmArgs& g, int mode, hipStream_t s) {
 
 using namespace vitg;
 
-static int g_attr_done = 0;
 static void set_attrs() {
-    if (g_attr_done) return;
-    g_attr_done = 1;
+    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev == done_dev) return;
+    done_dev = cur_dev;
     const int lds = 2 * 2 * BM * BK * 2;
 #define SETA(T, Mo) hipFuncSetAttribute((const void*)gemm128_kernel<T, Mo>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
     SETA(bf16_t, MODE_STORE16); SETA(bf16_t, MODE_F32); SETA(bf16_t, MODE_SWIGLU);

@@ -173,16 +173,26 @@ class SelectorEngine:
         self.attn_variant = attn_variant
         self.skip_dead_rows = True        # last tower layer only on the tokens the pool reads (see vit_forward)
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
-        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._poolsrc: Dict[tuple, object] = {}
 
-    # workspace: cached by (name, shape, dtype); zero-initialised once so that pad columns stay zero
+    # workspace: ONE buffer per name, grown to the largest row count seen and handed out as a [:rows] view, so a run over
+    # documents with varying prompt lengths / frame counts holds max-size buffers instead of one set per distinct shape.
+    # Zero-initialised buffers keep their pad COLUMNS zero (kernels only ever write the payload columns of a row).
     def _buf(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
-        key = (name, tuple(shape), dtype)
-        t = self._ws.get(key)
-        if t is None:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self._ws[key] = t
-        return t
+        rows, rest = int(shape[0]), tuple(int(s) for s in shape[1:])
+        t = self._ws.get(name)
+        if t is None or t.dtype != dtype or tuple(t.shape[1:]) != rest or t.shape[0] < rows:
+            t = (torch.zeros if zero else torch.empty)((rows,) + rest, dtype=dtype, device=self.device)
+            self._ws[name] = t                                   # the smaller buffer (if any) is dropped here
+        return t[:rows]
+
+    def workspace_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._ws.values())
+
+    def workspace_tensors(self) -> List[torch.Tensor]:
+        """the live buffers (a captured graph keeps these referenced so that a later growth cannot free what it replays on)"""
+        return list(self._ws.values())
 
     def release_workspace(self) -> None:
         self._ws.clear()
@@ -191,10 +201,10 @@ class SelectorEngine:
     def pool_sources(self, G: int, hw: int):
         """(idx int32 [Pc] sorted token ids y*G+x that carry weight, cmap int32 [G*G] token -> compact row or -1).
         27->5: 81 of 729 tokens, 32->5: 100 of 1024.  None when there is no pooling (hw == G)."""
-        key = ("poolsrc", G, hw)
-        if key not in self._ws:
+        key = (G, hw)
+        if key not in self._poolsrc:
             if hw >= G:
-                self._ws[key] = None
+                self._poolsrc[key] = None
             else:
                 used = set()
                 sc = torch.tensor(float(G), dtype=torch.float32) / torch.tensor(float(hw), dtype=torch.float32)
@@ -206,8 +216,8 @@ class SelectorEngine:
                 idx = torch.tensor([y * G + x for y in rows for x in rows], dtype=torch.int32)
                 cmap = torch.full((G * G,), -1, dtype=torch.int32)
                 cmap[idx.long()] = torch.arange(idx.numel(), dtype=torch.int32)
-                self._ws[key] = (idx.to(self.device), cmap.to(self.device))
-        return self._ws[key]
+                self._poolsrc[key] = (idx.to(self.device), cmap.to(self.device))
+        return self._poolsrc[key]
 
     # ---- A7: SigLIP tower -> fp32 features ------------------------------------------------------------------------
     def vit_forward(self, pix: torch.Tensor, hw: Optional[int] = None):
@@ -343,7 +353,7 @@ class SelectorEngine:
         pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
         if len(pos) != 1:
             raise ValueError(f"exactly one <image> token per sample is supported on the selector path, got {len(pos)}")
-        hw = cfg.pooled_grid(T) if cfg.pooled_grid(T) < G else G
+        hw = cfg.pooled_grid(T, G)
         nv = T * hw * hw
         pre, post = ids[:pos[0]], ids[pos[0] + 1:]
         n = pre.numel() + nv + post.numel()
@@ -386,7 +396,7 @@ class SelectorEngine:
             raise ValueError("all videos in a batch must share one frame size")
         pix = torch.cat([im.to(self.device) for im in images], 0) if B > 1 else images[0].to(self.device)
         G0 = pix.shape[-1] // self.cfg.vision.patch_size
-        hws = {min(self.cfg.pooled_grid(im.shape[0]), G0) for im in images}
+        hws = {self.cfg.pooled_grid(im.shape[0], G0) for im in images}
         hw_all = hws.pop() if len(hws) == 1 else None                 # videos of different length pool differently -> dense
         feats, G, cmap, pc = self.vit_forward(pix, hw_all)
         P = pc if cmap is not None else G * G
@@ -428,13 +438,14 @@ class GraphedForward:
         torch.cuda.current_stream(eng.device).wait_stream(side)
         with torch.cuda.graph(self.graph):
             self.out = self._run()
+        self._held = eng.workspace_tensors()                              # the graph replays on exactly these allocations
         assert self.out.shape == (T,)
 
     def _run(self) -> torch.Tensor:
         eng = self.eng
         T = self.pix.shape[0]
         G0 = self.pix.shape[-1] // eng.cfg.vision.patch_size
-        hw = min(eng.cfg.pooled_grid(T), G0)
+        hw = eng.cfg.pooled_grid(T, G0)
         feats, G, cmap, pc = eng.vit_forward(self.pix, hw)
         return eng.score_video(feats, T, G, self.ids_host, cmap, pc, ids_dev=self.ids_dev)
 

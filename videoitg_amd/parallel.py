@@ -121,7 +121,7 @@ class ContextParallel:
         pre, post = ids[:pos[0]], ids[pos[0] + 1:]
         T = pix.shape[0]
         G = pix.shape[-1] // cfg.vision.patch_size
-        hw = min(cfg.pooled_grid(T), G)                      # GLOBAL frame count (mlp_proj.py:48)
+        hw = cfg.pooled_grid(T, G)                           # GLOBAL frame count (mlp_proj.py:48)
         plan = make_plan(self.world, T, hw * hw, pre.numel(), post.numel())
         fr = plan.frames[self.rank]
         feats, _, cmap, pc = eng.vit_forward(pix[fr.start:fr.stop], hw)

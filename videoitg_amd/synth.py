@@ -44,6 +44,64 @@ def _normal(seed, key, shape, std, mean=0.0) -> torch.Tensor:
     return round_16(t)
 
 
+# ---- counter-based generator: bit-identical on every device ------------------------------------------------------------
+# torch's CPU and HIP generators draw different streams, so weights drawn on the GPU (fast) could not be reproduced by the
+# fp32 oracle on a CPU.  The full-size parity fixtures (tests/golden/make_fullsize_golden.py) and bench.py's `parity` block
+# need exactly that, so full-size weights come from a stateless integer hash of (seed, key, flat element index):
+# 32-bit-valued arithmetic carried in int64 (no overflow anywhere), the four bytes of the hash summed (Irwin-Hall(4):
+# mean 510, variance 4*(256^2-1)/12 = 21845) -> centred -> one fp32 multiply -> one fp32 add -> round_16.  Every step is an
+# exactly defined integer or single IEEE operation, so CPU and GPU agree in every bit.
+_M32 = 0xFFFFFFFF
+_IH4_STD = 21845.0 ** 0.5
+_CHUNK_CPU, _CHUNK_DEV = 1 << 20, 1 << 26      # cache-resident on a CPU (8x faster than one big pass), few launches on a GPU
+
+
+def _mix32(x: torch.Tensor) -> torch.Tensor:
+    x = ((x ^ (x >> 16)) * 0x45D9F3B) & _M32
+    x = ((x ^ (x >> 16)) * 0x45D9F3B) & _M32
+    return x ^ (x >> 16)
+
+
+def key_seed(seed: int, key: str) -> int:
+    return (seed * 1_000_003 + zlib.crc32(key.encode())) & _M32
+
+
+def counter_values(seed: int, key: str, flat_index: torch.Tensor, mean: float, std: float) -> torch.Tensor:
+    """fp32 values of tensor `key` at the given flat element indices (int64 tensor on any device)."""
+    x = _mix32((_mix32(flat_index & _M32) + key_seed(seed, key)) & _M32)
+    b = (x & 255) + ((x >> 8) & 255) + ((x >> 16) & 255) + (x >> 24)
+    scale = torch.tensor(std / _IH4_STD, dtype=torch.float32).item()          # the fp32 value, as a Python float
+    v = (b - 510).to(torch.float32) * scale
+    if mean != 0.0:
+        v = v + torch.tensor(mean, dtype=torch.float32).item()
+    return round_16(v)
+
+
+def counter_tensor(seed: int, key: str, shape, mean: float, std: float, device="cpu") -> torch.Tensor:
+    """Whole tensor `key` (fp32, 16-bit exact), generated on `device` in bounded chunks."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    chunk = _CHUNK_CPU if torch.device(device).type == "cpu" else _CHUNK_DEV
+    for s0 in range(0, n, chunk):
+        idx = torch.arange(s0, min(n, s0 + chunk), dtype=torch.int64, device=device)
+        out[s0:s0 + idx.numel()] = counter_values(seed, key, idx, mean, std)
+    return out.reshape(tuple(shape))
+
+
+def counter_rows(seed: int, key: str, shape, rows: torch.Tensor, mean: float, std: float) -> torch.Tensor:
+    """Selected rows of the 2-D tensor `key` without generating the rest (embedding rows of a prompt)."""
+    cols = int(shape[1])
+    rows = rows.to(torch.int64)
+    idx = rows[:, None] * cols + torch.arange(cols, dtype=torch.int64, device=rows.device)[None, :]
+    return counter_values(seed, key, idx.reshape(-1), mean, std).reshape(rows.numel(), cols)
+
+
+def counter_state_dict(specs, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    return {k: counter_tensor(seed, k, s, m, sd, device) for k, s, m, sd in specs}
+
+
 def llm_param_specs(cfg: ITGConfig) -> Iterator[Tuple[str, tuple, float, float]]:
     """(key, shape, mean, std) for every LLM / projector / head tensor."""
     D, F = cfg.hidden_size, cfg.intermediate_size

@@ -1,13 +1,12 @@
 """Random-init weights of the full architecture generated directly in HBM (benchmark / smoke use).
 
-Same shapes, key names and per-tensor distributions as ``videoitg_amd.synth`` but drawn with the device generator,
-one layer at a time (fp32 layer -> packed 16-bit layout -> fp32 freed), so a 7.6 B-parameter model is ready in
-seconds.  NOT bit-identical to the CPU generator of ``synth`` — parity tests use ``synth``; the benchmark only needs
-weights of the right architecture (no checkpoint is reachable offline).
+Same shapes, key names and per-tensor distributions as ``videoitg_amd.synth``, drawn with ``synth.counter_tensor`` - a
+stateless integer hash of (seed, key, element index) that is BIT-IDENTICAL on CPU and GPU - one layer at a time (fp32
+layer -> packed 16-bit layout -> fp32 freed), so a 7.6 B-parameter model is ready in seconds and the fp32 oracle can
+reproduce exactly the same weights on a CPU (tests/golden/make_fullsize_golden.py; bench.py's `parity` block).  No
+checkpoint is reachable offline.
 """
 from __future__ import annotations
-
-import zlib
 
 import torch
 
@@ -17,14 +16,7 @@ from .engine import PackedWeights
 
 
 def _draw(specs, device, seed):
-    out = {}
-    for k, shape, mean, std in specs:
-        g = torch.Generator(device=device)
-        g.manual_seed((seed * 1_000_003 + zlib.crc32(k.encode())) % (2 ** 63 - 1))
-        t = torch.empty(shape, dtype=torch.float32, device=device)
-        t.normal_(mean, std, generator=g)
-        out[k] = t
-    return out
+    return synth.counter_state_dict(specs, seed, device)
 
 
 def packed_random_weights(cfg: ITGConfig, dtype: torch.dtype, device, seed: int = 0) -> PackedWeights:
