@@ -24,11 +24,9 @@ def _specs(it, pred):
 
 
 def workload_inputs(cfg, T: int, R: int, prompt_len: int, pix_seed: int = 1234):
-    """(input_ids int64 [1, 1+L], pixel_values fp32 [T,3,R,R]) — the synthetic inputs of SURVEY.md §8(d): `<image>` followed by
-    `prompt_len` seeded token ids; low-pass-filtered pixels in [-1,1], exactly representable in bf16 and fp16.  The SAME function
-    feeds bench.py, the GPU parity tests and the oracle."""
-    ids = torch.cat([torch.tensor([O.IMAGE_TOKEN_INDEX]), synth.synth_prompt_ids(prompt_len, cfg.vocab_size)]).unsqueeze(0)
-    return ids, synth.synth_pixel_values(T, R, seed=pix_seed)
+    """the synthetic inputs of SURVEY.md §8(d); ONE function (videoitg_amd.synth.workload_inputs) feeds bench.py, the GPU parity
+    tests and this oracle"""
+    return synth.workload_inputs(cfg, T, R, prompt_len, pix_seed)
 
 
 def streaming_forward(cfg, input_ids: torch.Tensor, pix: torch.Tensor, seed: int = 0, frame_chunk: int = 16,

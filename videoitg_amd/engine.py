@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.nn.functional as F  # weight re-layout only (pad / interpolate of the position table at load time)
 
-from . import ops
+from .torch_ops import K          # kernel launches go through torch.ops.videoitg.* (the dispatcher-registered custom ops)
 from .config import ITGConfig
 from .constants import IMAGE_TOKEN_INDEX
 from .ops import pad64
@@ -232,9 +232,9 @@ class SelectorEngine:
         M = T * P
         Dv, Dvp, Fvp = v.hidden_size, pad64(v.hidden_size), pad64(v.intermediate_size)
         H, hd = v.num_attention_heads, v.head_dim
-        a0 = ops.patchify(pix, v.patch_size, w.patch_w.shape[1], self.dtype)
+        a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.dtype)
         x = self._buf("vit_x", (M, Dv), torch.float32)
-        ops.gemm(a0, w.patch_w, x, mode=ops.GEMM_F32, bias=w.patch_b, res=w.pos_table(G), res_mod=P)
+        K.gemm(a0, w.patch_w, x, mode=K.GEMM_F32, bias=w.patch_b, res=w.pos_table(G), res_mod=P)
         del a0
         h = self._buf("vit_h", (M, Dvp), self.dtype, zero=True)
         qkv = self._buf("vit_qkv", (M, 3 * Dv), self.dtype)
@@ -245,15 +245,15 @@ class SelectorEngine:
         full_layers = w.vit if src is None else w.vit[:-1]
         st = (P * 3 * Dv, 3 * Dv, hd)
         for lw in full_layers:
-            ops.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
-            ops.gemm(h, lw.qkv_w, qkv, mode=ops.GEMM_STORE16, bias=lw.qkv_b)
-            ops.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
+            K.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
+            K.gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
+            K.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
                           q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
                           variant=self.attn_variant)
-            ops.gemm(o, lw.out_w, x, mode=ops.GEMM_F32, bias=lw.out_b, res=x)
-            ops.layernorm(x, lw.ln2_w, lw.ln2_b, h, Dv, v.layer_norm_eps)
-            ops.gemm(h, lw.fc1_w, f, mode=ops.GEMM_STORE16, bias=lw.fc1_b, act=ops.ACT_GELU_TANH)
-            ops.gemm(f, lw.fc2_w, x, mode=ops.GEMM_F32, bias=lw.fc2_b, res=x)
+            K.gemm(o, lw.out_w, x, mode=K.GEMM_F32, bias=lw.out_b, res=x)
+            K.layernorm(x, lw.ln2_w, lw.ln2_b, h, Dv, v.layer_norm_eps)
+            K.gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
+            K.gemm(f, lw.fc2_w, x, mode=K.GEMM_F32, bias=lw.fc2_b, res=x)
         if src is None:
             return x, G, None, 0
         # ---- last needed layer on compact query rows -------------------------------------------------------------
@@ -261,23 +261,23 @@ class SelectorEngine:
         Pc = idx.numel()
         Mc = T * Pc
         lw = w.vit[-1]
-        ops.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
-        ops.gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=ops.GEMM_STORE16, bias=lw.qkv_b[Dv:])          # K|V for every token
+        K.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
+        K.gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, bias=lw.qkv_b[Dv:])          # K|V for every token
         hq = self._buf("vit_hq", (Mc, Dvp), self.dtype)
         xq = self._buf("vit_xq", (Mc, Dv), torch.float32)
-        ops.gather_rows(h, idx, P, T, hq, Dvp)
-        ops.gather_rows(x, idx, P, T, xq, Dv)
+        K.gather_rows(h, idx, P, T, hq, Dvp)
+        K.gather_rows(x, idx, P, T, xq, Dv)
         qc = self._buf("vit_qc", (Mc, Dv), self.dtype)
-        ops.gemm(hq, lw.qkv_w[:Dv], qc, mode=ops.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
+        K.gemm(hq, lw.qkv_w[:Dv], qc, mode=K.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
         oc = self._buf("vit_oc", (Mc, Dvp), self.dtype, zero=True)
-        ops.attention(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
+        K.attention(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
                       q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
                       variant=self.attn_variant)
-        ops.gemm(oc, lw.out_w, xq, mode=ops.GEMM_F32, bias=lw.out_b, res=xq)
-        ops.layernorm(xq, lw.ln2_w, lw.ln2_b, hq, Dv, v.layer_norm_eps)
+        K.gemm(oc, lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
+        K.layernorm(xq, lw.ln2_w, lw.ln2_b, hq, Dv, v.layer_norm_eps)
         fc = self._buf("vit_fc", (Mc, Fvp), self.dtype)
-        ops.gemm(hq, lw.fc1_w, fc, mode=ops.GEMM_STORE16, bias=lw.fc1_b, act=ops.ACT_GELU_TANH)
-        ops.gemm(fc, lw.fc2_w, xq, mode=ops.GEMM_F32, bias=lw.fc2_b, res=xq)
+        K.gemm(hq, lw.fc1_w, fc, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
+        K.gemm(fc, lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
         return xq, G, cmap, Pc
 
     # ---- A9: pool + projector, written straight into rows of the LLM residual stream ------------------
@@ -287,10 +287,10 @@ class SelectorEngine:
         Dv, Dvp, Dp = cfg.vision.hidden_size, pad64(cfg.vision.hidden_size), pad64(cfg.hidden_size)
         nv = T * hw * hw
         pooled = self._buf("pooled", (nv, Dvp), self.dtype)
-        ops.bilinear_pool(feats, pooled, T, G, hw, Dv, cmap, pc)
+        K.bilinear_pool(feats, pooled, T, G, hw, Dv, cmap, pc)
         g = self._buf("proj_g", (nv, Dp), self.dtype)
-        ops.gemm(pooled, w.proj0_w, g, mode=ops.GEMM_STORE16, bias=w.proj0_b, act=ops.ACT_GELU_ERF)
-        ops.gemm(g, w.proj2_w, dst_rows, mode=ops.GEMM_F32, bias=w.proj2_b)
+        K.gemm(pooled, w.proj0_w, g, mode=K.GEMM_STORE16, bias=w.proj0_b, act=K.ACT_GELU_ERF)
+        K.gemm(g, w.proj2_w, dst_rows, mode=K.GEMM_F32, bias=w.proj2_b)
 
     def rope_tables(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """fp32 cos/sin [n, hd/2], inv_freq = theta^(-2i/hd), positions 0..n-1 ([3P] Qwen2RotaryEmbedding;
@@ -322,24 +322,24 @@ class SelectorEngine:
         scale = hd ** -0.5
         kvw = 2 * nkv * hd
         for lw in w.llm:
-            ops.rmsnorm(x, lw.in_ln, h, D, cfg.rms_norm_eps)
-            ops.gemm(h, lw.qkv_w, qkv, mode=ops.GEMM_STORE16, bias=lw.qkv_b)
-            ops.rope_(qkv, cos, sin, nq + nkv, hd)
+            K.rmsnorm(x, lw.in_ln, h, D, cfg.rms_norm_eps)
+            K.gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
+            K.rope_(qkv, cos, sin, nq + nkv, hd)
             if kv_gather is None:
-                ops.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
+                K.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
                               head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
                               o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
             else:
                 kv = kv_gather(qkv[:, nq * hd:])                 # [total, 2*nkv*hd]: K heads then V heads per row
-                ops.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
+                K.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
                               head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, kvw, hd), v_strides=(0, kvw, hd),
                               o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
-            ops.gemm(o, lw.o_w, x, mode=ops.GEMM_F32, res=x)
-            ops.rmsnorm(x, lw.post_ln, h, D, cfg.rms_norm_eps)
-            ops.gemm(h, lw.gu_w, f, mode=ops.GEMM_SWIGLU)
-            ops.gemm(f, lw.down_w, x, mode=ops.GEMM_F32, res=x)
+            K.gemm(o, lw.o_w, x, mode=K.GEMM_F32, res=x)
+            K.rmsnorm(x, lw.post_ln, h, D, cfg.rms_norm_eps)
+            K.gemm(h, lw.gu_w, f, mode=K.GEMM_SWIGLU)
+            K.gemm(f, lw.down_w, x, mode=K.GEMM_F32, res=x)
         out = self._buf("llm_out", (N, D), torch.float32)
-        ops.rmsnorm(x, w.norm_w, out, D, cfg.rms_norm_eps)
+        K.rmsnorm(x, w.norm_w, out, D, cfg.rms_norm_eps)
         return out
 
     # ---- whole path for one sample whose frames are already encoded ---------------------------------
@@ -367,14 +367,14 @@ class SelectorEngine:
         x = self._buf("llm_x", (n, cfg.hidden_size), torch.float32)
         if pre.numel():
             src = ids_dev[:pos[0]] if ids_dev is not None else pre.contiguous().to(self.device)
-            ops.embed_gather(src, self.w.embed, x[:pre.numel()])
+            K.embed_gather(src, self.w.embed, x[:pre.numel()])
         self.project_into(feats, T, G, hw, x[pre.numel():pre.numel() + nv], cmap, pc)
         if post.numel():
             src = ids_dev[pos[0] + 1:pos[0] + 1 + post.numel()] if ids_dev is not None else post.contiguous().to(self.device)
-            ops.embed_gather(src, self.w.embed, x[pre.numel() + nv:])
+            K.embed_gather(src, self.w.embed, x[pre.numel() + nv:])
         hfin = self.llm_forward(x)
         logits = torch.empty(T, dtype=torch.float32, device=self.device)
-        ops.pool_score(hfin[pre.numel():], T, hw * hw, cfg.hidden_size, self.w.head_w, self.w.head_b, logits)
+        K.pool_score(hfin[pre.numel():], T, hw * hw, cfg.hidden_size, self.w.head_w, self.w.head_b, logits)
         return logits
 
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], images: Sequence[torch.Tensor]

@@ -66,7 +66,7 @@ class SiglipImageProcessor:
             if (self.image_mean, self.image_std) != ([0.5, 0.5, 0.5], [0.5, 0.5, 0.5]) or self.rescale_factor != 1 / 255 \
                     or self.resample != Image.BICUBIC:
                 raise ValueError("the device path implements the SigLIP preprocessor_config (bicubic, 1/255, mean = std = 0.5)")
-            from . import ops
+            from .torch_ops import K as ops
             return BatchFeature(pixel_values=ops.preprocess_u8(images, self.size["height"], torch.float32))
         if isinstance(images, Image.Image):
             images = [images]

@@ -117,7 +117,7 @@ class VideoITG(_Base):
     def score(self, contexts: str, visual):
         """One document: -> (frame ids in descending score order, scores rounded to 2 dp, #visuals)."""
         from PIL import Image
-        from ... import ops
+        from ...torch_ops import K as ops
         if isinstance(visual, Image.Image):
             frames, sampled = [visual], [0]
         else:

@@ -181,7 +181,7 @@ class EagleQwenG(nn.Module):
                 return SelectorOutput(logits=logits)
             # labelled evaluation (grounding_qwen2.py:159-181): the loss VALUE (no backward here), and - as in the reference -
             # `logits` becomes the flat fp32 concatenation over the batch instead of the per-video list
-            from .. import ops
+            from ..torch_ops import K as ops
             flat = torch.cat([l.float().view(-1) for l in logits])
             lab = torch.cat([torch.as_tensor(g).view(-1) for g in grounding_labels]).to(flat.device, torch.float32)
             loss, _ = ops.bce_loss(flat, lab)

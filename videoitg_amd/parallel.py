@@ -84,7 +84,7 @@ class RowGatherer:
         if local.is_cuda:
             # ragged shards (the prompt tokens sit on the first / last rank): ONE gather-rows launch compacts the padded
             # receive buffer instead of `world` slice copies
-            from . import ops
+            from .torch_ops import K as ops
             if self._idx is None:
                 idx = torch.cat([torch.arange(p.n_local[r], dtype=torch.int32) + r * self.n_max for r in range(p.world)])
                 self._idx = idx.to(local.device)
@@ -112,7 +112,7 @@ class ContextParallel:
     def forward(self, eng, input_ids: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
         """input_ids [1, L] (one <image>), pix [T,3,R,R] resident on every rank (only the local frames are read)
         -> logits fp32 [T] on every rank."""
-        from . import ops
+        from .torch_ops import K as ops
         cfg = eng.cfg
         ids = input_ids.reshape(-1).cpu()
         pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()

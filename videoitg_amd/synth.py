@@ -185,6 +185,14 @@ def synth_prompt_ids(length: int, vocab_size: int, seed: int = 4321) -> torch.Te
     return torch.randint(0, hi, (length,), generator=g, dtype=torch.long)
 
 
+def workload_inputs(cfg: ITGConfig, T: int, R: int, prompt_len: int, pix_seed: int = 1234):
+    """(input_ids int64 [1, 1+L], pixel_values fp32 [T,3,R,R]) - the synthetic inputs of SURVEY.md §8(d): `<image>` followed by
+    `prompt_len` seeded token ids; low-pass-filtered pixels in [-1,1], exactly representable in bf16 and fp16.  bench.py, the GPU
+    parity tests and the full-size oracle fixtures (tests/golden/full_*.json) all start from this one function."""
+    ids = torch.cat([torch.tensor([-200]), synth_prompt_ids(prompt_len, cfg.vocab_size)]).unsqueeze(0)
+    return ids, synth_pixel_values(T, R, seed=pix_seed)
+
+
 def synth_video_frames(seed: int, T: int, H: int, W: int):
     """uint8 [T,H,W,3] decoded-frame stand-in (numpy): noise blended with a smooth gradient, plus a full-contrast band so
     that the bicubic resize both interpolates mid-range values and overshoots into the [0, 255] clip."""

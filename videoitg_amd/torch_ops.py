@@ -1,0 +1,168 @@
+"""``torch.ops.videoitg.*`` — the kernels of libvideoitg_hip.so registered with the PyTorch dispatcher (SURVEY.md §8b last
+row: "PyTorch-ROCm custom ops ... schema-typed, stream-ordered on the current HIP stream, no host sync, errors ->
+RuntimeError").
+
+A thin layer: every op's CUDA(=HIP) implementation is the ctypes wrapper of ``videoitg_amd.ops`` over the same C ABI
+(include/videoitg_hip.h); nothing is computed here.  Schemas carry the mutation annotations (``Tensor(a!)``) so that the
+dispatcher, functionalisation and ``torch.compile`` see which buffers an op writes; Meta ("fake") implementations give the
+output shapes so the ops trace without running.  There is deliberately NO CPU registration: calling an op on host tensors
+raises ``NotImplementedError`` from the dispatcher (the product has no CPU path).
+
+``SelectorEngine`` launches through this module (``videoitg_amd.engine.K``); ``videoitg_amd.ops`` stays the raw binding.
+Names are the build's choice: patchify, gemm, layernorm, rmsnorm, rope_, attention, bilinear_pool,
+gather_rows, embed_gather, pool_score, rank, preprocess_u8, bce_loss.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops as _raw
+
+_lib = torch.library.Library("videoitg", "DEF")
+_T = torch.Tensor
+
+
+def _def(schema: str, impl, fake=None):
+    name = schema.split("(", 1)[0]
+    _lib.define(schema)
+    _lib.impl(name, impl, "CUDA")
+    if fake is not None:
+        torch.library.register_fake(f"videoitg::{name}", fake)
+
+
+_DT = {0: torch.bfloat16, 1: torch.float16, 2: torch.float32}
+
+# ---- patch embedding ---------------------------------------------------------------------------------------------------
+_def("patchify(Tensor pix, int patch, int kpad, int dtype) -> Tensor",
+     lambda pix, patch, kpad, dtype: _raw.patchify(pix, patch, kpad, _DT[dtype]),
+     lambda pix, patch, kpad, dtype: pix.new_empty((pix.shape[0] * (pix.shape[2] // patch) ** 2, kpad), dtype=_DT[dtype]))
+
+# ---- GEMM with fused epilogue --------------------------------------------------------------------------------------------
+_def("gemm(Tensor a, Tensor w, Tensor(a!) out, int mode, int? n=None, Tensor? bias=None, int act=0, Tensor? res=None, "
+     "int res_mod=0, int? m=None) -> ()",
+     lambda a, w, out, mode, n=None, bias=None, act=0, res=None, res_mod=0, m=None:
+         (_raw.gemm(a, w, out, mode=mode, n=n, bias=bias, act=act, res=res, res_mod=res_mod, m=m), None)[1],
+     lambda a, w, out, mode, n=None, bias=None, act=0, res=None, res_mod=0, m=None: None)
+
+# ---- norms / rope ----------------------------------------------------------------------------------------------------------
+_def("layernorm(Tensor x, Tensor w, Tensor b, Tensor(a!) out, int d, float eps) -> ()",
+     lambda x, w, b, out, d, eps: (_raw.layernorm(x, w, b, out, d, eps), None)[1], lambda x, w, b, out, d, eps: None)
+_def("rmsnorm(Tensor x, Tensor w, Tensor(a!) out, int d, float eps) -> ()",
+     lambda x, w, out, d, eps: (_raw.rmsnorm(x, w, out, d, eps), None)[1], lambda x, w, out, d, eps: None)
+_def("rope_(Tensor(a!) qkv, Tensor cos, Tensor sin, int heads, int head_dim) -> ()",
+     lambda qkv, cos, sin, heads, head_dim: (_raw.rope_(qkv, cos, sin, heads, head_dim), None)[1],
+     lambda qkv, cos, sin, heads, head_dim: None)
+
+# ---- non-causal flash attention ------------------------------------------------------------------------------------------
+_def("attention(Tensor q, Tensor k, Tensor v, Tensor(a!) o, int batch, int heads, int kv_heads, int seq, int head_dim, "
+     "int[] q_strides, int[] k_strides, int[] v_strides, int[] o_strides, float scale, int variant=0, int? kv_seq=None) -> ()",
+     lambda q, k, v, o, batch, heads, kv_heads, seq, head_dim, q_strides, k_strides, v_strides, o_strides, scale, variant=0,
+            kv_seq=None:
+         (_raw.attention(q, k, v, o, batch=batch, heads=heads, kv_heads=kv_heads, seq=seq, head_dim=head_dim, q_strides=q_strides,
+                         k_strides=k_strides, v_strides=v_strides, o_strides=o_strides, scale=scale, variant=variant,
+                         kv_seq=kv_seq), None)[1],
+     lambda *a, **k: None)
+
+# ---- pooling / gathers / head ------------------------------------------------------------------------------------------------
+_def("bilinear_pool(Tensor x, Tensor(a!) out, int T, int G, int HW, int d, Tensor? cmap=None, int pc=0) -> ()",
+     lambda x, out, T, G, HW, d, cmap=None, pc=0: (_raw.bilinear_pool(x, out, T, G, HW, d, cmap, pc), None)[1],
+     lambda *a, **k: None)
+_def("gather_rows(Tensor src, Tensor idx, int rows_per_batch, int batch, Tensor(a!) out, int width) -> ()",
+     lambda src, idx, rows_per_batch, batch, out, width: (_raw.gather_rows(src, idx, rows_per_batch, batch, out, width), None)[1],
+     lambda *a, **k: None)
+_def("embed_gather(Tensor ids, Tensor table, Tensor(a!) out) -> ()",
+     lambda ids, table, out: (_raw.embed_gather(ids, table, out), None)[1], lambda *a, **k: None)
+_def("pool_score(Tensor h, int frames, int tokens_per_frame, int d, Tensor w, Tensor b, Tensor(a!) logits) -> ()",
+     lambda h, frames, tokens_per_frame, d, w, b, logits: (_raw.pool_score(h, frames, tokens_per_frame, d, w, b, logits), None)[1],
+     lambda *a, **k: None)
+_def("rank(Tensor logits) -> (Tensor, Tensor)", lambda logits: _raw.rank(logits),
+     lambda logits: (logits.new_empty(logits.numel()), logits.new_empty(logits.numel(), dtype=torch.int32)))
+_def("bce_loss(Tensor logits, Tensor labels) -> (Tensor, Tensor)", lambda logits, labels: _raw.bce_loss(logits, labels),
+     lambda logits, labels: (logits.new_empty(()), logits.new_empty(())))
+
+# ---- preprocessing front-end ------------------------------------------------------------------------------------------------
+_def("preprocess_u8(Tensor frames, int size, int out_dtype=2) -> Tensor",
+     lambda frames, size, out_dtype=2: _raw.preprocess_u8(frames, size, _DT[out_dtype]),
+     lambda frames, size, out_dtype=2: frames.new_empty((frames.shape[0], 3, size, size), dtype=_DT[out_dtype]))
+
+
+# ---- call-compatible namespace for the engine (same signatures as videoitg_amd.ops) ------------------------------------
+_ops = torch.ops.videoitg
+_CODE = {v: k for k, v in _DT.items()}
+
+
+class _Namespace:
+    """`K.gemm(...)` etc. with the keyword signatures of videoitg_amd.ops, dispatched through torch.ops.videoitg."""
+    GEMM_STORE16, GEMM_F32, GEMM_SWIGLU = _raw.GEMM_STORE16, _raw.GEMM_F32, _raw.GEMM_SWIGLU
+    ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = _raw.ACT_NONE, _raw.ACT_GELU_TANH, _raw.ACT_GELU_ERF
+    pad64 = staticmethod(_raw.pad64)
+
+    @staticmethod
+    def patchify(pix, patch, kpad, dtype):
+        return _ops.patchify(pix, patch, kpad, _CODE[dtype])
+
+    @staticmethod
+    def gemm(a, w, out, *, mode, n=None, bias=None, act=0, res=None, res_mod=0, m=None):
+        _ops.gemm(a, w, out, mode, n, bias, act, res, res_mod, m)
+        return out
+
+    @staticmethod
+    def layernorm(x, w, b, out, d, eps):
+        _ops.layernorm(x, w, b, out, d, eps)
+        return out
+
+    @staticmethod
+    def rmsnorm(x, w, out, d, eps):
+        _ops.rmsnorm(x, w, out, d, eps)
+        return out
+
+    @staticmethod
+    def rope_(qkv, cos, sin, heads, head_dim):
+        _ops.rope_(qkv, cos, sin, heads, head_dim)
+        return qkv
+
+    @staticmethod
+    def attention(q, k, v, o, *, batch, heads, kv_heads, seq, head_dim, q_strides, k_strides, v_strides, o_strides, scale,
+                  variant=0, kv_seq=None):
+        _ops.attention(q, k, v, o, batch, heads, kv_heads, seq, head_dim, list(q_strides), list(k_strides), list(v_strides),
+                       list(o_strides), scale, variant, kv_seq)
+        return o
+
+    @staticmethod
+    def bilinear_pool(x, out, T, G, HW, d, cmap=None, pc=0):
+        _ops.bilinear_pool(x, out, T, G, HW, d, cmap, pc)
+        return out
+
+    @staticmethod
+    def gather_rows(src, idx, rows_per_batch, batch, out, width):
+        _ops.gather_rows(src, idx, rows_per_batch, batch, out, width)
+        return out
+
+    @staticmethod
+    def embed_gather(ids, table, out):
+        _ops.embed_gather(ids, table, out)
+        return out
+
+    @staticmethod
+    def pool_score(h, frames, tokens_per_frame, d, w, b, logits):
+        _ops.pool_score(h, frames, tokens_per_frame, d, w, b, logits)
+        return logits
+
+    @staticmethod
+    def rank(logits):
+        return _ops.rank(logits)
+
+    @staticmethod
+    def bce_loss(logits, labels):
+        return _ops.bce_loss(logits, labels)
+
+    @staticmethod
+    def preprocess_u8(frames, size, out_dtype=torch.float32):
+        return _ops.preprocess_u8(frames, size, _CODE[out_dtype])
+
+
+K = _Namespace()
+OP_NAMES: List[str] = ["patchify", "gemm", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
+                       "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8"]
