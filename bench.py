@@ -48,7 +48,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
                     help="MFMA input type; bf16 = the configuration BASELINE.json names, fp16 = what the reference itself runs (model.half())")
     ap.add_argument("--config", default="full", choices=["full", "tiny"])
-    ap.add_argument("--graph", action="store_true", help="replay the single-GPU step from a captured HIP graph (same kernels; no gain measured)")
+    ap.add_argument("--graph", action="store_true", help="replay the single-GPU step from a captured HIP graph (same kernels)")
+    ap.add_argument("--videos", type=int, default=0,
+                    help="BASELINE.json configs[3]: V concurrent videos PER GPU, each scored by replaying a hipGraph-captured forward "
+                         "(replicas: one model per GPU, no collective on the data path; weak scaling).  0 = the default one-video job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the from-uint8-frames (GPU preprocessing) measurement")
     ap.add_argument("--seed", type=int, default=0)
@@ -200,6 +203,64 @@ def cpu_baseline(cfg, T, R, n_text, threads):
     return out
 
 
+def time_video_replays(eng, cfg, dtype, dev, T, R, prompt_len, n_videos, first_seed, steps, warmup, barrier):
+    """V different videos (own pixels, own prompt of a different length inside one 32-token bucket), each scored by replaying ONE
+    captured graph.  -> (seconds for `steps` passes over the V videos, per-video Top-32 lists of the last pass, #captures)."""
+    from videoitg_amd import ops, synth
+    from videoitg_amd.engine import GraphCache
+    vids = []
+    for i in range(n_videos):
+        ids, px = synth.workload_inputs(cfg, T, R, prompt_len - (i % 8), pix_seed=first_seed + i)
+        vids.append((ids, px.to(dtype).to(dev)))
+    cache = GraphCache(eng)
+
+    def one_pass():
+        outs = [ops.rank(cache(ids, px))[1] for ids, px in vids]
+        return [o.cpu().tolist() for o in outs]            # D2H of the index lists = end of the timed region
+    for _ in range(warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orders = one_pass()
+    barrier()
+    return time.perf_counter() - t0, [sorted(o[:32]) for o in orders], cache.captures
+
+
+def bench_videos(args, cfg, eng, dtype, dev, rank, world, T, R):
+    """--videos V: the batch-of-videos configuration (BASELINE.json configs[3]); mirrors the reference's data parallelism - one
+    model per GPU, documents strided over ranks, no collective (/root/reference/lmms_eval/utils.py:689-695)."""
+    V = args.videos
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+    dt, top32, captures = time_video_replays(eng, cfg, dtype, dev, T, R, args.prompt_len, V, 1234 + rank * V, args.steps, args.warmup, barrier)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        fl = algorithmic_flops(cfg, T, R, args.prompt_len)
+        n = world * V * args.steps
+        print(json.dumps({
+            "metric": "frames scored/sec", "value": round(n * T / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic (random-init weights of the VideoITG-8B architecture, seeded low-pass pixels, 53-60-token prompts)",
+            "config": {"workload": f"batch of {world * V} videos x {T} frames x {R}^2, {V} per GPU, each scored by replaying one "
+                                   f"hipGraph-captured forward ({captures} capture(s) on rank 0: prompts of different length share a 32-token bucket)",
+                       "frames": T, "resolution": R, "videos_per_gpu": V, "parallelism": f"replicas x{world}, no collective",
+                       "algorithmic_tflop_per_video": round(fl["total"] / 1e12, 1)},
+            "end_to_end_tflops": round(fl["total"] * n / dt / 1e12 / world, 1), "top32_first_video": top32[0]}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +297,9 @@ def main():
     ids, pix32 = synth.workload_inputs(cfg, T, R, args.prompt_len)          # 16-bit-exact values: bf16 and fp16 runs see the same pixels
     pix = pix32.to(dtype).to(dev)
     del pix32
+
+    if args.videos > 0:
+        return bench_videos(args, cfg, eng, dtype, dev, rank, world, T, R)
 
     timer = GemmTimer()
     ops.gemm = timer.wrap(ops.gemm)
@@ -300,7 +364,7 @@ def main():
             "metric": "frames scored/sec", "value": round(T / (dt / args.steps), 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic (random-init weights of the VideoITG-8B architecture, uniform pixels, "
+            "dtype": args.dtype, "data": "synthetic (counter-generated random-init weights of the VideoITG-8B architecture, seeded low-pass pixels, "
                                          "60-token prompt)",
             "config": {"workload": f"{T} frames x {R}^2, SigLIP-so400m/14 ({cfg.num_vit_layers_needed()} layers) + seq_mlp "
                                    f"(pool {fl['hw']}x{fl['hw']}) + Qwen2-7B bidirectional ({cfg.num_hidden_layers} layers), "
@@ -348,6 +412,11 @@ def main():
                                                       "unit": "frames/s", "ms_per_step": round(d1 * 1e3, 2),
                                                       "preprocess_ms": round(e0.elapsed_time(e1), 3)}}
             del frames
+            # BASELINE.json configs[3] on one GPU: 4 different videos scored back to back by replaying ONE captured hipGraph
+            # (prompts of different length inside a bucket); `bench.py --videos V [--gpus N]` is the full mode
+            d4, _, ncap = time_video_replays(eng, cfg, dtype, dev, T, R, args.prompt_len, 4, 5000, 1, 1, torch.cuda.synchronize)
+            out["secondary"]["batch_of_videos_graph"] = {"videos": 4, "captures": ncap, "value": round(4 * T / d4, 2), "unit": "frames/s",
+                                                         "ms_per_video": round(d4 / 4 * 1e3, 2)}
             # B0 = 512 frames at the reference-native 384^2 (27x27 grid, no position-embedding interpolation): SURVEY.md 8d
             pix0 = synth.workload_inputs(cfg, T, 384, args.prompt_len)[1].to(dtype).to(dev)
             b0 = {}

@@ -121,6 +121,16 @@ int vitg_attention(const void* q, const void* k, const void* v, void* o, int bat
                    int Sk, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs, int v_rs, int o_rs,
                    int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype, int variant, void* stream);
 
+/* vitg_attention with the number of keys read from DEVICE memory at kernel start: keys [0, min(*kv_len_dev, Sk_max)) are attended,
+ * rows beyond are ignored (their own outputs are still produced and are garbage-in/garbage-out for the caller to discard).
+ * Launch geometry depends only on S, so one captured HIP graph serves every prompt length inside a padded bucket (SURVEY.md
+ * section 7 hard part 6: "key-padding handled inside the attention kernel by length, not mask tensor").  Replaces the same
+ * flash-attn call sites as vitg_attention; the reference strips padding on the host instead (eagle_archv1.py:272). */
+int vitg_attention_dyn(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads, int S,
+                       int Sk_max, const int* kv_len_dev, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs,
+                       int k_rs, int v_rs, int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype, int variant,
+                       void* stream);
+
 /* Bilinear G x G -> HW x HW token pool (align_corners=False, no antialias) of fp32 features [T*G*G, ldx] into
  * 16-bit [T*HW*HW, ldo]; HW == G is a plain cast.  cmap == NULL: x holds all G*G rows per frame; otherwise x holds Pc
  * compact rows per frame and cmap[y*G+x] is the compact row of token (y,x).  Replaces F.interpolate at mlp_proj.py:57-68. */

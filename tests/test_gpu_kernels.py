@@ -399,3 +399,30 @@ def test_gemm_software_tile_loop_bit_identical(ops, dtype, cfg):
             ops.set_option("gemm_flags", 0)
     for got, ref in zip(res[1 << 24], res[0]):
         assert torch.isfinite(got.float()).all() and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,HKV,S,D,real", [(4, 2, 523, 128, 500), (4, 2, 523, 128, 523), (28, 4, 1300, 128, 1237), (2, 2, 729, 72, 700),
+                                            (2, 1, 200, 128, 64), (2, 1, 200, 128, 1)])
+def test_attention_key_count_from_device_memory(ops, attn_waves, dtype, H, HKV, S, D, real):
+    """vitg_attention_dyn: the key count is read from device memory at kernel start; the first `real` query rows must be
+    BIT-identical to a launch whose Sk argument is `real` (same tiles, same tail masking), whatever the rows beyond hold."""
+    B = 1
+    q, k, v = rnd((B, H, S, D), 30, dtype=dtype), rnd((B, HKV, S, D), 31, dtype=dtype), rnd((B, HKV, S, D), 32, dtype=dtype)
+    k[:, :, real:] = 1e4                     # padding rows carry values that would dominate the softmax if they were attended to
+    ld = (H + 2 * HKV) * D
+    flat = torch.cat([q.permute(0, 2, 1, 3).reshape(B, S, H * D), k.permute(0, 2, 1, 3).reshape(B, S, HKV * D),
+                      v.permute(0, 2, 1, 3).reshape(B, S, HKV * D)], -1).to(dtype).cuda().contiguous().view(B * S, ld)
+    st = dict(q_strides=(S * ld, ld, D), k_strides=(S * ld, ld, D), v_strides=(S * ld, ld, D), o_strides=(S * H * D, H * D, D))
+    o_ref = torch.zeros((S, H * D), dtype=dtype, device="cuda")
+    ops.attention(flat, flat[:, H * D:], flat[:, (H + HKV) * D:], o_ref, batch=B, heads=H, kv_heads=HKV, seq=S, kv_seq=real, head_dim=D,
+                  scale=D ** -0.5, **st)
+    o_dyn = torch.zeros((S, H * D), dtype=dtype, device="cuda")
+    n = torch.tensor([real], dtype=torch.int32, device="cuda")
+    ops.attention(flat, flat[:, H * D:], flat[:, (H + HKV) * D:], o_dyn, batch=B, heads=H, kv_heads=HKV, seq=S, kv_seq=S, head_dim=D,
+                  scale=D ** -0.5, kv_len=n, **st)
+    assert torch.isfinite(o_dyn[:real].float()).all()
+    assert torch.equal(o_dyn, o_ref)
+    want = ref_attention(q[:, :, :real], k[:, :, :real], v[:, :, :real], D ** -0.5)
+    got = o_dyn[:real].float().cpu().view(1, real, H, D).permute(0, 2, 1, 3)
+    assert (got - want).abs().max().item() <= 6 * EPS16[dtype] * v.abs().max().item()

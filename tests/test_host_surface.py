@@ -111,3 +111,22 @@ def test_image_processor_matches_siglip_definition():
     assert np.abs(exact[0].numpy() - ((sq[0].astype(np.float32) / 255 - 0.5) / 0.5).transpose(2, 0, 1)).max() < 1e-6
     with pytest.raises(ValueError):
         p.preprocess(frames, return_tensors="tf")
+
+
+def test_model_object_survives_accelerate_wrap_on_cpu():
+    """lmms_eval/models/videoitg.py:193-205: accelerator.prepare_model(model, evaluation_mode=True).  No GPU here: the wrap must keep
+    the operator surface intact and the forward must still fail loudly (there is no CPU path to fall back to)."""
+    import pytest
+    import torch
+    from accelerate import Accelerator
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.model.grounding_qwen2 import EagleQwenG
+    cfg = tiny_config()
+    m = EagleQwenG(cfg, synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0), torch.float16, "cuda:0")
+    w = Accelerator(cpu=True).prepare_model(m, evaluation_mode=True)
+    w.eval()
+    w.tie_weights()
+    assert w.config is cfg and w.get_vision_tower().image_processor is not None
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        w(torch.tensor([[-200, 5]]), attention_mask=None, images=[torch.zeros(2, 3, 56, 56)])

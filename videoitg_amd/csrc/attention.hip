@@ -19,7 +19,8 @@
 namespace vitg {
 
 template <typename T, int D, bool TR, int NW, bool ABL = false, bool PIPE = false, bool DMA = false>
-__global__ __launch_bounds__(NW * 64, (NW == 8 && D == 72 && DMA) ? 4 : 2) void attn_kernel(AttnArgs a) {   // (256,3) for hd72 spills: 548 -> 428 TF/s
+__global__ __launch_bounds__(NW * 64, (NW == 8 && D == 72 && DMA) ? 4 : 2) void attn_kernel(AttnArgs a) {
+    adopt_device_key_count(a);   // (256,3) for hd72 spills: 548 -> 428 TF/s
     const int ablate = ABL ? a.ablate : 0;      // ablation switches exist only in the profiling instantiation
     constexpr int ATT_THREADS = NW * 64, ATT_BQ = NW * 32;
     typedef typename T16<T>::vec8 vec8;
@@ -457,10 +458,10 @@ int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, hi
 
 using namespace vitg;
 
-extern "C" int vitg_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads,
-                              int S, int Sk, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs,
-                              int v_rs, int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype,
-                              int variant, void* stream) {
+static int attention_entry(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads,
+                           int S, int Sk, const int* sk_dev, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs,
+                           int v_rs, int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype,
+                           int variant, void* stream) {
     if (batch <= 0 || heads <= 0 || S <= 0) return 0;
     if (Sk <= 0) return VITG_ERR_SHAPE;
     if (kv_heads <= 0 || heads % kv_heads) return VITG_ERR_SHAPE;
@@ -473,7 +474,7 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
     a.q_rs = q_rs; a.k_rs = k_rs; a.v_rs = v_rs; a.o_rs = o_rs;
     a.q_hs = q_hs; a.k_hs = k_hs; a.v_hs = v_hs; a.o_hs = o_hs;
-    a.S = S; a.Sk = Sk; a.group = heads / kv_heads; a.kv_heads = kv_heads; a.nqb = 0;
+    a.S = S; a.Sk = Sk; a.sk_dev = sk_dev; a.group = heads / kv_heads; a.kv_heads = kv_heads; a.nqb = 0;
     a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -525,4 +526,21 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
     else rc = head_dim == 72 ? GO(f16_t, 72) : GO(f16_t, 128);
 #undef GO
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+}
+
+extern "C" int vitg_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads,
+                              int S, int Sk, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs,
+                              int v_rs, int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype,
+                              int variant, void* stream) {
+    return attention_entry(q, k, v, o, batch, heads, kv_heads, S, Sk, nullptr, head_dim, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs,
+                           q_hs, k_hs, v_hs, o_hs, scale, dtype, variant, stream);
+}
+
+extern "C" int vitg_attention_dyn(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads,
+                                  int S, int Sk_max, const int* kv_len_dev, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs,
+                                  int q_rs, int k_rs, int v_rs, int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale,
+                                  int dtype, int variant, void* stream) {
+    if (!kv_len_dev) return VITG_ERR_ARG;
+    return attention_entry(q, k, v, o, batch, heads, kv_heads, S, Sk_max, kv_len_dev, head_dim, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs,
+                           o_rs, q_hs, k_hs, v_hs, o_hs, scale, dtype, variant, stream);
 }

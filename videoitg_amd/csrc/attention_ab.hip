@@ -22,6 +22,7 @@ constexpr float AB_LAZY_RESCALE_LOG2 = 8.0f;      // see attention_sp.hip: runni
 
 template <typename T, int D, int NW>
 __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
+    adopt_device_key_count(a);
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
     constexpr int KS = C::DK / 16;           // QK^T k-steps per 32-key half

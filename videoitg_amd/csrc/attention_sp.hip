@@ -39,6 +39,7 @@ constexpr float LAZY_RESCALE_LOG2 = 8.0f;
 
 template <typename T, int D, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
+    adopt_device_key_count(a);
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
     constexpr int KS = C::DK / 16;           // QK^T k-steps per 32-key half

@@ -11,11 +11,18 @@ struct AttnArgs {
     int q_hs, k_hs, v_hs, o_hs;      // head strides (elements)
     int S;                           // number of queries
     int Sk;                          // number of keys (== S unless the keys were all-gathered from other ranks)
+    const int* sk_dev;               // optional: the number of keys lives in device memory (<= Sk); lets ONE captured graph serve
+                                     // prompts of different length inside a bucket (vitg_attention_dyn)
     int group;                       // q heads per kv head
     int kv_heads, nqb;               // kv heads, q-blocks per head
     int ablate;                      // profiling only (tools/attn_ablate.py): bit0 no QK^T, bit1 no exp, bit2 no PV, bit3 no K/V staging
     float scale_log2e;               // softmax scale * log2(e)
 };
+
+// first statement of every attention kernel: adopt the device-side key count (wave-uniform scalar load)
+__device__ __forceinline__ void adopt_device_key_count(AttnArgs& a) {
+    if (a.sk_dev) a.Sk = min(a.Sk, max(1, __builtin_amdgcn_readfirstlane(*a.sk_dev)));
+}
 
 constexpr int ATT_BK = 64;
 // NW waves per block, 32 queries per wave: BQ = 32*NW queries share one K/V staging stream (NW = 8: 256 queries, 1 block/CU;

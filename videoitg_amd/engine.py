@@ -303,9 +303,12 @@ class SelectorEngine:
         return self._rope[n]
 
     # ---- A11: bidirectional Qwen2 stack over fp32 x [N, D] (in place) -> final-normed fp32 -------------
-    def llm_forward(self, x: torch.Tensor, pos0: int = 0, total: Optional[int] = None, kv_gather=None) -> torch.Tensor:
+    def llm_forward(self, x: torch.Tensor, pos0: int = 0, total: Optional[int] = None, kv_gather=None,
+                    kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: this rank's rows (all rows on one GPU).  Context-parallel use (videoitg_amd.parallel): pos0 = global
-        position of row 0, total = global token count, kv_gather(local K|V rows) -> all K|V rows."""
+        position of row 0, total = global token count, kv_gather(local K|V rows) -> all K|V rows.
+        kv_len (int32 device scalar, single-GPU path): only the first kv_len rows are real tokens - the rest is bucket padding
+        that no query may attend to (a captured graph serves every prompt length of its bucket)."""
         cfg, w = self.cfg, self.w
         N, D = x.shape
         total = N if total is None else total
@@ -328,7 +331,7 @@ class SelectorEngine:
             if kv_gather is None:
                 K.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
                               head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
-                              o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
+                              o_strides=(0, op, hd), scale=scale, variant=self.attn_variant, kv_len=kv_len)
             else:
                 kv = kv_gather(qkv[:, nq * hd:])                 # [total, 2*nkv*hd]: K heads then V heads per row
                 K.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
@@ -344,10 +347,11 @@ class SelectorEngine:
 
     # ---- whole path for one sample whose frames are already encoded ---------------------------------
     def score_video(self, feats: torch.Tensor, T: int, G: int, ids: torch.Tensor, cmap: Optional[torch.Tensor] = None,
-                    pc: int = 0, ids_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    pc: int = 0, ids_dev: Optional[torch.Tensor] = None, kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         """feats fp32 [T*P, Dv] (this video's rows), ids HOST int64 [L] (unpadded, one IMAGE_TOKEN_INDEX) ->
         logits fp32 [T].  ids_dev: the same ids already on the device (graph capture: no host-to-device copy may be
-        recorded; only the text VALUES are read from it, the layout comes from the host copy)."""
+        recorded; only the text VALUES are read from it, the layout comes from the host copy).  kv_len: see llm_forward - with it,
+        `ids` is the BUCKET-PADDED prompt (pad ids after the real text) and the device scalar holds the real token count."""
         cfg = self.cfg
         ids = ids.cpu()
         pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
@@ -372,7 +376,7 @@ class SelectorEngine:
         if post.numel():
             src = ids_dev[pos[0] + 1:pos[0] + 1 + post.numel()] if ids_dev is not None else post.contiguous().to(self.device)
             K.embed_gather(src, self.w.embed, x[pre.numel() + nv:])
-        hfin = self.llm_forward(x)
+        hfin = self.llm_forward(x, kv_len=kv_len)
         logits = torch.empty(T, dtype=torch.float32, device=self.device)
         K.pool_score(hfin[pre.numel():], T, hw * hw, cfg.hidden_size, self.w.head_w, self.w.head_b, logits)
         return logits
@@ -412,22 +416,39 @@ class SelectorEngine:
         return out
 
 
+def prompt_bucket(n_post: int, bucket: int) -> int:
+    """text tokens after <image>, rounded up to the capture bucket (at least one bucket)"""
+    return max(bucket, (n_post + bucket - 1) // bucket * bucket)
+
+
 class GraphedForward:
     """One video's selector forward captured in a HIP graph (torch.cuda.CUDAGraph) and replayed: ~850 kernel launches become
-    one graph launch.  The capture is keyed by what fixes the launch geometry - frame count, resolution, prompt length and
-    the position of <image> - while the pixel values and the prompt token VALUES are read from static device buffers that
-    are refreshed before every replay.  (BASELINE.json's batch-of-videos configuration asks for a graph-captured per-video
-    forward; at one video per GPU the launch gaps are not what limits the step - tools/cp_rank_time.py measures replay =
-    stream launches within 0.3 % - so this is an option, not the default path.)"""
+    one graph launch (BASELINE.json configs[3]: "hipGraph-captured per-video forward").
 
-    def __init__(self, eng: "SelectorEngine", input_ids: torch.Tensor, pix: torch.Tensor):
-        self.eng = eng
+    The capture is keyed by what fixes the launch geometry: frame count, resolution, the number of text tokens before <image> and
+    the BUCKET of the text length after it.  Pixel values, prompt token VALUES and the real token count are read from static
+    device buffers refreshed before every replay; rows between the real prompt end and the bucket end are padding that the
+    attention kernels exclude by length (vitg_attention_dyn reads the key count from device memory), so one capture serves every
+    prompt of its bucket with results identical to the unpadded eager forward (SURVEY.md section 7 hard part 6)."""
+
+    def __init__(self, eng: "SelectorEngine", input_ids: torch.Tensor, pix: torch.Tensor, bucket: int = 32):
+        self.eng, self.bucket = eng, bucket
         ids = input_ids.reshape(-1).cpu()
-        self.layout = (tuple((ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()), ids.numel(), tuple(pix.shape))
-        self.ids_host = ids.clone()
-        self.ids_dev = ids.clamp(min=0).to(eng.device)                   # <image> slot is never read
-        self.pix = pix.to(eng.device).clone()
+        self.key = self.layout_key(eng, ids, pix, bucket)
+        n_pre, n_post_b, _ = self.key
         T = pix.shape[0]
+        G = pix.shape[-1] // eng.cfg.vision.patch_size
+        self.nv = T * eng.cfg.pooled_grid(T, G) ** 2
+        lim = eng.cfg.tokenizer_model_max_length
+        if lim is not None and n_pre + self.nv + n_post_b > lim:
+            raise ValueError("prompt bucket exceeds tokenizer_model_max_length; use the eager forward (it truncates like the reference)")
+        # host-side layout of the padded prompt: [pre][<image>][post padded to the bucket]; the values live on the device
+        self.ids_layout = torch.cat([torch.zeros(n_pre, dtype=torch.long), torch.tensor([IMAGE_TOKEN_INDEX]),
+                                     torch.zeros(n_post_b, dtype=torch.long)])
+        self.ids_dev = torch.zeros(n_pre + 1 + n_post_b, dtype=torch.long, device=eng.device)
+        self.kv_len = torch.zeros(1, dtype=torch.int32, device=eng.device)
+        self.pix = torch.empty_like(pix, device=eng.device)
+        self._stage(ids, pix)
         self._run()                                                       # eager warm-up: allocates every workspace buffer
         torch.cuda.synchronize(eng.device)
         self.graph = torch.cuda.CUDAGraph()
@@ -441,23 +462,63 @@ class GraphedForward:
         self._held = eng.workspace_tensors()                              # the graph replays on exactly these allocations
         assert self.out.shape == (T,)
 
+    @staticmethod
+    def layout_key(eng, ids: torch.Tensor, pix: torch.Tensor, bucket: int):
+        ids = ids.reshape(-1)
+        pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
+        if len(pos) != 1:
+            raise ValueError(f"exactly one <image> token per sample is supported on the selector path, got {len(pos)}")
+        return (pos[0], prompt_bucket(ids.numel() - pos[0] - 1, bucket), tuple(pix.shape))
+
+    def _stage(self, ids: torch.Tensor, pix: torch.Tensor) -> None:
+        """refresh the static inputs (stream-ordered copies; nothing here is captured)"""
+        n_pre, n_post_b, _ = self.key
+        ids = ids.reshape(-1)
+        padded = torch.zeros(n_pre + 1 + n_post_b, dtype=torch.long)
+        padded[:ids.numel()] = ids.clamp(min=0)                            # the <image> slot is never read
+        self.ids_dev.copy_(padded, non_blocking=True)
+        self.kv_len.fill_(n_pre + self.nv + ids.numel() - n_pre - 1)
+        self.pix.copy_(pix, non_blocking=True)
+
     def _run(self) -> torch.Tensor:
         eng = self.eng
         T = self.pix.shape[0]
         G0 = self.pix.shape[-1] // eng.cfg.vision.patch_size
         hw = eng.cfg.pooled_grid(T, G0)
         feats, G, cmap, pc = eng.vit_forward(self.pix, hw)
-        return eng.score_video(feats, T, G, self.ids_host, cmap, pc, ids_dev=self.ids_dev)
+        return eng.score_video(feats, T, G, self.ids_layout, cmap, pc, ids_dev=self.ids_dev, kv_len=self.kv_len)
 
     def matches(self, input_ids: torch.Tensor, pix: torch.Tensor) -> bool:
-        ids = input_ids.reshape(-1).cpu()
-        return self.layout == (tuple((ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()), ids.numel(), tuple(pix.shape))
+        try:
+            return self.key == self.layout_key(self.eng, input_ids.cpu(), pix, self.bucket)
+        except ValueError:
+            return False
 
     def __call__(self, input_ids: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
-        """-> logits fp32 [T] (a fresh tensor); the layout must be the captured one"""
+        """-> logits fp32 [T] (a fresh tensor); the layout must be inside the captured bucket"""
         if not self.matches(input_ids, pix):
-            raise ValueError("GraphedForward: frame count, resolution, prompt length and <image> position must equal the captured ones")
-        self.ids_dev.copy_(input_ids.reshape(-1).clamp(min=0), non_blocking=True)
-        self.pix.copy_(pix, non_blocking=True)
+            raise ValueError("GraphedForward: frame count, resolution, <image> position and prompt-length bucket must equal the captured ones")
+        self._stage(input_ids.cpu(), pix)
         self.graph.replay()
         return self.out.clone()
+
+
+class GraphCache:
+    """Captured forwards keyed by layout (frames, resolution, <image> position, prompt bucket), least-recently-used eviction.
+    A harness run over one benchmark (fixed num_frames, prompts of 20-120 tokens) needs a handful of captures."""
+
+    def __init__(self, eng: "SelectorEngine", bucket: int = 32, max_entries: int = 8):
+        self.eng, self.bucket, self.max_entries = eng, bucket, max_entries
+        self._graphs: Dict[tuple, GraphedForward] = {}
+        self.captures = 0
+
+    def __call__(self, input_ids: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
+        key = GraphedForward.layout_key(self.eng, input_ids.cpu(), pix, self.bucket)
+        g = self._graphs.pop(key, None)
+        if g is None:
+            if len(self._graphs) >= self.max_entries:
+                self._graphs.pop(next(iter(self._graphs)))
+            g = GraphedForward(self.eng, input_ids, pix, self.bucket)
+            self.captures += 1
+        self._graphs[key] = g                                              # (re-)inserted last = most recently used
+        return g(input_ids, pix)

@@ -12,6 +12,7 @@ libvideoitg_hip.so through ``SelectorEngine`` and there is no fallback when that
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
 
@@ -91,6 +92,10 @@ class EagleQwenG(nn.Module):
         self._device = torch.device(device)
         self._engine: Optional[SelectorEngine] = None
         self._tower = _VisionTowerHandle(config)
+        # opt-in: replay single-video forwards from captured HIP graphs keyed by (frames, resolution, prompt bucket)
+        # (engine.GraphCache; BASELINE.json configs[3]).  VITG_GRAPHS=1 or model.use_graphs = True.
+        self.use_graphs = os.environ.get("VITG_GRAPHS", "0") not in ("", "0")
+        self._graphs = None
 
     # ---- chaining the callers do ---------------------------------------------------------------
     def _set(self, dtype=None, device=None):
@@ -176,7 +181,17 @@ class EagleQwenG(nn.Module):
             raise NotImplementedError("dpo / inputs_embeds branches are outside the inference hot path")
         eng = self.engine()
         with torch.cuda.device(self._device):
-            logits = eng.forward(input_ids, attention_mask, list(images))
+            images = list(images)
+            single = len(images) == 1 and (input_ids.dim() == 1 or input_ids.shape[0] == 1) and \
+                (attention_mask is None or bool(attention_mask.all()))
+            if self.use_graphs and single and grounding_labels is None:
+                if self._graphs is None or self._graphs.eng is not eng:
+                    from ..engine import GraphCache
+                    self._graphs = GraphCache(eng)
+                im = images[0] if images[0].dim() == 4 else images[0].unsqueeze(0)
+                lg = self._graphs(input_ids.reshape(-1), im.to(self._device, self._dtype))
+                return SelectorOutput(logits=[lg.reshape(-1, 1)])
+            logits = eng.forward(input_ids, attention_mask, images)
             if grounding_labels is None:
                 return SelectorOutput(logits=logits)
             # labelled evaluation (grounding_qwen2.py:159-181): the loss VALUE (no backward here), and - as in the reference -
