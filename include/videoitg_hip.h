@@ -43,22 +43,18 @@ int vitg_version(void);
 int vitg_device_info(char* name, int name_len);
 
 /* Kernel-selection knobs for A/B measurements and tests; 0 = the measured default everywhere.  Defaults can also come from
- * the environment (VITG_<KEY IN CAPS>).  Host-only, no GPU needed.  Keys:
- *   gemm_tile   128 | 256                       force the 128x128 register-staged or the 256-wide LDS-DMA kernels
- *   gemm_cfg    1 256x256x32 ring-4 | 2 256x128x32 | 3 256x256x64 ring-2 | 4 persistent | 5 asm LDS reads | 6 phased (default
- *               for >= 160 tiles) | 7 phased, 2 k-steps per interval | 8 four waves x 128x128 (AGPR accumulators) |
- *               9 256x384 (default for fp32-residual shapes) | 10 384x256 (default for SwiGLU) | 11 register-staged operands |
- *               13 persistent blocks with a deferred epilogue (16-bit-output and SwiGLU GEMMs; opt-in)
+ * the environment (VITG_<KEY IN CAPS>).  Host-only, no GPU needed.  Keys of the PRODUCT library:
+ *   gemm_tile   128 | 256      force the 128x128 register-staged or the 256-wide LDS-DMA kernels
+ *   gemm_cfg    2 256x128x32 (2 blocks/CU; small-M shapes) | 6 256x256x64 phased | 9 256x384 (fp32-residual shapes) |
+ *               10 384x256 (SwiGLU, 16-bit outputs); anything else = 6.  Auto mode picks per shape (gemm256.hip: choose_cfg)
  *   gemm_group  M-tiles per group of the XCD-aware tile order (default 4)
- *   gemm_flags  bit0 non-temporal stores (profiling build only: measured +-0), bit5 N-split launch, bit7 5-stage ring for cfg 8, bit8 disable cfg 9/10 auto-selection;
- *               bit20 auto mode uses cfg 13 for 16-bit-output GEMMs with >= 2 tiles per CU, bit21 also for SwiGLU; bit24 one block
- *               per CU walks the tile list inside gemm256 ("software relaunch");
- *               bits 1-4, 6, 9, 15-19, 22-23: profiling ablations (WRONG results or A/B only; need VITG_PROFILING=1, and for the
- *               gemm256 main-loop ones a library built with -DVITG_PROFILING_BUILD=1)
- *   gemm_stagger  persistent kernel (cfg 4): de-phase the XCDs
+ *   gemm_flags  bit8 wide tiles off, bits 11-14 cost-model A/B switches, bit24 one block per CU walks the tile list
  *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
  *   attn_ab     1 | 2  half-tile-out-of-phase hd-72 kernel on / off (default on)
- *   attn_sp     1 | 2  software-pipelined kernel on (both head sizes) / off (default: on for hd 128) */
+ *   attn_sp     1 | 2  software-pipelined kernel on (both head sizes) / off (default: on for hd 128)
+ * The research configurations of round 1 (gemm_cfg 1/3/4/5/7/8/11/13, fragment-packed weights, the ablation switches that produce
+ * WRONG results by design) are NOT in this library: they live in libvideoitg_hip_prof.so (build.sh --profiling,
+ * include/videoitg_hip_profiling.h), which tools/ load and the product never does. */
 int vitg_set_option(const char* key, int value);
 
 /* A0[T*G*G, Kpad] (16-bit) = im2col of pixel_values [T,3,R,R] NCHW (pix_dtype VITG_F32/F16/BF16), k ordered
@@ -78,18 +74,6 @@ int vitg_patchify(const void* pix, int pix_dtype, void* out, int T, int R, int p
 int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, int mode,
               const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
               void* stream);
-
-/* Static-weight fast path of vitg_gemm.  Weights never change between forwards, so they can be stored a second time in the order
- * the MFMA consumes them: vitg_pack_weight_fragments writes, for every (32-row weight tile, 16-deep k-step), one contiguous 1-KiB
- * block whose 16-byte chunk l is W[tile*32 + (l & 31)][kstep*16 + 8*(l >> 5) .. +7] (rows >= N zero; N rounded up to 64).
- * vitg_gemm_wf then fetches whole fragments with coalesced global loads and keeps the weight operand out of LDS
- * (videoitg_amd/csrc/gemm_wf.hip).  Same contract, same results as vitg_gemm (same MFMA, same accumulation order); shapes the
- * fast path does not cover (M or N < 256) run vitg_gemm on W.  Wf may be NULL (= vitg_gemm).  Same reference call sites as
- * vitg_gemm: the weights are the nn.Linear parameters of [3P] modeling_siglip / modeling_qwen2 and mlp_proj.py:31-35. */
-int vitg_weight_fragments_bytes(int N, int K, long* bytes);
-int vitg_pack_weight_fragments(const void* W, int ldw, int N, int K, void* out, void* stream);
-int vitg_gemm_wf(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype, int mode,
-                 const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod, void* stream);
 
 /* Profiling aid (no reference counterpart, not on the product path): launches an MFMA-only kernel (blocks x 512 threads, 16
  * v_mfma_f32_32x32x16 per wave and iteration) whose operands are the 8 fragments of `pool` (8 x 64 lanes x 16 bytes, caller

@@ -58,3 +58,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.VitgError):
         _lib.load()
+
+
+def test_product_library_ships_no_research_scaffolding():
+    """the wrong-results-by-design switches and the opt-in GEMM variants live in libvideoitg_hip_prof.so
+    (include/videoitg_hip_profiling.h); the product library must not export them and the product never loads the other one."""
+    import ctypes
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    assert os.path.basename(_lib.LIB_PATH) == "libvideoitg_hip.so" and not _lib.PROFILING
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in _lib.PROFILING_SIGNATURES:
+        assert not hasattr(lib, s), f"{s} belongs to the profiling library only"
+    pkg = os.path.join(ROOT, "videoitg_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py") and f != "_lib.py":
+                assert "libvideoitg_hip_prof" not in open(os.path.join(dp, f)).read(), f

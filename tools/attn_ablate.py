@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ablation timing of the attention kernel (results are WRONG by construction; time only)."""
 import os, sys, torch
-os.environ['VITG_PROFILING'] = '1'          # ablation switches produce wrong results: opt in explicitly
+os.environ['VITG_PROFILING'] = '1'; os.environ.setdefault('VITG_PROFILING_LIB', '1')          # ablation switches produce wrong results: opt in explicitly
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops
 dt = torch.float16

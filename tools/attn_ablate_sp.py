@@ -1,5 +1,5 @@
 import os, sys, torch
-os.environ['VITG_PROFILING'] = '1'          # ablation switches produce wrong results: opt in explicitly
+os.environ['VITG_PROFILING'] = '1'; os.environ.setdefault('VITG_PROFILING_LIB', '1')          # ablation switches produce wrong results: opt in explicitly
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops
 ops.set_option("attn_sp", 1)

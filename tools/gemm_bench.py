@@ -5,7 +5,7 @@ import os
 import sys
 import torch
 
-os.environ.setdefault('VITG_PROFILING', '1')   # lets gemm_flags ablation bits through (they produce wrong results)
+os.environ.setdefault('VITG_PROFILING', '1'); os.environ.setdefault('VITG_PROFILING_LIB', '1')   # lets gemm_flags ablation bits through (they produce wrong results)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops  # noqa: E402

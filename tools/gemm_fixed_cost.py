@@ -1,5 +1,5 @@
 import os, sys, torch
-os.environ.setdefault('VITG_PROFILING', '1')   # lets gemm_flags ablation bits through (they produce wrong results)
+os.environ.setdefault('VITG_PROFILING', '1'); os.environ.setdefault('VITG_PROFILING_LIB', '1')   # lets gemm_flags ablation bits through (they produce wrong results)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops
 for _a in sys.argv[1:]:

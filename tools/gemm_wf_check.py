@@ -1,4 +1,5 @@
 import torch, sys
+import os; os.environ.setdefault('VITG_PROFILING_LIB', '1')   # fragment-packed weights live in the profiling library
 sys.path.insert(0, '/root/repo')
 from videoitg_amd import ops
 torch.manual_seed(0)

@@ -9,7 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvideoitg_hip.so")
+# VITG_PROFILING_LIB=1 (set by tools/, never by the product) selects the profiling build: the same kernels plus the research
+# GEMM variants and ablation switches of include/videoitg_hip_profiling.h
+PROFILING = os.environ.get("VITG_PROFILING_LIB", "0") not in ("", "0")
+LIB_PATH = os.path.join(_HERE, "libvideoitg_hip_prof.so" if PROFILING else "libvideoitg_hip.so")
 
 BF16, F16, F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
@@ -26,9 +29,6 @@ SIGNATURES = {
     "vitg_set_option": [C.c_char_p, _i],
     "vitg_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "vitg_gemm": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
-    "vitg_gemm_wf": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
-    "vitg_weight_fragments_bytes": [_i, _i, C.POINTER(C.c_long)],
-    "vitg_pack_weight_fragments": [_p, _i, _i, _i, _p, _p],
     "vitg_mfma_probe": [_p, _i, _i, _i, _p, C.POINTER(C.c_double), _p],
     "vitg_layernorm": [_p, _i, _p, _p, _p, _i, _i, _l, _i, _f, _p],
     "vitg_rmsnorm": [_p, _i, _p, _p, _i, _i, _l, _i, _f, _p],
@@ -43,6 +43,13 @@ SIGNATURES = {
     "vitg_bce_loss": [_p, _p, _i, _p, _p],
     "vitg_preprocess_tmp_bytes": [_i, _i, _i, _i, C.POINTER(C.c_long)],
     "vitg_preprocess_u8": [_p, _i, _i, _i, _l, _i, _p, _i, _i, _p, _l, _p],
+}
+
+# include/videoitg_hip_profiling.h: only in libvideoitg_hip_prof.so
+PROFILING_SIGNATURES = {
+    "vitg_gemm_wf": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
+    "vitg_weight_fragments_bytes": [_i, _i, C.POINTER(C.c_long)],
+    "vitg_pack_weight_fragments": [_p, _i, _i, _i, _p, _p],
 }
 
 _lib = None
@@ -60,9 +67,10 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise VitgError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            + ("(profiling flavour: `bash videoitg_amd/csrc/build.sh --profiling`) " if PROFILING else "") +
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the selector forward.")
     lib = C.CDLL(LIB_PATH)
-    for name, args in SIGNATURES.items():
+    for name, args in list(SIGNATURES.items()) + (list(PROFILING_SIGNATURES.items()) if PROFILING else []):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = _i

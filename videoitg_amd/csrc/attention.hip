@@ -481,8 +481,12 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     a.ablate = variant >> 4;             // profiling ablations (WRONG results): only in a process that set VITG_PROFILING=1
     variant &= 15;
     if (a.ablate) {
+#if VITG_PROFILING_BUILD
         static const bool profiling = [] { const char* e = getenv("VITG_PROFILING"); return e && atoi(e) != 0; }();
         if (!profiling) return VITG_ERR_ARG;
+#else
+        return VITG_ERR_ARG;              // the product library has no ablation instantiations
+#endif
     }
     const bool tr = variant != 1;
     if (!tr) { }     // variant 1 = scalar LDS reads of V (cross-check path for the tr-read)
@@ -492,11 +496,13 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     const int nw_env = tuning().attn_waves;
     int nw = nw_env ? nw_env : 8;
     if (!nw_env && (long)ceil_div(S, 256) * heads * batch < 384) nw = 4;       // too few 256-query blocks to fill the chip
+#if VITG_PROFILING_BUILD
     if (a.ablate && tuning().attn_sp != 1) {   // profiling instantiations (fp16 only)
         if (dtype != DT_F16) return VITG_ERR_ARG;
         rc = head_dim == 72 ? launch_attn<f16_t, 72, true, 4, true>(a, batch, heads, s) : launch_attn<f16_t, 128, true, 8, true>(a, batch, heads, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
+#endif
 #define GO(T, D) (!tr ? launch_attn<T, D, false, 4>(a, batch, heads, s) : nw == 4 ? launch_attn<T, D, true, 4>(a, batch, heads, s) : launch_attn<T, D, true, 8>(a, batch, heads, s))
     // hd 72: optional cross-tile software-pipelined variant (QK^T of tile t+1 issued before the softmax of tile t).  Measured
     // equal to the plain loop (549 vs 555 TF/s, profiles/r01_attention.md), so it is opt-in: attn_pipe = 1

@@ -1,19 +1,34 @@
 #!/bin/bash
-# Build libvideoitg_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+# Build libvideoitg_hip.so for gfx950 (cross-compiles without a GPU).
+#   build.sh [extra hipcc flags]               product library: shipped kernels only
+#   build.sh --profiling [extra hipcc flags]   libvideoitg_hip_prof.so: + research GEMM variants and ablation switches
+#                                              (include/videoitg_hip_profiling.h); loaded by tools/ only, never by the product
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../libvideoitg_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+SRCS="device gemm gemm256 gemm_fp8 attention attention_sp attention_ab elementwise preprocess probe"
+OUT="$HERE/../libvideoitg_hip.so"
 OBJ="$HERE/build"
+DEFS=""
+if [ "${1:-}" = "--profiling" ]; then
+  shift
+  SRCS="$SRCS gemm_w4 gemm_wf gemm_pe"
+  OUT="$HERE/../libvideoitg_hip_prof.so"
+  OBJ="$HERE/build_prof"
+  DEFS="-DVITG_PROFILING_BUILD=1"
+fi
 mkdir -p "$OBJ"
 pids=()
-for f in device gemm gemm256 gemm_w4 gemm_wf gemm_pe attention attention_sp attention_ab elementwise preprocess probe; do
+objs=()
+for f in $SRCS; do
   src="$HERE/$f.hip"; obj="$OBJ/$f.o"
+  [ -f "$src" ] || continue
+  objs+=("$obj")
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/gemm_common.h" -nt "$obj" ] || [ "$HERE/attn_common.h" -nt "$obj" ] || [ "$HERE/../../include/videoitg_hip.h" -nt "$obj" ]; then
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$src" -o "$obj" "$@" &
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC $DEFS -c "$src" -o "$obj" "$@" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/device.o "$OBJ"/gemm.o "$OBJ"/gemm256.o "$OBJ"/gemm_w4.o "$OBJ"/gemm_wf.o "$OBJ"/gemm_pe.o "$OBJ"/attention.o "$OBJ"/attention_sp.o "$OBJ"/attention_ab.o "$OBJ"/elementwise.o "$OBJ"/preprocess.o "$OBJ"/probe.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
 echo "built $OUT"

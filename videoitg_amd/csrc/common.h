@@ -1,5 +1,8 @@
 // Shared device helpers for the VideoITG gfx950 (CDNA4) kernels.  wave = 64 lanes everywhere.
 #pragma once
+#ifndef VITG_PROFILING_BUILD
+#define VITG_PROFILING_BUILD 0     // 1 only for libvideoitg_hip_prof.so (build.sh --profiling): research variants + ablation switches
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

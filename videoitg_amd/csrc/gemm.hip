@@ -220,6 +220,7 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     // Kernel choice by tile count (measured on the per-rank shapes of the context-parallel LLM, tools/gemm_small_m.py):
     // >= 160 tiles of 256x256 -> 256x256x64 ring-2 (1 block/CU); fewer -> 256x128x32 ring-3 at 2 blocks/CU (twice the tiles,
     // 512 slots) which beat both the 256x256 and the 128x128 kernel there; M < 256 / unaligned cases -> 128x128.
+#if VITG_PROFILING_BUILD
     if (Wf && force != 128 && gemm_wf_applicable(g, mode)) rc = launch_gemm_wf(g, dtype, mode, s);
     // gemm_pe.hip (cfg 13: persistent blocks, deferred epilogue; same bits as the other 256-tile kernels) is opt-in: gemm_cfg 13
     // forces it, gemm_flags bit20 puts auto mode on it for 16-bit-output GEMMs with >= 2 tiles per CU (bit21: SwiGLU too).  It was
@@ -231,7 +232,9 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
                (mode != VITG_GEMM_SWIGLU || (tuning().gemm_flags & 0x200000)) && ceil_div(M, 256) * ceil_div(N, 256) >= 512)) &&
              force != 128 && gemm_pe_applicable(g, mode))
         rc = launch_gemm_pe(g, dtype, mode, s);
-    else if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
+    else
+#endif
+    if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
     else rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
 }
@@ -242,8 +245,10 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
     return gemm_entry(A, lda, W, ldw, nullptr, M, N, K, dtype, mode, bias, act, out, ldo, res, ldr, res_mod, stream);
 }
 
+#if VITG_PROFILING_BUILD
 extern "C" int vitg_gemm_wf(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype,
                             int mode, const float* bias, int act, void* out, int ldo,
                             const float* res, int ldr, int res_mod, void* stream) {
     return gemm_entry(A, lda, W, ldw, Wf, M, N, K, dtype, mode, bias, act, out, ldo, res, ldr, res_mod, stream);
 }
+#endif

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     }   // tile loop
 }
 
+#if VITG_PROFILING_BUILD
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent variant of the 256x256x64 ring-2 configuration: one block per CU walks a static, XCD-contiguous list of
 // tiles.  The K-tile ring simply continues across tile boundaries (the last iteration of a tile prefetches K-tile 0 of the
@@ -684,6 +685,8 @@ static int launch256p(GemmArgs g, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+#endif   // VITG_PROFILING_BUILD (persistent cfg 4)
+
 template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM>
 static int launch256(GemmArgs g, hipStream_t s) {
     constexpr int lds = STAGES * (BM * BK * 2 + BN * BK * 2);
@@ -765,16 +768,23 @@ template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     int cfg = tuning().gemm_cfg;
     if (!cfg) cfg = choose_cfg(g, MODE);
+#if VITG_PROFILING_BUILD
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
+#endif
     if (cfg == 10 && g.M >= 384) return launch256<T, MODE, 256, 2, 2, 64, false, 1, 384>(g, s);               // 384x256x64 phased (wave tile 192x64)
     if (cfg == 9 && MODE != MODE_SWIGLU && g.N >= 384) return launch256<T, MODE, 384, 2, 2, 64, false, 1>(g, s);   // 256x384x64 phased (wave tile 128x96)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
+#if VITG_PROFILING_BUILD
+    // research configurations (profiles/r01_gemm_shapes.md): only in libvideoitg_hip_prof.so
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
     if (cfg == 11) return launch256<T, MODE, 256, 2, 2, 64, false, 3>(g, s);    // 11 = phased, operands staged through registers instead of LDS-DMA
-    if (cfg == 6) return launch256<T, MODE, 256, 2, 2, 64, false, 1>(g, s);     // 6 = phased, 1 k-step per interval
     if (cfg == 7) return launch256<T, MODE, 256, 2, 2, 64, false, 2>(g, s);     // 7 = phased, 2 k-steps per interval
     if (cfg == 5) return launch256<T, MODE, 256, 2, 2, 64, true>(g, s);       // 5 = inline-asm LDS reads + counted lgkmcnt (measured = cfg 3)
+    if (cfg == 3) return launch256<T, MODE, 256, 2, 2, 64, false>(g, s);      // 3 = free-running ring-2 loop
+#endif
+    return launch256<T, MODE, 256, 2, 2, 64, false, 1>(g, s);                  // 6 = phased, 1 k-step per interval
+#if 0
     // N = k*256 + 128 (SigLIP: 1152 = 4.5 tiles, 3456 = 13.5): a 256-wide last tile would be half padding.  Run the k*256
     // columns with the 256x256 kernel and the last 128 columns with the 256x128 kernel (two launches, same stream).
     // Measured: qkv +-0, out-proj -4 %, fc2 +2 % -> off by default (gemm_flags bit5 enables it).
@@ -791,6 +801,7 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
         return launch256<T, MODE, 128, 4, 3, 32>(b, s);
     }
     return launch256<T, MODE, 256, 2, 2, 64, false>(g, s);
+#endif
 }
 
 template <typename T>

@@ -81,7 +81,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: O
         _req(bias, torch.float32)
     if res is not None:
         _req(res, torch.float32)
-    if wf is not None:
+    if wf is not None:                                    # profiling library only (include/videoitg_hip_profiling.h)
         _lib.call("vitg_gemm_wf", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(wf), M, N, K, dt_code(a.dtype), mode, _ptr(bias),
                   act, _ptr(out), out.stride(0), _ptr(res), 0 if res is None else res.stride(0), res_mod, _stream())
         return out
@@ -91,7 +91,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: O
 
 
 def pack_weight_fragments(w: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
-    """MFMA-fragment-ordered copy of w[:n] [N,K] for gemm(..., wf=...) (vitg_pack_weight_fragments)"""
+    """MFMA-fragment-ordered copy of w[:n] [N,K] for gemm(..., wf=...) (vitg_pack_weight_fragments; profiling library only)"""
     import ctypes
     _req(w)
     N = w.shape[0] if n is None else n
