@@ -75,6 +75,27 @@ int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int 
               const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
               void* stream);
 
+/* ---- FP8 weight path (BASELINE.json configs[4]; videoitg_amd/csrc/gemm_fp8.hip) ------------------------------------------------
+ * The reference runs fp16 everywhere (/root/reference/eagle/model/builder.py:59), so this is an additional precision tier of the
+ * same GEMM call sites as vitg_gemm: weights are stored as OCP e4m3fn bytes with one fp32 scale per OUTPUT CHANNEL (quantised
+ * once at load time with vitg_quant_rows_fp8 on the [N,K] weight), activations are quantised PER TOKEN on the fly, and the
+ * matrix pipe runs v_mfma_scale_f32_32x32x64_f8f6f4 (twice the 16-bit rate).  Accumulation, residual stream, norm and softmax
+ * statistics stay fp32; attention stays 16-bit.
+ *
+ * vitg_quant_rows_fp8: out8[m, 0..ldo) = e4m3fn(x[m, :] / scale[m]) with scale[m] = max|x[m, :D]| / 448 (1 for an all-zero row),
+ * round-to-nearest-even, columns D..ldo-1 zeroed.  x: in_dtype VITG_F32 / F16 / BF16, leading dimension ldx ELEMENTS; out8
+ * leading dimension ldo BYTES (multiple of 16).
+ * vitg_norm_quant_fp8: the same quantiser fused behind LayerNorm (b != NULL) or RMSNorm (b == NULL) of the fp32 residual row
+ * (replaces vitg_layernorm / vitg_rmsnorm + a separate quantiser pass); D <= 4096.
+ * vitg_gemm_fp8: out = epilogue( sa[m] * sw[n] * sum_k A8[m,k] W8[n,k] ), epilogue modes / bias / act / res exactly as vitg_gemm;
+ * lda / ldw in BYTES (multiples of 16), K a multiple of 128 (callers zero-pad), N % 8 == 0; out_dtype = type of 16-bit outputs. */
+int vitg_quant_rows_fp8(const void* x, long ldx, int in_dtype, void* out8, long ldo, float* scale, long M, int D, void* stream);
+int vitg_norm_quant_fp8(const float* x, long ldx, const float* w, const float* b, void* out8, long ldo, float* scale, long M, int D,
+                        float eps, void* stream);
+int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const void* W8, int ldw, const float* sw, int M, int N, int K,
+                  int out_dtype, int mode, const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
+                  void* stream);
+
 /* Profiling aid (no reference counterpart, not on the product path): launches an MFMA-only kernel (blocks x 512 threads, 16
  * v_mfma_f32_32x32x16 per wave and iteration) whose operands are the 8 fragments of `pool` (8 x 64 lanes x 16 bytes, caller
  * filled: zeros, random, ...); *flops receives the flop count of the launch.  bench.py times it to report the MFMA rate the

@@ -11,6 +11,12 @@ that DESIGN.md quotes and that tests/test_numerics_budget.py checks on CPU:
   activations all produce 16-bit tensors (matmuls accumulate in fp32 inside the BLAS kernel, flash-attn keeps
   softmax statistics in fp32 and P in 16 bit).
 
+* ``mode="fp8"``: ``"product"`` plus the fp8 weight path of ``videoitg_amd/csrc/gemm_fp8.hip`` (BASELINE.json configs[4]): at the
+  tower / decoder layer GEMMs (qkv, out, fc1, fc2; qkv, o, gate/up, down) the weight is quantised per OUTPUT CHANNEL and the
+  activation per TOKEN to OCP e4m3fn (scale = amax * fp32(1/448), value * (1/scale) rounded to nearest even, clamp +-448), exactly
+  the arithmetic of ``quant_rows_kernel`` / ``norm_quant_kernel``; norm outputs are quantised from their fp32 value (the fused
+  kernel never rounds them to 16 bit), attention / GELU / SwiGLU outputs from their 16-bit value.
+
 Comparing each against the fp32 oracle gives (a) the rounding noise the product SHOULD show if its kernels are
 otherwise exact and (b) the noise the reference's own fp16 run carries.
 """
@@ -34,6 +40,28 @@ class Q:
 
     def every(self, t):    # op-output rounding (reference16 only)
         return self.mm(t) if self.mode == "reference16" else t
+
+    # ---- fp8 weight path: operands of the layer GEMMs -------------------------------------------------------------------
+    def a_norm(self, t):   # a norm output as GEMM operand
+        return q8_rows(t) if self.mode == "fp8" else self.mm(t)
+
+    def a_act(self, t):    # an already 16-bit-rounded activation as GEMM operand
+        return q8_rows(t) if self.mode == "fp8" else t
+
+    def w(self, t):        # a layer GEMM weight (rows = output channels)
+        return q8_rows(t) if self.mode == "fp8" else t
+
+
+_INV448 = torch.tensor(1.0 / 448.0, dtype=torch.float32)
+
+
+def q8_rows(t: torch.Tensor) -> torch.Tensor:
+    """per-row OCP e4m3fn quantise-dequantise with the kernel's arithmetic (fp32): scale = amax * fp32(1/448), q = RNE(x * (1/scale))"""
+    t = t.float()
+    amax = t.abs().amax(-1, keepdim=True)
+    sc = torch.where(amax > 0, amax * _INV448, torch.ones_like(amax))
+    q = (t * (1.0 / sc)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    return q * sc
 
 
 def _attn(q, k, v, scale, qz: Q, q_chunk=1024):
@@ -65,14 +93,14 @@ def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tens
     n_run = v.num_hidden_layers + 1 + cfg.mm_vision_select_layer
     for i in range(n_run):
         p = f"vision_model.encoder.layers.{i}."
-        h = qz.mm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm1.weight"], vsd[p + "layer_norm1.bias"], v.layer_norm_eps))
-        q, k, vv = (qz.mm(F.linear(h, vsd[p + f"self_attn.{n}_proj.weight"], vsd[p + f"self_attn.{n}_proj.bias"]))
+        h = qz.a_norm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm1.weight"], vsd[p + "layer_norm1.bias"], v.layer_norm_eps))
+        q, k, vv = (qz.mm(F.linear(h, qz.w(vsd[p + f"self_attn.{n}_proj.weight"]), vsd[p + f"self_attn.{n}_proj.bias"]))
                     .view(T, -1, H, hd).transpose(1, 2) for n in "qkv")
         o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz)).transpose(1, 2).reshape(T, -1, Dv)
-        x = qz.every(x + qz.every(F.linear(o, vsd[p + "self_attn.out_proj.weight"], vsd[p + "self_attn.out_proj.bias"])))
-        h = qz.mm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm2.weight"], vsd[p + "layer_norm2.bias"], v.layer_norm_eps))
-        f = qz.mm(O.gelu_tanh(qz.every(F.linear(h, vsd[p + "mlp.fc1.weight"], vsd[p + "mlp.fc1.bias"]))))
-        x = qz.every(x + qz.every(F.linear(f, vsd[p + "mlp.fc2.weight"], vsd[p + "mlp.fc2.bias"])))
+        x = qz.every(x + qz.every(F.linear(qz.a_act(o), qz.w(vsd[p + "self_attn.out_proj.weight"]), vsd[p + "self_attn.out_proj.bias"])))
+        h = qz.a_norm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm2.weight"], vsd[p + "layer_norm2.bias"], v.layer_norm_eps))
+        f = qz.mm(O.gelu_tanh(qz.every(F.linear(h, qz.w(vsd[p + "mlp.fc1.weight"]), vsd[p + "mlp.fc1.bias"]))))
+        x = qz.every(x + qz.every(F.linear(qz.a_act(f), qz.w(vsd[p + "mlp.fc2.weight"]), vsd[p + "mlp.fc2.bias"])))
     feats = torch.split(x, [im.shape[0] for im in images], 0)
     # ---- projector
     pre = "model.mm_projector.out_projection."
@@ -97,19 +125,19 @@ def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tens
             cos, sin = qz.mm(cos), qz.mm(sin)            # HF casts the tables to the activation dtype
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
-            h = qz.mm(O.rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps))
-            q = qz.mm(F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"])).view(1, N, nq, hd).transpose(1, 2)
-            k = qz.mm(F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])).view(1, N, nkv, hd).transpose(1, 2)
-            vv = qz.mm(F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])).view(1, N, nkv, hd).transpose(1, 2)
+            h = qz.a_norm(O.rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps))
+            q = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.q_proj.weight"]), sd[p + "self_attn.q_proj.bias"])).view(1, N, nq, hd).transpose(1, 2)
+            k = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.k_proj.weight"]), sd[p + "self_attn.k_proj.bias"])).view(1, N, nkv, hd).transpose(1, 2)
+            vv = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.v_proj.weight"]), sd[p + "self_attn.v_proj.bias"])).view(1, N, nkv, hd).transpose(1, 2)
             q = qz.mm(q * cos + O.rotate_half(q) * sin)
             k = qz.mm(k * cos + O.rotate_half(k) * sin)
             o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz)).transpose(1, 2).reshape(1, N, D)
-            x = qz.every(x + qz.every(F.linear(o, sd[p + "self_attn.o_proj.weight"])))
-            h = qz.mm(O.rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
-            g = qz.every(F.linear(h, sd[p + "mlp.gate_proj.weight"]))
-            u = qz.every(F.linear(h, sd[p + "mlp.up_proj.weight"]))
+            x = qz.every(x + qz.every(F.linear(qz.a_act(o), qz.w(sd[p + "self_attn.o_proj.weight"]))))
+            h = qz.a_norm(O.rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
+            g = qz.every(F.linear(h, qz.w(sd[p + "mlp.gate_proj.weight"])))
+            u = qz.every(F.linear(h, qz.w(sd[p + "mlp.up_proj.weight"])))
             f = qz.mm(qz.every(F.silu(g)) * u)
-            x = qz.every(x + qz.every(F.linear(f, sd[p + "mlp.down_proj.weight"])))
+            x = qz.every(x + qz.every(F.linear(qz.a_act(f), qz.w(sd[p + "mlp.down_proj.weight"]))))
         hfin = qz.every(O.rms_norm(x, sd["model.norm.weight"], cfg.rms_norm_eps))
         tt = tts[b][mask[b]]
         pooled = qz.every(hfin[0][tt == 3].reshape(im.shape[0], -1, D).mean(1))

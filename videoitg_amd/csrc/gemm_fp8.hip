@@ -1,0 +1,397 @@
+// FP8 (OCP e4m3fn) weight path:  C[M,N] = diag(sa) * (A8[M,K] * W8[N,K]^T) * diag(sw)  with the fused epilogues of gemm256.hip.
+//
+//   A8: activations quantised PER TOKEN   (row m:  a = A8[m,:] * sa[m],  sa[m] = amax_m / 448), produced by quant_rows_fp8 /
+//       the fused norm kernels below;
+//   W8: weights quantised PER OUTPUT CHANNEL at load time (row n:  w = W8[n,:] * sw[n]).
+// The matrix pipe runs v_mfma_scale_f32_32x32x64_f8f6f4 (the only fp8 MFMA of gfx950 that runs at twice the 16-bit rate:
+// 64 deep, 16 passes; the carried-forward 32x32x16_fp8_fp8 runs at the bf16 rate) with both block scales pinned to 2^0 - the
+// real scales are per row / per column of the OUTPUT, so they factor out of the K sum and are applied once to the fp32
+// accumulators in the epilogue.
+//
+// Structure = the phased 256xBN kernel of gemm256.hip measured in BYTES: an LDS row is 128 B (= 128 fp8 of K), a k-step is
+// 64 B of it (one MFMA, 32 B per lane = two ds_read_b128), so per K-tile there are 2 k-steps of 8 MFMAs x 64 cycles where the
+// 16-bit kernel has 4 k-steps of 8 MFMAs x 32 cycles: same LDS bytes per MFMA cycle, same DMA bytes per MFMA cycle, same
+// barrier cadence - and twice the flops.  Operands by LDS-DMA (saddr form), 2-stage ring, waves 4-7 one barrier behind waves 0-3
+// so that one wave per SIMD owns the matrix pipe while its sibling reads fragments / issues DMA.
+//
+// Fragment layout of the f8f6f4 MFMA (32x32x64, fp8): lane l holds row (l & 31) and the 32 consecutive K bytes
+// [32 (l >> 5), +32) of the 64-deep step, for A and B alike - so any K order inside the instruction pairs A with B correctly.
+// C/D layout is the shape's (same as 32x32x16): lane (token = l & 31, h = l >> 5) holds features 8 (r >> 2) + 4 h + (r & 3).
+#include "gemm_common.h"
+
+namespace vitg {
+
+struct Gemm8Args {
+    GemmArgs g;               // A / W are fp8 bytes; lda / ldw in BYTES (multiples of 16); K a multiple of 128
+    const float* sa;          // [M] per-token activation scales
+    const float* sw;          // [N] per-output-channel weight scales (row order of W8, i.e. interleaved for SwiGLU)
+};
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int F8_THREADS = 512, F8_ROWB = 128, F8_KS = 2, F8_STAGES = 2;
+
+template <typename T, int MODE, int BM, int BN>
+__global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
+    const GemmArgs& g = ga.g;
+    constexpr int WM = 2, WN = 4;
+    constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+    constexpr int CPR = F8_ROWB / 16;                   // 8 chunks of 16 B per LDS row
+    constexpr int RPI = 1024 / F8_ROWB;                 // 8 rows per 1-KiB DMA instruction
+    constexpr int A_BYTES = BM * F8_ROWB, W_BYTES = BN * F8_ROWB, STAGE = A_BYTES + W_BYTES;
+    constexpr int A_INSTR = A_BYTES / 1024 / 8, W_INSTR = W_BYTES / 1024 / 8, LPT = A_INSTR + W_INSTR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    int tm, tn;
+    block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- LDS-DMA: one instruction = 8 rows x 128 B; lane -> (row = lane / 8, slot = lane % 8); XOR swizzle on the SOURCE chunk
+    auto swz = [](int row) { return (row >> 1) & 7; };
+    const int drow = lane / CPR, dslot = lane % CPR;
+    const char* const a_base = (const char*)g.A + (size_t)m0 * g.lda;
+    const char* const w_base = (const char*)g.W + (size_t)n0 * g.ldw;
+    unsigned a_cur[A_INSTR], w_cur[W_INSTR];
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+        const int R = (wave * A_INSTR + j) * RPI + drow;
+        a_cur[j] = (unsigned)(min(R, g.M - 1 - m0) * g.lda) + (unsigned)((dslot ^ swz(R)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) {
+        const int R = (wave * W_INSTR + j) * RPI + drow;
+        w_cur[j] = (unsigned)(min(R, g.N - 1 - n0) * g.ldw) + (unsigned)((dslot ^ swz(R)) << 4);
+    }
+    auto issue_one = [&](int kt, int j) {
+        char* st = smem + (kt & 1) * STAGE;
+        const size_t koff = (size_t)kt * F8_ROWB;
+        const char* ka = a_base + koff;
+        const char* kw = w_base + koff;
+        unsigned off = j < A_INSTR ? a_cur[j] : w_cur[j - A_INSTR];
+        asm volatile("" : "+v"(off));                  // keeps the saddr + 32-bit voffset form (see gemm256.hip)
+        if (j < A_INSTR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ka + off),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kw + off),
+                                             (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * W_INSTR + j - A_INSTR) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment byte offsets: row*128 + ((chunk ^ swz(row)) << 4), chunk = 4 ks + 2 h (and chunk + 1 = the same address ^ 16)
+    const int frow = lane & 31, fh = lane >> 5;
+    int a_off[F8_KS][2], w_off[F8_KS][2];
+    {
+        const int sw = swz(frow);                       // invariant under row += 32
+#pragma unroll
+        for (int ks = 0; ks < F8_KS; ++ks)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ch = ((ks * 4 + fh * 2 + u) ^ sw) << 4;
+                a_off[ks][u] = (wr * (MT * 32) + frow) * F8_ROWB + ch;
+                w_off[ks][u] = A_BYTES + (wc * (NT * 32) + frow) * F8_ROWB + ch;
+            }
+    }
+    const int nk = g.K / F8_ROWB;
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) issue_one(0, j);
+
+    i32x8 fa[MT], fw[NT];
+    const int one = 0x7F7F7F7F;                         // E8M0 127 = 2^0 in every byte: block scales off
+    const bool grpB = wr == 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grpB) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+#pragma unroll
+        for (int pp = 0; pp < F8_KS; ++pp) {
+            const char* st_ = smem + (kt & 1) * STAGE;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const i32x4v lo = *(const i32x4v*)(st_ + w_off[pp][0] + i * (32 * F8_ROWB));
+                const i32x4v hi = *(const i32x4v*)(st_ + w_off[pp][1] + i * (32 * F8_ROWB));
+                fw[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const i32x4v lo = *(const i32x4v*)(st_ + a_off[pp][0] + i * (32 * F8_ROWB));
+                const i32x4v hi = *(const i32x4v*)(st_ + a_off[pp][1] + i * (32 * F8_ROWB));
+                fa[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                // the next K-tile goes into the other stage (last read one interval ago by the sibling group): half of the pieces
+                // in each of the two read phases
+#pragma unroll
+                for (int j = 0; j < LPT; ++j)
+                    if (j / (LPT / 2) == pp) issue_one(kt + 1, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (pp == F8_KS - 1 && more && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, one, 0, one);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pp == F8_KS - 1 && more && !grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();            // pairs group B's extra barrier
+
+    // ---- dequantise: acc[nt][mt][r] *= sa[token] * sw[feature] ------------------------------------------------------------
+    {
+        float sam[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) sam[mt] = ga.sa[min(m0 + wr * (MT * 32) + mt * 32 + frow, g.M - 1)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int n = n0 + wc * (NT * 32) + nt * 32 + q4 * 8 + fh * 4;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                if (n < g.N) s = *(const f32x4*)(ga.sw + n);          // N % 4 == 0 (checked by the host)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[nt][mt][q4 * 4 + e] *= sam[mt] * s[e];
+            }
+    }
+    // ---- epilogue: the staged full-row stores of gemm_common.h (bias, activation, SwiGLU, fp32 residual) ----------------------
+    __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring before it is reused
+    if constexpr (MODE == MODE_F32) {
+        constexpr int SB = 32 * NT * 128;
+        static_assert(8 * SB <= F8_STAGES * STAGE, "fp32 staging must fit in the ring");
+        epilogue_staged<T, MODE_F32, MT, NT>(g, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+    } else {
+        constexpr int STAGE_BYTES = MT * 32 * (MODE == MODE_SWIGLU ? 1 : NT) * 64;
+        static_assert(8 * STAGE_BYTES <= F8_STAGES * STAGE, "16-bit staging must fit in the ring");
+        epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+    }
+}
+
+template <typename T, int MODE, int BM, int BN>
+static int launch_fp8(Gemm8Args ga, hipStream_t s) {
+    constexpr int lds = F8_STAGES * (BM + BN) * F8_ROWB;
+    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev != done_dev) {
+        (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<T, MODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        done_dev = cur_dev;
+    }
+    ga.g.tiles_m = ceil_div(ga.g.M, BM);
+    ga.g.tiles_n = ceil_div(ga.g.N, BN);
+    ga.g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
+    hipLaunchKernelGGL((gemm_fp8_kernel<T, MODE, BM, BN>), dim3(ga.g.tiles_m * ga.g.tiles_n), dim3(F8_THREADS), lds, s, ga);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_fp8_t(const Gemm8Args& ga, int mode, hipStream_t s) {
+    if (mode == MODE_SWIGLU) return launch_fp8<T, MODE_SWIGLU, 256, 256>(ga, s);
+    if (mode == MODE_F32) return launch_fp8<T, MODE_F32, 256, 256>(ga, s);
+    return launch_fp8<T, MODE_STORE16, 256, 256>(ga, s);
+}
+
+// ---- row quantisers ---------------------------------------------------------------------------------------------------------
+// e4m3fn: max finite 448.  scale = amax / 448 (1 for an all-zero row), q = RNE(x / scale) via v_cvt_pk_fp8_f32 (OCP on gfx950).
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+template <typename TI> __device__ __forceinline__ f32x4 load4(const TI* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    const bf16x4 v = *(const bf16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <> __device__ __forceinline__ f32x4 load4<f16_t>(const f16_t* p) {
+    const f16x4 v = *(const f16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return v;
+}
+
+// one block (256 threads) per row: pass 1 row amax, pass 2 re-reads the (cache-hot) row and writes fp8; pad columns [D, ldo) zeroed
+template <typename TI>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const TI* __restrict__ x, long ldx, unsigned char* __restrict__ out, long ldo,
+                                                         float* __restrict__ scale, int D) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const TI* xr = x + row * ldx;
+    float amax = 0.f;
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        const f32x4 v = load4<TI>(xr + c);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    amax = block_max_256(amax, red);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (threadIdx.x == 0) scale[row] = sc;
+    unsigned* orow = (unsigned*)(out + row * ldo);
+    for (int c = threadIdx.x * 4; c < ldo; c += 1024) {
+        unsigned q = 0;
+        if (c < D) {
+            const f32x4 v = load4<TI>(xr + c);
+            q = pack4_fp8(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+        }
+        orow[c >> 2] = q;
+    }
+}
+
+// LayerNorm / RMSNorm fused with the per-token quantiser: y = norm(x) * w (+ b) in fp32, then amax / fp8 as above.  One block
+// per row, the row is held in registers (D <= 4096: 4 values x 4 per thread).
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_quant_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ b, unsigned char* __restrict__ out, long ldo,
+                                                         float* __restrict__ scale, int D, float eps) {
+    __shared__ float red[4];
+    __shared__ float red2[4];
+    const long row = blockIdx.x;
+    const float* xr = x + row * ldx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 v[4];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x * 4 + i * 1024;
+        v[i] = c < D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s += v[i][e]; ss += v[i][e] * v[i][e]; }
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) { red[wave] = s; red2[wave] = ss; }
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    ss = red2[0] + red2[1] + red2[2] + red2[3];
+    __syncthreads();
+    float mean = 0.f, rstd;
+    if (RMS) rstd = rsqrtf(ss / D + eps);
+    else {
+        mean = s / D;
+        // two-pass variance on the register-resident row (the one-pass form cancels badly on the residual stream's outlier channels)
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = threadIdx.x * 4 + i * 1024;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < D) { const float d = v[i][e] - mean; q += d * d; }
+        }
+        q = wave_sum(q);
+        if (lane == 0) red[wave] = q;
+        __syncthreads();
+        q = red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+        rstd = rsqrtf(q / D + eps);
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x * 4 + i * 1024;
+        if (c < D) {
+            const f32x4 wv = *(const f32x4*)(w + c);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (!RMS) bv = *(const f32x4*)(b + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] = RMS ? wv[e] * (v[i][e] * rstd) : (v[i][e] - mean) * rstd * wv[e] + bv[e];
+                amax = fmaxf(amax, fabsf(v[i][e]));
+            }
+        }
+    }
+    amax = block_max_256(amax, red);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (threadIdx.x == 0) scale[row] = sc;
+    unsigned* orow = (unsigned*)(out + row * ldo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x * 4 + i * 1024;
+        if (c < ldo) orow[c >> 2] = c < D ? pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv) : 0u;
+    }
+}
+
+}  // namespace vitg
+
+using namespace vitg;
+
+extern "C" int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const void* W8, int ldw, const float* sw, int M, int N, int K,
+                             int out_dtype, int mode, const float* bias, int act, void* out, int ldo, const float* res, int ldr,
+                             int res_mod, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || K % F8_ROWB != 0) return VITG_ERR_SHAPE;
+    if ((lda % 16) || (ldw % 16) || lda < K || ldw < K) return VITG_ERR_ALIGN;
+    if (!A8 || !W8 || !sa || !sw || !out) return VITG_ERR_ARG;
+    if (mode < 0 || mode > 2) return VITG_ERR_ARG;
+    if (mode == VITG_GEMM_SWIGLU && (N % 64 != 0)) return VITG_ERR_SHAPE;
+    if (N % 8 != 0 || ldo % 8 != 0 || (res && ldr % 4 != 0)) return VITG_ERR_ALIGN;
+    if (out_dtype != DT_BF16 && out_dtype != DT_F16) return VITG_ERR_DTYPE;     // type of the 16-bit outputs (ignored for VITG_GEMM_F32)
+    Gemm8Args ga;
+    GemmArgs& g = ga.g;
+    g.A = A8; g.lda = lda; g.W = W8; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
+    g.tiles_m = g.tiles_n = 0; g.stagger_ns = 0; g.group_m = 4; g.Wf = nullptr; g.flags = 0;
+    ga.sa = sa; ga.sw = sw;
+    const int rc = out_dtype == DT_BF16 ? launch_fp8_t<bf16_t>(ga, mode, (hipStream_t)stream) : launch_fp8_t<f16_t>(ga, mode, (hipStream_t)stream);
+    return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+}
+
+extern "C" int vitg_quant_rows_fp8(const void* x, long ldx, int in_dtype, void* out8, long ldo, float* scale, long M, int D,
+                                   void* stream) {
+    if (M <= 0) return 0;
+    if (D <= 0 || D % 4 || ldx % 4 || ldo % 16 || ldo < D) return VITG_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)M), blk(256);
+    if (in_dtype == DT_F32) hipLaunchKernelGGL((quant_rows_kernel<float>), grid, blk, 0, s, (const float*)x, ldx, (unsigned char*)out8, ldo, scale, D);
+    else if (in_dtype == DT_BF16) hipLaunchKernelGGL((quant_rows_kernel<bf16_t>), grid, blk, 0, s, (const bf16_t*)x, ldx, (unsigned char*)out8, ldo, scale, D);
+    else if (in_dtype == DT_F16) hipLaunchKernelGGL((quant_rows_kernel<f16_t>), grid, blk, 0, s, (const f16_t*)x, ldx, (unsigned char*)out8, ldo, scale, D);
+    else return VITG_ERR_DTYPE;
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}
+
+extern "C" int vitg_norm_quant_fp8(const float* x, long ldx, const float* w, const float* b, void* out8, long ldo, float* scale,
+                                   long M, int D, float eps, void* stream) {
+    if (M <= 0) return 0;
+    if (D <= 0 || D > 4096 || D % 4 || ldx % 4 || ldo % 16 || ldo < D || ldo > 4096) return VITG_ERR_ALIGN;
+    if (!w) return VITG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)M), blk(256);
+    if (b) hipLaunchKernelGGL((norm_quant_kernel<false>), grid, blk, 0, s, x, ldx, w, b, (unsigned char*)out8, ldo, scale, D, eps);
+    else hipLaunchKernelGGL((norm_quant_kernel<true>), grid, blk, 0, s, x, ldx, w, b, (unsigned char*)out8, ldo, scale, D, eps);
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}

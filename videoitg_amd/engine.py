@@ -37,6 +37,20 @@ def _pad1(b: torch.Tensor, n: int) -> torch.Tensor:
     return b if b.shape[0] == n else F.pad(b, (0, n - b.shape[0]))
 
 
+class Fp8Weight:
+    """[N, pad128(K)] e4m3fn bytes + one fp32 scale per output channel (vitg_quant_rows_fp8 on the packed 16-bit weight)."""
+
+    def __init__(self, w8: torch.Tensor, sw: torch.Tensor):
+        self.w8, self.sw = w8, sw
+
+    @property
+    def shape(self):
+        return self.w8.shape
+
+    def __getitem__(self, rows):
+        return Fp8Weight(self.w8[rows], self.sw[rows])
+
+
 @dataclass
 class VitLayerW:
     ln1_w: torch.Tensor; ln1_b: torch.Tensor
@@ -62,6 +76,7 @@ class PackedWeights:
     cfg: ITGConfig
     dtype: torch.dtype
     device: torch.device
+    fp8: bool = False                               # BASELINE.json configs[4]: tower / decoder GEMM weights as e4m3fn + per-channel scales
     patch_w: torch.Tensor = None; patch_b: torch.Tensor = None
     pos_native: torch.Tensor = None                # fp32 [P0, Dv]
     pos_cache: Dict[int, torch.Tensor] = field(default_factory=dict)
@@ -79,6 +94,16 @@ class PackedWeights:
         rows = w.shape[0] if rows is None else rows
         cols = pad64(w.shape[1]) if cols is None else cols
         return _pad2(w, rows, cols).to(self.dtype).contiguous()
+
+    def _wl(self, w: torch.Tensor, rows: Optional[int] = None):
+        """weight of a tower / decoder layer GEMM: 16-bit, or - on the fp8 weight path - e4m3fn bytes + per-output-channel scales
+        (quantised from the SAME 16-bit-rounded, zero-padded matrix the 16-bit path would multiply with)"""
+        w16 = self._w16(w, rows)
+        if not self.fp8:
+            return w16
+        w8, sw = K.quant_rows_fp8(w16, w16.shape[1], torch.empty((w16.shape[0], K.pad128(w16.shape[1])), dtype=torch.uint8, device=self.device),
+                                  torch.empty(w16.shape[0], dtype=torch.float32, device=self.device))
+        return Fp8Weight(w8, sw)
 
     def _f32(self, t: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
         t = t.to(self.device, torch.float32)
@@ -99,11 +124,11 @@ class PackedWeights:
         qkv_b = torch.cat([vsd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
         self.vit.append(VitLayerW(
             ln1_w=self._f32(vsd[p + "layer_norm1.weight"]), ln1_b=self._f32(vsd[p + "layer_norm1.bias"]),
-            qkv_w=self._w16(qkv_w), qkv_b=self._f32(qkv_b),
-            out_w=self._w16(vsd[p + "self_attn.out_proj.weight"]), out_b=self._f32(vsd[p + "self_attn.out_proj.bias"]),
+            qkv_w=self._wl(qkv_w), qkv_b=self._f32(qkv_b),
+            out_w=self._wl(vsd[p + "self_attn.out_proj.weight"]), out_b=self._f32(vsd[p + "self_attn.out_proj.bias"]),
             ln2_w=self._f32(vsd[p + "layer_norm2.weight"]), ln2_b=self._f32(vsd[p + "layer_norm2.bias"]),
-            fc1_w=self._w16(vsd[p + "mlp.fc1.weight"], rows=fvp), fc1_b=self._f32(vsd[p + "mlp.fc1.bias"], fvp),
-            fc2_w=self._w16(vsd[p + "mlp.fc2.weight"]), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
+            fc1_w=self._wl(vsd[p + "mlp.fc1.weight"], rows=fvp), fc1_b=self._f32(vsd[p + "mlp.fc1.bias"], fvp),
+            fc2_w=self._wl(vsd[p + "mlp.fc2.weight"]), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
         ))
 
     def pack_projector_and_head(self, sd: SD) -> None:
@@ -130,16 +155,16 @@ class PackedWeights:
         gu = torch.cat([g, u], 1).reshape(2 * fp, -1)           # rows: [32 gate | 32 up] repeated
         self.llm.append(LlmLayerW(
             in_ln=self._f32(sd[p + "input_layernorm.weight"]),
-            qkv_w=self._w16(qkv_w), qkv_b=self._f32(qkv_b),
-            o_w=self._w16(sd[p + "self_attn.o_proj.weight"]),
+            qkv_w=self._wl(qkv_w), qkv_b=self._f32(qkv_b),
+            o_w=self._wl(sd[p + "self_attn.o_proj.weight"]),
             post_ln=self._f32(sd[p + "post_attention_layernorm.weight"]),
-            gu_w=self._w16(gu),
-            down_w=self._w16(sd[p + "mlp.down_proj.weight"]),
+            gu_w=self._wl(gu),
+            down_w=self._wl(sd[p + "mlp.down_proj.weight"]),
         ))
 
     @staticmethod
-    def from_state_dicts(cfg: ITGConfig, sd: SD, vsd: SD, dtype: torch.dtype, device) -> "PackedWeights":
-        pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device(device))
+    def from_state_dicts(cfg: ITGConfig, sd: SD, vsd: SD, dtype: torch.dtype, device, fp8: bool = False) -> "PackedWeights":
+        pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device(device), fp8=fp8)
         pw.pack_vision_embeddings(vsd)
         for i in range(cfg.num_vit_layers_needed()):
             pw.pack_vision_layer(vsd, i)
@@ -197,6 +222,36 @@ class SelectorEngine:
     def release_workspace(self) -> None:
         self._ws.clear()
 
+    # ---- GEMM operands: 16-bit tensors, or (e4m3fn bytes, per-token scales) on the fp8 weight path ---------------------------
+    def _norm(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], name: str, d: int, eps: float):
+        """LayerNorm (b given) / RMSNorm of the fp32 residual rows as the A operand of the next GEMM"""
+        M = x.shape[0]
+        if self.w.fp8:
+            a8 = self._buf(name + "_q8", (M, K.pad128(d)), torch.uint8)
+            sa = self._buf(name + "_qs", (M,), torch.float32)
+            K.norm_quant_fp8(x, w, b, a8, sa, d, eps)
+            return a8, sa
+        h = self._buf(name, (M, pad64(d)), self.dtype, zero=True)
+        if b is not None:
+            K.layernorm(x, w, b, h, d, eps)
+        else:
+            K.rmsnorm(x, w, h, d, eps)
+        return h
+
+    def _operand(self, t: torch.Tensor, name: str, d: int):
+        """a 16-bit activation (attention output, GELU / SwiGLU output) as the A operand of the next GEMM"""
+        if not self.w.fp8:
+            return t
+        a8 = self._buf(name + "_q8", (t.shape[0], K.pad128(d)), torch.uint8)
+        sa = self._buf(name + "_qs", (t.shape[0],), torch.float32)
+        K.quant_rows_fp8(t, d, a8, sa)
+        return a8, sa
+
+    def _gemm(self, a, w, out: torch.Tensor, **kw) -> torch.Tensor:
+        if isinstance(w, Fp8Weight):
+            return K.gemm_fp8(a[0], a[1], w.w8, w.sw, out, out_dtype=self.dtype, **kw)
+        return K.gemm(a, w, out, **kw)
+
     # ---- which tokens does the bilinear pool read? (mlp_proj.py:57-68 semantics: align_corners=False) ----------------
     def pool_sources(self, G: int, hw: int):
         """(idx int32 [Pc] sorted token ids y*G+x that carry weight, cmap int32 [G*G] token -> compact row or -1).
@@ -236,7 +291,6 @@ class SelectorEngine:
         x = self._buf("vit_x", (M, Dv), torch.float32)
         K.gemm(a0, w.patch_w, x, mode=K.GEMM_F32, bias=w.patch_b, res=w.pos_table(G), res_mod=P)
         del a0
-        h = self._buf("vit_h", (M, Dvp), self.dtype, zero=True)
         qkv = self._buf("vit_qkv", (M, 3 * Dv), self.dtype)
         o = self._buf("vit_o", (M, Dvp), self.dtype, zero=True)
         f = self._buf("vit_f", (M, Fvp), self.dtype)
@@ -245,15 +299,15 @@ class SelectorEngine:
         full_layers = w.vit if src is None else w.vit[:-1]
         st = (P * 3 * Dv, 3 * Dv, hd)
         for lw in full_layers:
-            K.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
-            K.gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
+            h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, v.layer_norm_eps)
+            self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
             K.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
-                          q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
-                          variant=self.attn_variant)
-            K.gemm(o, lw.out_w, x, mode=K.GEMM_F32, bias=lw.out_b, res=x)
-            K.layernorm(x, lw.ln2_w, lw.ln2_b, h, Dv, v.layer_norm_eps)
-            K.gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
-            K.gemm(f, lw.fc2_w, x, mode=K.GEMM_F32, bias=lw.fc2_b, res=x)
+                        q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
+                        variant=self.attn_variant)
+            self._gemm(self._operand(o, "vit_o", Dv), lw.out_w, x, mode=K.GEMM_F32, bias=lw.out_b, res=x)
+            h = self._norm(x, lw.ln2_w, lw.ln2_b, "vit_h", Dv, v.layer_norm_eps)
+            self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
+            self._gemm(self._operand(f, "vit_f", Fvp), lw.fc2_w, x, mode=K.GEMM_F32, bias=lw.fc2_b, res=x)
         if src is None:
             return x, G, None, 0
         # ---- last needed layer on compact query rows -------------------------------------------------------------
@@ -261,23 +315,23 @@ class SelectorEngine:
         Pc = idx.numel()
         Mc = T * Pc
         lw = w.vit[-1]
-        K.layernorm(x, lw.ln1_w, lw.ln1_b, h, Dv, v.layer_norm_eps)
-        K.gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, bias=lw.qkv_b[Dv:])          # K|V for every token
-        hq = self._buf("vit_hq", (Mc, Dvp), self.dtype)
+        h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, v.layer_norm_eps)
+        self._gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, bias=lw.qkv_b[Dv:])          # K|V for every token
         xq = self._buf("vit_xq", (Mc, Dv), torch.float32)
-        K.gather_rows(h, idx, P, T, hq, Dvp)
         K.gather_rows(x, idx, P, T, xq, Dv)
+        # LayerNorm is per row: normalising the gathered residual rows equals gathering the normalised rows
+        hq = self._norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq", Dv, v.layer_norm_eps)
         qc = self._buf("vit_qc", (Mc, Dv), self.dtype)
-        K.gemm(hq, lw.qkv_w[:Dv], qc, mode=K.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
+        self._gemm(hq, lw.qkv_w[:Dv], qc, mode=K.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
         oc = self._buf("vit_oc", (Mc, Dvp), self.dtype, zero=True)
         K.attention(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
-                      q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
-                      variant=self.attn_variant)
-        K.gemm(oc, lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
-        K.layernorm(xq, lw.ln2_w, lw.ln2_b, hq, Dv, v.layer_norm_eps)
+                    q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
+                    variant=self.attn_variant)
+        self._gemm(self._operand(oc, "vit_oc", Dv), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
+        hq = self._norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", Dv, v.layer_norm_eps)
         fc = self._buf("vit_fc", (Mc, Fvp), self.dtype)
-        K.gemm(hq, lw.fc1_w, fc, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
-        K.gemm(fc, lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
+        self._gemm(hq, lw.fc1_w, fc, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
+        self._gemm(self._operand(fc, "vit_fc", Fvp), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
         return xq, G, cmap, Pc
 
     # ---- A9: pool + projector, written straight into rows of the LLM residual stream ------------------
@@ -316,7 +370,6 @@ class SelectorEngine:
         nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         qkv_n = (nq + 2 * nkv) * hd
         op = pad64(nq * hd)
-        h = self._buf("llm_h", (N, Dp), self.dtype, zero=True)
         qkv = self._buf("llm_qkv", (N, qkv_n), self.dtype)
         o = self._buf("llm_o", (N, op), self.dtype, zero=True)
         f = self._buf("llm_f", (N, Fp), self.dtype)
@@ -325,22 +378,22 @@ class SelectorEngine:
         scale = hd ** -0.5
         kvw = 2 * nkv * hd
         for lw in w.llm:
-            K.rmsnorm(x, lw.in_ln, h, D, cfg.rms_norm_eps)
-            K.gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
+            h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps)
+            self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
             K.rope_(qkv, cos, sin, nq + nkv, hd)
             if kv_gather is None:
                 K.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
-                              head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
-                              o_strides=(0, op, hd), scale=scale, variant=self.attn_variant, kv_len=kv_len)
+                            head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
+                            o_strides=(0, op, hd), scale=scale, variant=self.attn_variant, kv_len=kv_len)
             else:
                 kv = kv_gather(qkv[:, nq * hd:])                 # [total, 2*nkv*hd]: K heads then V heads per row
                 K.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
-                              head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, kvw, hd), v_strides=(0, kvw, hd),
-                              o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
-            K.gemm(o, lw.o_w, x, mode=K.GEMM_F32, res=x)
-            K.rmsnorm(x, lw.post_ln, h, D, cfg.rms_norm_eps)
-            K.gemm(h, lw.gu_w, f, mode=K.GEMM_SWIGLU)
-            K.gemm(f, lw.down_w, x, mode=K.GEMM_F32, res=x)
+                            head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, kvw, hd), v_strides=(0, kvw, hd),
+                            o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
+            self._gemm(self._operand(o, "llm_o", nq * hd), lw.o_w, x, mode=K.GEMM_F32, res=x)
+            h = self._norm(x, lw.post_ln, None, "llm_h", D, cfg.rms_norm_eps)
+            self._gemm(h, lw.gu_w, f, mode=K.GEMM_SWIGLU)
+            self._gemm(self._operand(f, "llm_f", Fp), lw.down_w, x, mode=K.GEMM_F32, res=x)
         out = self._buf("llm_out", (N, D), torch.float32)
         K.rmsnorm(x, w.norm_w, out, D, cfg.rms_norm_eps)
         return out

@@ -95,17 +95,24 @@ class EagleQwenG(nn.Module):
         # opt-in: replay single-video forwards from captured HIP graphs keyed by (frames, resolution, prompt bucket)
         # (engine.GraphCache; BASELINE.json configs[3]).  VITG_GRAPHS=1 or model.use_graphs = True.
         self.use_graphs = os.environ.get("VITG_GRAPHS", "0") not in ("", "0")
+        # opt-in fp8 weight path (BASELINE.json configs[4]): tower / decoder GEMM weights as e4m3fn + per-channel scales, per-token
+        # fp8 activations into those GEMMs.  VITG_FP8=1 or model.fp8 = True before the first forward.
+        self.fp8 = os.environ.get("VITG_FP8", "0") not in ("", "0")
         self._graphs = None
 
     # ---- chaining the callers do ---------------------------------------------------------------
     def _set(self, dtype=None, device=None):
         if dtype is not None and dtype not in (torch.float16, torch.bfloat16):
             raise ValueError(f"the selector kernels take fp16 or bf16 MFMA inputs, not {dtype}")
-        changed = (dtype is not None and dtype != self._dtype) or (device is not None and torch.device(device) != self._device)
+        if device is not None:
+            device = torch.device(device)
+            if device.type == "cuda" and device.index is None:      # "cuda" names the current device: keep the index we were given
+                device = torch.device("cuda", self._device.index if self._device.type == "cuda" and self._device.index is not None else 0)
+        changed = (dtype is not None and dtype != self._dtype) or (device is not None and device != self._device)
         if dtype is not None:
             self._dtype = dtype
         if device is not None:
-            self._device = torch.device(device)
+            self._device = device
         if changed and self._engine is not None:
             if self._src is None:
                 raise RuntimeError("weights were already packed and the source state dict was released; "
@@ -163,7 +170,7 @@ class EagleQwenG(nn.Module):
                                    "there is no CPU path")
             sd, vsd = self._src
             with torch.cuda.device(self._device):
-                pw = PackedWeights.from_state_dicts(self.config, sd, vsd, self._dtype, self._device)
+                pw = PackedWeights.from_state_dicts(self.config, sd, vsd, self._dtype, self._device, fp8=self.fp8)
             self._engine = SelectorEngine(pw)
             if not keep_source:
                 self._src = None

@@ -90,6 +90,60 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: O
     return out
 
 
+def pad128(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
+def quant_rows_fp8(x: torch.Tensor, d: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                   scale: Optional[torch.Tensor] = None):
+    """x [M, ld] (fp32 / fp16 / bf16; first d columns are payload) -> (uint8 [M, pad128(d)] e4m3fn bytes, fp32 [M] scales)"""
+    _req(x)
+    M = x.shape[0]
+    d = x.shape[1] if d is None else d
+    if out is None:
+        out = torch.empty((M, pad128(d)), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(M, dtype=torch.float32, device=x.device)
+    _req(out, torch.uint8)
+    _req(scale, torch.float32)
+    assert x.stride(1) == 1 and out.stride(1) == 1 and out.shape[0] >= M and scale.numel() >= M
+    _lib.call("vitg_quant_rows_fp8", _ptr(x), x.stride(0), dt_code(x.dtype), _ptr(out), out.stride(0), _ptr(scale), M, d, _stream())
+    return out, scale
+
+
+def norm_quant_fp8(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, scale: torch.Tensor, d: int,
+                   eps: float):
+    """LayerNorm (b given) / RMSNorm (b None) of fp32 rows fused with the per-token e4m3fn quantiser"""
+    _req(x, torch.float32)
+    _req(out, torch.uint8)
+    _req(scale, torch.float32)
+    _lib.call("vitg_norm_quant_fp8", _ptr(x), x.stride(0), _ptr(_req(w, torch.float32)), _ptr(None if b is None else _req(b, torch.float32)),
+              _ptr(out), out.stride(0), _ptr(scale), x.shape[0], d, eps, _stream())
+    return out, scale
+
+
+def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, out: torch.Tensor, *, mode: int,
+             out_dtype: torch.dtype, n: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+             res: Optional[torch.Tensor] = None, res_mod: int = 0, m: Optional[int] = None) -> torch.Tensor:
+    """out = epilogue(diag(sa) (a8[:m] @ w8[:n].T) diag(sw)); a8 [M,K], w8 [N,K] uint8 e4m3fn bytes, K % 128 == 0"""
+    _req(a8, torch.uint8)
+    _req(w8, torch.uint8)
+    M = a8.shape[0] if m is None else m
+    N = w8.shape[0] if n is None else n
+    K = w8.shape[1]
+    assert a8.shape[1] == K and a8.stride(1) == 1 and w8.stride(1) == 1 and out.stride(1) == 1
+    _req(out, torch.float32 if mode == GEMM_F32 else out_dtype)
+    _req(sa, torch.float32)
+    _req(sw, torch.float32)
+    if bias is not None:
+        _req(bias, torch.float32)
+    if res is not None:
+        _req(res, torch.float32)
+    _lib.call("vitg_gemm_fp8", _ptr(a8), a8.stride(0), _ptr(sa), _ptr(w8), w8.stride(0), _ptr(sw), M, N, K, dt_code(out_dtype), mode,
+              _ptr(bias), act, _ptr(out), out.stride(0), _ptr(res), 0 if res is None else res.stride(0), res_mod, _stream())
+    return out
+
+
 def pack_weight_fragments(w: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
     """MFMA-fragment-ordered copy of w[:n] [N,K] for gemm(..., wf=...) (vitg_pack_weight_fragments; profiling library only)"""
     import ctypes

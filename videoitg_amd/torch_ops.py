@@ -10,7 +10,7 @@ raises ``NotImplementedError`` from the dispatcher (the product has no CPU path)
 
 ``SelectorEngine`` launches through this module (``videoitg_amd.engine.K``); ``videoitg_amd.ops`` stays the raw binding.
 Names are the build's choice: patchify, gemm, layernorm, rmsnorm, rope_, attention, bilinear_pool,
-gather_rows, embed_gather, pool_score, rank, preprocess_u8, bce_loss.
+gather_rows, embed_gather, pool_score, rank, preprocess_u8, bce_loss, quant_rows_fp8, norm_quant_fp8, gemm_fp8.
 """
 from __future__ import annotations
 
@@ -89,6 +89,18 @@ _def("preprocess_u8(Tensor frames, int size, int out_dtype=2) -> Tensor",
      lambda frames, size, out_dtype=2: frames.new_empty((frames.shape[0], 3, size, size), dtype=_DT[out_dtype]))
 
 
+# ---- FP8 weight path ---------------------------------------------------------------------------------------------------------
+_def("quant_rows_fp8(Tensor x, int d, Tensor(a!) out, Tensor(b!) scale) -> ()",
+     lambda x, d, out, scale: (_raw.quant_rows_fp8(x, d, out, scale), None)[1], lambda *a, **k: None)
+_def("norm_quant_fp8(Tensor x, Tensor w, Tensor? b, Tensor(a!) out, Tensor(b!) scale, int d, float eps) -> ()",
+     lambda x, w, b, out, scale, d, eps: (_raw.norm_quant_fp8(x, w, b, out, scale, d, eps), None)[1], lambda *a, **k: None)
+_def("gemm_fp8(Tensor a8, Tensor sa, Tensor w8, Tensor sw, Tensor(a!) out, int mode, int out_dtype, int? n=None, Tensor? bias=None, "
+     "int act=0, Tensor? res=None, int res_mod=0, int? m=None) -> ()",
+     lambda a8, sa, w8, sw, out, mode, out_dtype, n=None, bias=None, act=0, res=None, res_mod=0, m=None:
+         (_raw.gemm_fp8(a8, sa, w8, sw, out, mode=mode, out_dtype=_DT[out_dtype], n=n, bias=bias, act=act, res=res, res_mod=res_mod, m=m),
+          None)[1],
+     lambda *a, **k: None)
+
 # ---- call-compatible namespace for the engine (same signatures as videoitg_amd.ops) ------------------------------------
 _ops = torch.ops.videoitg
 _CODE = {v: k for k, v in _DT.items()}
@@ -159,6 +171,23 @@ class _Namespace:
     def bce_loss(logits, labels):
         return _ops.bce_loss(logits, labels)
 
+    pad128 = staticmethod(_raw.pad128)
+
+    @staticmethod
+    def quant_rows_fp8(x, d, out, scale):
+        _ops.quant_rows_fp8(x, d, out, scale)
+        return out, scale
+
+    @staticmethod
+    def norm_quant_fp8(x, w, b, out, scale, d, eps):
+        _ops.norm_quant_fp8(x, w, b, out, scale, d, eps)
+        return out, scale
+
+    @staticmethod
+    def gemm_fp8(a8, sa, w8, sw, out, *, mode, out_dtype, n=None, bias=None, act=0, res=None, res_mod=0, m=None):
+        _ops.gemm_fp8(a8, sa, w8, sw, out, mode, _CODE[out_dtype], n, bias, act, res, res_mod, m)
+        return out
+
     @staticmethod
     def preprocess_u8(frames, size, out_dtype=torch.float32):
         return _ops.preprocess_u8(frames, size, _CODE[out_dtype])
@@ -166,4 +195,4 @@ class _Namespace:
 
 K = _Namespace()
 OP_NAMES: List[str] = ["patchify", "gemm", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
-                       "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8"]
+                       "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8"]
