@@ -102,7 +102,7 @@ def executed_gemm_flops(cfg, T, R, n_text, skip_dead_rows=True):
     return fl["gemm"] - skipped
 
 
-def parity_block(T, R, prompt_len, seed, logits, order):
+def parity_block(T, R, prompt_len, seed, logits, order, tol=1e-3):
     """Compare this run's logits with the committed complete-pass ORACLE fixture for exactly this workload
     (tests/golden/full_*.json: data only - fp32 oracle logits computed in the build container on the same counter-generated
     weights and inputs).  None when no fixture matches the command line."""
@@ -120,7 +120,8 @@ def parity_block(T, R, prompt_len, seed, logits, order):
         return {"fixture": f"tests/golden/{fn}", "oracle": "complete fp32 pass, 26+28 layers, same counter-generated weights and inputs",
                 "max_abs_dscore": round(ds, 6), "max_abs_dlogit": round((got - want).abs().max().item(), 5),
                 f"top{k}_set_match": sorted(order[:k]) == rec["topk"], f"oracle_gap_rank{k}_{k + 1}": rec["gap_k_k1"],
-                "full_order_match": order == rec["order"], "tolerance": 1e-3, "pass": bool(ds <= 1e-3 and sorted(order[:k]) == rec["topk"])}
+                "full_order_match": order == rec["order"], "tolerance": tol,
+                "pass": bool(ds <= tol and (tol > 1e-3 or sorted(order[:k]) == rec["topk"]))}
     return None
 
 
@@ -295,6 +296,9 @@ def main():
 
     # synthetic inputs, identical on every rank; resident in HBM before the timed region
     ids, pix32 = synth.workload_inputs(cfg, T, R, args.prompt_len)          # 16-bit-exact values: bf16 and fp16 runs see the same pixels
+    if cp is not None:                                                      # every rank keeps ONLY its own frames in HBM
+        fr = cp.local_frames(T)
+        pix32 = pix32[fr.start:fr.stop]
     pix = pix32.to(dtype).to(dev)
     del pix32
 
@@ -315,7 +319,7 @@ def main():
         elif cp is None:
             logits = eng.forward(ids, None, [pix])[0].view(-1)
         else:
-            logits = cp.forward(eng, ids, pix)
+            logits = cp.forward(eng, ids, pix, total_frames=T)
         scores, order = ops.rank(logits)
         return order.cpu().tolist(), logits          # D2H of the index list = end of the timed region
 
@@ -464,6 +468,46 @@ def main():
                                                                                "parity": parity_block(T, R, args.prompt_len, args.seed, oo["logits"], oo["order"])}
             eng_o.release_workspace()
             del eng_o, pix_o
+            # BASELINE.json configs[4]: the fp8 weight path (e4m3fn weights per output channel, per-token fp8 activations into the
+            # tower / decoder GEMMs, v_mfma_scale_f32_32x32x64_f8f6f4), same workload, same parity fixture; its GEMM roofline is
+            # priced against the dense fp8 peak.  A separate precision tier: reported beside `value`, never as `value`.
+            eng8 = SelectorEngine(packed_random_weights(cfg, dtype, dev, seed=args.seed, fp8=True))
+            t8 = GemmTimer()
+            raw_fp8 = ops.gemm_fp8
+            ops.gemm_fp8 = t8.wrap(ops.gemm_fp8)
+            o8 = {}
+
+            def step_8():
+                o8["logits"] = eng8.forward(ids, None, [pix])[0].view(-1)
+                _, order_ = ops.rank(o8["logits"])
+                o8["order"] = order_.cpu().tolist()
+            step_8()
+            torch.cuda.synchronize()
+            t8.enabled = True
+            t4 = time.perf_counter()
+            step_8()
+            step_8()
+            torch.cuda.synchronize()
+            d8 = (time.perf_counter() - t4) / 2
+            t8.enabled = False
+            ops.gemm_fp8 = raw_fp8
+            n8, ms8 = t8.summary()
+            v = cfg.vision
+            layer_gemm = executed_gemm_flops(cfg, T, R, ids.shape[1] - 1, eng8.skip_dead_rows) - fl["patch"] - fl["proj"]
+            ach8 = layer_gemm * 2 / max(ms8 * 1e-3, 1e-9) / 1e12
+            ref16 = last_logits.float().cpu().view(-1)
+            got8 = o8["logits"].float().cpu().view(-1)
+            out["secondary"]["fp8"] = {
+                "value": round(T / d8, 2), "unit": "frames/s", "ms_per_step": round(d8 * 1e3, 2),
+                "what": "e4m3fn weights (per output channel) + per-token e4m3fn activations into the tower/decoder GEMMs; attention, "
+                        "residual stream, norms as in the 16-bit path",
+                "roofline": {"kernel": "gemm_fp8_kernel", "bound": "mfma", "achieved": round(ach8, 1), "peak": 5000.0, "unit": "TFLOP/s",
+                             "frac": round(ach8 / 5000.0, 4), "launches": n8, "avg_launch_ms": round(ms8 / max(n8, 1), 4)},
+                "parity_vs_oracle": parity_block(T, R, args.prompt_len, args.seed, o8["logits"], o8["order"], tol=0.15),
+                "vs_16bit_hip": {"max_abs_dscore": round((torch.sigmoid(got8) - torch.sigmoid(ref16)).abs().max().item(), 5),
+                                 "top32_overlap": len(set(o8["order"][:32]) & set(order[:32]))}}
+            eng8.release_workspace()
+            del eng8
         if world == 1 and not args.no_cpu_baseline:
             eng.release_workspace()
             try:

@@ -73,24 +73,35 @@ class VideoITG(_Base):
                  num_frames: int = 512, target_fps: int = 1, multiple: int = 1,
                  output_dir="./longvideobench_val_v_grounding_patchv1", video_loader: Optional[Callable] = None, **kwargs) -> None:
         super().__init__()
-        rank = int(os.environ.get("LOCAL_RANK", "0"))
-        world = int(os.environ.get("WORLD_SIZE", "1"))
-        if world > 1 and device_map == "":                       # one model per GPU (videoitg.py:156-158)
-            self._device = torch.device(f"cuda:{rank}")
-            self.device_map = f"cuda:{rank}"
+        # process group / rank handling as in the reference (videoitg.py:154-214): an accelerate Accelerator owns the process group,
+        # one model per GPU, every rank waits before loading, and with several processes the model goes through
+        # accelerator.prepare_model(evaluation_mode=True) (no DDP wrapper in evaluation mode; the model object survives it,
+        # tests/test_gpu_graphs.py::test_model_survives_accelerate_prepare_model)
+        from datetime import timedelta
+        from accelerate import Accelerator, InitProcessGroupKwargs
+        accelerator = Accelerator(kwargs_handlers=[InitProcessGroupKwargs(timeout=timedelta(weeks=52))])
+        if accelerator.num_processes > 1 and device_map == "":   # videoitg.py:156-158
+            self._device = torch.device(f"cuda:{accelerator.local_process_index}")
+            self.device_map = f"cuda:{accelerator.local_process_index}"
         else:
             self._device = torch.device(device)
             self.device_map = device_map or str(self._device)
-        self._rank, self._world_size = int(os.environ.get("RANK", "0")), world
         self.pretrained = self.model_path = pretrained
         self.model_name = get_model_name_from_path(pretrained)
         self.num_frames, self.target_fps, self.multiple = num_frames, target_fps, multiple
         self.output_dir = output_dir
+        accelerator.wait_for_everyone()                           # videoitg.py:170
         self._tokenizer, self._model, self.image_processor, self._max_length = load_pretrained_model(
             self.model_path, None, self.model_name, device_map=self.device_map, use_flash_attn=use_flash_attn)
         self._config = self._model.config
         self.model.eval()
         self.model.tie_weights()
+        if accelerator.num_processes > 1:                         # videoitg.py:189-208 (DDP branch; FSDP / DeepSpeed are training set-ups)
+            self._model = accelerator.prepare_model(self.model, evaluation_mode=True)
+            self._rank, self._world_size = accelerator.local_process_index, accelerator.num_processes
+        else:
+            self._rank, self._world_size = 0, 1
+        self.accelerator = accelerator
         self.truncation, self.batch_size_per_gpu = truncation, int(batch_size)
         self.conv_template, self.use_cache, self.truncate_context = conv_template, use_cache, truncate_context
         self._video_loader = video_loader or load_video

@@ -108,10 +108,18 @@ def gather_logits(local: torch.Tensor, plan: ShardPlan, rank: int, group=None) -
 class ContextParallel:
     def __init__(self, rank: int, world: int, group=None):
         self.rank, self.world, self.group = rank, world, group
+        self._gatherers = {}             # plan key -> RowGatherer: send / receive buffers and the compaction index are built ONCE
 
-    def forward(self, eng, input_ids: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
-        """input_ids [1, L] (one <image>), pix [T,3,R,R] resident on every rank (only the local frames are read)
-        -> logits fp32 [T] on every rank."""
+    def local_frames(self, total_frames: int) -> range:
+        """the frames this rank encodes (what a caller that shards the pixels itself has to hand to forward)"""
+        base, extra = divmod(total_frames, self.world)
+        start = self.rank * base + min(self.rank, extra)
+        return range(start, start + base + (1 if self.rank < extra else 0))
+
+    def forward(self, eng, input_ids: torch.Tensor, pix: torch.Tensor, total_frames: Optional[int] = None) -> torch.Tensor:
+        """input_ids [1, L] (one <image>) -> logits fp32 [T] on every rank.  pix: either the whole video [T,3,R,R] (only the local
+        frames are read) or, with total_frames = T, ONLY this rank's frames [len(local_frames(T)),3,R,R] - the pixels of the other
+        ranks never need to be resident here."""
         from .torch_ops import K as ops
         cfg = eng.cfg
         ids = input_ids.reshape(-1).cpu()
@@ -119,12 +127,18 @@ class ContextParallel:
         if len(pos) != 1:
             raise ValueError("exactly one <image> token per sample")
         pre, post = ids[:pos[0]], ids[pos[0] + 1:]
-        T = pix.shape[0]
+        T = pix.shape[0] if total_frames is None else total_frames
         G = pix.shape[-1] // cfg.vision.patch_size
         hw = cfg.pooled_grid(T, G)                           # GLOBAL frame count (mlp_proj.py:48)
         plan = make_plan(self.world, T, hw * hw, pre.numel(), post.numel())
         fr = plan.frames[self.rank]
-        feats, _, cmap, pc = eng.vit_forward(pix[fr.start:fr.stop], hw)
+        if total_frames is None:
+            local_pix = pix[fr.start:fr.stop]
+        else:
+            if pix.shape[0] != len(fr):
+                raise ValueError(f"rank {self.rank} owns {len(fr)} of {T} frames, got {pix.shape[0]}")
+            local_pix = pix
+        feats, _, cmap, pc = eng.vit_forward(local_pix, hw)
         n = plan.n_local[self.rank]
         x = eng._buf("llm_x", (n, cfg.hidden_size), torch.float32)
         vs = plan.vis_start(self.rank)
@@ -134,7 +148,10 @@ class ContextParallel:
         eng.project_into(feats, len(fr), G, hw, x[vs:vs + nv], cmap, pc)
         if self.rank == self.world - 1 and post.numel():
             ops.embed_gather(post.contiguous().to(eng.device), eng.w.embed, x[vs + nv:])
-        gather = RowGatherer(plan, self.rank, self.group)
+        key = (T, hw, pre.numel(), post.numel())
+        gather = self._gatherers.get(key)
+        if gather is None:
+            gather = self._gatherers[key] = RowGatherer(plan, self.rank, self.group)
         hfin = eng.llm_forward(x, pos0=plan.offset[self.rank], total=plan.total, kv_gather=gather)
         local = torch.empty(len(fr), dtype=torch.float32, device=eng.device)
         ops.pool_score(hfin[vs:], len(fr), hw * hw, cfg.hidden_size, eng.w.head_w, eng.w.head_b, local)
