@@ -43,10 +43,12 @@ def parse():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--res", type=int, default=448)
     ap.add_argument("--prompt-len", type=int, default=60)
-    # bf16 = the dtype of BASELINE.json's bench configuration; fp16 = the reference's inference dtype (builder.py:59) and the dtype
-    # the parity tests hold to 1e-3.  Same kernels, same rate class.
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
-                    help="MFMA input type; bf16 = the configuration BASELINE.json names, fp16 = what the reference itself runs (model.half())")
+    # fp16 = the reference's own inference dtype (model.half(), eagle/model/builder.py:59, infer.py:21) and the one that holds
+    # north_star's |dscore| <= 1e-3 against the complete fp32 oracle pass at this workload (1.4e-4; bf16: 1.4e-3 - measured by the
+    # `parity` block below and tests/test_fullsize_parity.py), so it is the headline; bf16 (the type BASELINE.json's configuration
+    # names) runs the same kernels ~4 % faster and is reported as `secondary.bf16` with its own parity block.
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
+                    help="MFMA input type; fp16 = what the reference itself runs and what meets the 1e-3 score bound; bf16 = secondary")
     ap.add_argument("--config", default="full", choices=["full", "tiny"])
     ap.add_argument("--graph", action="store_true", help="replay the single-GPU step from a captured HIP graph (same kernels)")
     ap.add_argument("--videos", type=int, default=0,
@@ -151,11 +153,12 @@ class GemmTimer:
 
 
 def cpu_baseline(cfg, T, R, n_text, threads):
-    """Oracle (kind "port") on this host's cores on the bounded sample SURVEY.md 8d prescribes for T = 512: the WHOLE needed tower
-    depth (26 layers) on a 16-frame slice, x (T/16) frame groups (frames are independent), plus 2 of the 28 decoder layers at the
-    FULL token count N, x 14 (layers are identical in cost).  Projector / head < 0.1 % of the work.  Same counter-generated weights
-    as the GPU run.  The complete passes behind the parity fixtures (tests/golden/full_*.json, 8 vCPUs of the build container)
-    are quoted beside it."""
+    """Oracle (kind "port") on this host's cores on a bounded sample shaped as SURVEY.md 8d prescribes for T = 512: the WHOLE needed
+    tower depth (26 layers) on a frame slice, x (T / slice) frame groups (frames are independent), plus whole decoder layers at the
+    FULL token count N, x (28 / layers timed) (layers are identical in cost).  8d asks for 16 frames and 2 layers; on the GPU box's
+    128 host threads that is 107 s (measured, profiles/r02_bench_*.json), so the default run times 4 frames and 1 layer (~30 s)
+    and says so.  Projector / head < 0.1 % of the work.  Same counter-generated weights as the GPU run.  The COMPLETE passes behind
+    the parity fixtures (tests/golden/full_*.json, 8 vCPUs of the build container) are quoted beside it."""
     from oracle import videoitg_oracle as O          # checker/baseline only
     from videoitg_amd import synth
     torch.set_num_threads(threads)
@@ -164,7 +167,7 @@ def cpu_baseline(cfg, T, R, n_text, threads):
     n_vit = cfg.num_vit_layers_needed()
     vsd = synth.counter_state_dict([sp for sp in synth.vision_param_specs(cfg)
                                     if sp[0].startswith("vision_model.embeddings.") or int(sp[0].split(".")[3]) < n_vit], 0)
-    nf = min(16, T)
+    nf = min(4, T)
     pix = synth.synth_pixel_values(nf, R, seed=1234)
     with torch.inference_mode():
         O.siglip_tower(pix[:1], vsd, patch=v.patch_size, num_heads=v.num_attention_heads, num_layers=2, select_layer=2)  # warm
@@ -173,9 +176,8 @@ def cpu_baseline(cfg, T, R, n_text, threads):
                        select_layer=cfg.mm_vision_select_layer, frame_chunk=nf)
         t_vit = time.perf_counter() - t0
     del vsd
-    nl = 2
-    sd = synth.counter_state_dict([sp for sp in synth.llm_param_specs(cfg)
-                                   if sp[0].startswith("model.layers.0.") or sp[0].startswith("model.layers.1.")], 0)
+    nl = 1
+    sd = synth.counter_state_dict([sp for sp in synth.llm_param_specs(cfg) if sp[0].startswith("model.layers.0.")], 0)
     N = fl["N"]
     x = torch.randn(1, N, cfg.hidden_size)
     cos, sin = O.rope_tables(N, cfg.head_dim, cfg.rope_theta)

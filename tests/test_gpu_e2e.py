@@ -31,32 +31,20 @@ def run_case(golden_dir, name, dtype, variant=0):
     return z, [g.float().cpu() for g in got], T
 
 
-def rounding_budget(golden_dir, name, dtype):
-    """Score error that 16-bit MFMA inputs alone cause (CPU model of the product's rounding sites,
-    oracle/quant_model.py) -- the floor no implementation with 16-bit matrix inputs can beat."""
-    from oracle import quant_model as QM
-    from oracle import videoitg_oracle as O
-    from videoitg_amd import synth
-    from videoitg_amd.config import ITGConfig
-    z = np.load(os.path.join(golden_dir, f"{name}.npz"))
-    cfg = ITGConfig.from_dict(json.loads(str(z["cfg"])))
-    T = z["T"].tolist()
-    images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i) for i, t in enumerate(T)]
-    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
-    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
-    ref = O.forward(cfg, sd, vsd, ids, mask, images)
-    q = QM.forward(cfg, sd, vsd, ids, mask, images, dtype=dtype, mode="product")
-    return max((torch.sigmoid(a) - torch.sigmoid(b)).abs().max().item() for a, b in zip(q, ref))
+# Fixed, stated bounds (no model of this implementation's own rounding enters): fp16 - the reference's inference dtype and the
+# headline - is held to north_star's 1e-3 on every fixture but chunk520 (a 520-frame toy whose random weights spread the logits
+# over +-8: 1.43e-3 measured, held to 2e-3); bf16 is the secondary tier (8-bit mantissa on every MFMA operand) and is held to
+# 2e-2 on these 2-3-layer random-weight toys (1.5e-2 measured; at full depth with the real widths it measures 1.4e-3,
+# tests/test_fullsize_parity.py).
+GOLDEN_TOL = {torch.float16: {"chunk520": 2e-3}, torch.bfloat16: {}}
+GOLDEN_TOL_DEFAULT = {torch.float16: SCORE_TOL, torch.bfloat16: 2e-2}
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name", CASES)
 def test_forward_matches_reference_golden(golden_dir, name, dtype):
-    """|score - reference| <= 1e-3 (north_star) wherever 16-bit matrix inputs permit it at all; where the rounding
-    floor itself is above 5e-4 the bound is 2x that floor (fp16: only chunk520, floor 1.2e-3; bf16: every case)."""
     z, got, T = run_case(golden_dir, name, dtype)
-    floor = rounding_budget(golden_dir, name, dtype)
-    tol = max(SCORE_TOL, 2.0 * floor)
+    tol = GOLDEN_TOL[dtype].get(name, GOLDEN_TOL_DEFAULT[dtype])
     worst = 0.0
     for b in range(len(T)):
         ref = torch.from_numpy(z[f"logits{b}"])
@@ -64,11 +52,8 @@ def test_forward_matches_reference_golden(golden_dir, name, dtype):
         assert torch.isfinite(got[b]).all()
         d = (torch.sigmoid(got[b]) - torch.sigmoid(ref)).abs().max().item()
         worst = max(worst, d)
-        print(f"{name}[{b}] {dtype}: max|dscore|={d:.2e} max|dlogit|={(got[b] - ref).abs().max().item():.2e} "
-              f"(16-bit rounding floor {floor:.2e}, tol {tol:.2e})")
+        print(f"{name}[{b}] {dtype}: max|dscore|={d:.2e} max|dlogit|={(got[b] - ref).abs().max().item():.2e} (tol {tol:.1e})")
     assert worst <= tol, (worst, tol)
-    if dtype == torch.float16 and name != "chunk520":
-        assert worst <= SCORE_TOL, worst
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -110,8 +95,7 @@ def test_attention_loop_structures_agree(golden_dir, name):
     same real-number result with different 16-bit roundings of P.  Each must sit inside the golden tolerance on its own,
     and they differ from each other by no more than two such roundings (measured: tools/attn_variants_vs_golden.py)."""
     from videoitg_amd import ops
-    floor = rounding_budget(golden_dir, name, torch.float16)
-    tol = max(SCORE_TOL, 2.0 * floor)
+    tol = GOLDEN_TOL[torch.float16].get(name, SCORE_TOL)
     outs = []
     for sp in (2, 1):
         ops.set_option("attn_sp", sp)
@@ -216,7 +200,6 @@ def test_full_width_reduced_depth_parity(vit_layers, llm_layers):
     non-native grid, 16->10 token pool) at reduced depth / frame count so the fp32 oracle finishes on the host: every
     production kernel instantiation (hd 72 and hd 128 attention, 256x256 persistent GEMM incl. K=4352/18944, SwiGLU,
     LN/RMS at 1152/3584) is on this path."""
-    from oracle import quant_model as QM
     from oracle import videoitg_oracle as O
     from videoitg_amd import ops, synth
     from videoitg_amd.config import ITGConfig, VisionConfig
@@ -229,17 +212,16 @@ def test_full_width_reduced_depth_parity(vit_layers, llm_layers):
     ids = torch.cat([torch.tensor([-200]), synth.synth_prompt_ids(60, cfg.vocab_size)]).unsqueeze(0)
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     want = O.forward(cfg, sd, vsd, ids, None, [pix])[0].view(-1)
-    floor = (torch.sigmoid(QM.forward(cfg, sd, vsd, ids, None, [pix], dtype=torch.float16)[0].view(-1)) - torch.sigmoid(want)).abs().max().item()
     eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
     got = eng.forward(ids, None, [pix.cuda()])[0].view(-1).float().cpu()
     d = (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item()
-    print(f"full-width {vit_layers - 1}+{llm_layers} layers: max|dscore|={d:.2e} max|dlogit|={(got - want).abs().max().item():.2e} rounding floor {floor:.2e}; "
+    print(f"full-width {vit_layers - 1}+{llm_layers} layers: max|dscore|={d:.2e} max|dlogit|={(got - want).abs().max().item():.2e} "
           f"logit range [{want.min():.2f}, {want.max():.2f}]")
-    assert d <= max(SCORE_TOL, 2 * floor), (d, floor)
+    assert d <= SCORE_TOL, d
     _, order = ops.rank(got.cuda())
     sref, oref = torch.sort(torch.sigmoid(want), descending=True, stable=True)
     for k in range(1, T):
-        if (sref[k - 1] - sref[k]).item() > 2.5 * max(SCORE_TOL, floor):
+        if (sref[k - 1] - sref[k]).item() > 2.5 * SCORE_TOL:
             assert set(order[:k].cpu().tolist()) == set(oref[:k].tolist()), k
 
 
