@@ -47,7 +47,7 @@ def parse():
     # north_star's |dscore| <= 1e-3 against the complete fp32 oracle pass at this workload (1.4e-4; bf16: 1.4e-3 - measured by the
     # `parity` block below and tests/test_fullsize_parity.py), so it is the headline; bf16 (the type BASELINE.json's configuration
     # names) runs the same kernels ~4 % faster and is reported as `secondary.bf16` with its own parity block.
-    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "tower_bf16_llm_fp16"],
                     help="MFMA input type; fp16 = what the reference itself runs and what meets the 1e-3 score bound; bf16 = secondary")
     ap.add_argument("--config", default="full", choices=["full", "tiny"])
     ap.add_argument("--graph", action="store_true", help="replay the single-GPU step from a captured HIP graph (same kernels)")
@@ -287,12 +287,13 @@ def main():
     from videoitg_amd.parallel import ContextParallel
     from videoitg_amd.synth_device import packed_random_weights
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16                        # LLM / projector MFMA input type
+    vit_dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16                     # tower MFMA input type
     cfg = ITGConfig() if args.config == "full" else tiny_config(vision_token_num=16384)
     T, R = args.frames, args.res
     if args.config == "tiny":
         R = cfg.vision.image_size
-    weights = packed_random_weights(cfg, dtype, dev, seed=args.seed)
+    weights = packed_random_weights(cfg, dtype, dev, seed=args.seed, vit_dtype=vit_dtype)
     eng = SelectorEngine(weights)
     cp = ContextParallel(rank, world) if world > 1 else None
 
@@ -301,7 +302,7 @@ def main():
     if cp is not None:                                                      # every rank keeps ONLY its own frames in HBM
         fr = cp.local_frames(T)
         pix32 = pix32[fr.start:fr.stop]
-    pix = pix32.to(dtype).to(dev)
+    pix = pix32.to(vit_dtype).to(dev)
     del pix32
 
     if args.videos > 0:
@@ -446,30 +447,31 @@ def main():
             del pix0
             # the other 16-bit type on the same workload: bf16 is what BASELINE.json's configuration names, fp16 what the reference
             # itself runs (model.half()); both go through the same kernels
-            other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
             eng.release_workspace()
-            eng_o = SelectorEngine(packed_random_weights(cfg, other, dev, seed=args.seed))
-            pix_o = pix.to(other)
+            # ("tower bf16 + LLM fp16": the tower tolerates bf16 inside the 1e-3 bound, the LLM does not - profiles/r02_parity.md)
+            F16, B16 = torch.float16, torch.bfloat16
+            policies = {"fp16": (F16, F16), "bf16": (B16, B16), "tower_bf16_llm_fp16": (F16, B16)}
+            policies.pop(args.dtype, None)
+            for pname, (ldt, vdt) in policies.items():
+                eng_o = SelectorEngine(packed_random_weights(cfg, ldt, dev, seed=args.seed, vit_dtype=vdt))
+                pix_o = pix.to(vdt)
+                oo = {}
 
-            oo = {}
-
-            def step_o():
-                oo["logits"] = eng_o.forward(ids, None, [pix_o])[0].view(-1)
-                _, order_ = ops.rank(oo["logits"])
-                oo["order"] = order_.cpu().tolist()
-                return oo["order"]
-            step_o()
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            step_o()
-            step_o()
-            torch.cuda.synchronize()
-            d3 = (time.perf_counter() - t3) / 2
-            out["secondary"]["fp16" if other == torch.float16 else "bf16"] = {"value": round(T / d3, 2), "unit": "frames/s",
-                                                                               "ms_per_step": round(d3 * 1e3, 2),
-                                                                               "parity": parity_block(T, R, args.prompt_len, args.seed, oo["logits"], oo["order"])}
-            eng_o.release_workspace()
-            del eng_o, pix_o
+                def step_o():
+                    oo["logits"] = eng_o.forward(ids, None, [pix_o])[0].view(-1)
+                    _, order_ = ops.rank(oo["logits"])
+                    oo["order"] = order_.cpu().tolist()
+                step_o()
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                step_o()
+                step_o()
+                torch.cuda.synchronize()
+                d3 = (time.perf_counter() - t3) / 2
+                out["secondary"][pname] = {"value": round(T / d3, 2), "unit": "frames/s", "ms_per_step": round(d3 * 1e3, 2),
+                                           "parity": parity_block(T, R, args.prompt_len, args.seed, oo["logits"], oo["order"])}
+                eng_o.release_workspace()
+                del eng_o, pix_o
             # BASELINE.json configs[4]: the fp8 weight path (e4m3fn weights per output channel, per-token fp8 activations into the
             # tower / decoder GEMMs, v_mfma_scale_f32_32x32x64_f8f6f4), same workload, same parity fixture; its GEMM roofline is
             # priced against the dense fp8 peak.  A separate precision tier: reported beside `value`, never as `value`.

@@ -76,6 +76,9 @@ class PackedWeights:
     cfg: ITGConfig
     dtype: torch.dtype
     device: torch.device
+    vit_dtype: Optional[torch.dtype] = None         # MFMA input type of the SigLIP tower (None = dtype): the tower tolerates bf16 (8-bit
+                                                    # mantissa) inside the 1e-3 score bound, the 28-layer bidirectional LLM does not
+                                                    # (profiles/r02_parity.md), so "tower bf16 + LLM fp16" is a supported mix
     fp8: bool = False                               # BASELINE.json configs[4]: tower / decoder GEMM weights as e4m3fn + per-channel scales
     patch_w: torch.Tensor = None; patch_b: torch.Tensor = None
     pos_native: torch.Tensor = None                # fp32 [P0, Dv]
@@ -89,11 +92,16 @@ class PackedWeights:
     head_w: torch.Tensor = None; head_b: torch.Tensor = None
 
     # ---- packing ---------------------------------------------------------------------------------
+    def __post_init__(self):
+        if self.vit_dtype is None:
+            self.vit_dtype = self.dtype
+        self._packing = self.dtype                  # type the _w16 / _wl helpers currently emit (switched while the tower is packed)
+
     def _w16(self, w: torch.Tensor, rows: Optional[int] = None, cols: Optional[int] = None) -> torch.Tensor:
         w = w.to(self.device)
         rows = w.shape[0] if rows is None else rows
         cols = pad64(w.shape[1]) if cols is None else cols
-        return _pad2(w, rows, cols).to(self.dtype).contiguous()
+        return _pad2(w, rows, cols).to(self._packing).contiguous()
 
     def _wl(self, w: torch.Tensor, rows: Optional[int] = None):
         """weight of a tower / decoder layer GEMM: 16-bit, or - on the fp8 weight path - e4m3fn bytes + per-output-channel scales
@@ -112,7 +120,9 @@ class PackedWeights:
     def pack_vision_embeddings(self, vsd: SD) -> None:
         e = "vision_model.embeddings."
         w = vsd[e + "patch_embedding.weight"]
+        self._packing = self.vit_dtype
         self.patch_w = self._w16(w.reshape(w.shape[0], -1))
+        self._packing = self.dtype
         self.patch_b = self._f32(vsd[e + "patch_embedding.bias"])
         self.pos_native = self._f32(vsd[e + "position_embedding.weight"])
 
@@ -122,6 +132,7 @@ class PackedWeights:
         fvp = pad64(v.intermediate_size)
         qkv_w = torch.cat([vsd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
         qkv_b = torch.cat([vsd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        self._packing = self.vit_dtype
         self.vit.append(VitLayerW(
             ln1_w=self._f32(vsd[p + "layer_norm1.weight"]), ln1_b=self._f32(vsd[p + "layer_norm1.bias"]),
             qkv_w=self._wl(qkv_w), qkv_b=self._f32(qkv_b),
@@ -130,6 +141,7 @@ class PackedWeights:
             fc1_w=self._wl(vsd[p + "mlp.fc1.weight"], rows=fvp), fc1_b=self._f32(vsd[p + "mlp.fc1.bias"], fvp),
             fc2_w=self._wl(vsd[p + "mlp.fc2.weight"]), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
         ))
+        self._packing = self.dtype
 
     def pack_projector_and_head(self, sd: SD) -> None:
         pre = "model.mm_projector.out_projection."
@@ -163,8 +175,9 @@ class PackedWeights:
         ))
 
     @staticmethod
-    def from_state_dicts(cfg: ITGConfig, sd: SD, vsd: SD, dtype: torch.dtype, device, fp8: bool = False) -> "PackedWeights":
-        pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device(device), fp8=fp8)
+    def from_state_dicts(cfg: ITGConfig, sd: SD, vsd: SD, dtype: torch.dtype, device, fp8: bool = False,
+                         vit_dtype: Optional[torch.dtype] = None) -> "PackedWeights":
+        pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device(device), fp8=fp8, vit_dtype=vit_dtype)
         pw.pack_vision_embeddings(vsd)
         for i in range(cfg.num_vit_layers_needed()):
             pw.pack_vision_layer(vsd, i)
@@ -193,7 +206,8 @@ class SelectorEngine:
     def __init__(self, weights: PackedWeights, attn_variant: int = 0):
         self.w = weights
         self.cfg = weights.cfg
-        self.dtype = weights.dtype
+        self.dtype = weights.dtype                # LLM / projector MFMA input type
+        self.vdtype = weights.vit_dtype           # tower MFMA input type
         self.device = weights.device
         self.attn_variant = attn_variant
         self.skip_dead_rows = True        # last tower layer only on the tokens the pool reads (see vit_forward)
@@ -223,7 +237,8 @@ class SelectorEngine:
         self._ws.clear()
 
     # ---- GEMM operands: 16-bit tensors, or (e4m3fn bytes, per-token scales) on the fp8 weight path ---------------------------
-    def _norm(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], name: str, d: int, eps: float):
+    def _norm(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], name: str, d: int, eps: float,
+              dt: Optional[torch.dtype] = None):
         """LayerNorm (b given) / RMSNorm of the fp32 residual rows as the A operand of the next GEMM"""
         M = x.shape[0]
         if self.w.fp8:
@@ -231,7 +246,7 @@ class SelectorEngine:
             sa = self._buf(name + "_qs", (M,), torch.float32)
             K.norm_quant_fp8(x, w, b, a8, sa, d, eps)
             return a8, sa
-        h = self._buf(name, (M, pad64(d)), self.dtype, zero=True)
+        h = self._buf(name, (M, pad64(d)), dt or self.dtype, zero=True)
         if b is not None:
             K.layernorm(x, w, b, h, d, eps)
         else:
@@ -249,7 +264,7 @@ class SelectorEngine:
 
     def _gemm(self, a, w, out: torch.Tensor, **kw) -> torch.Tensor:
         if isinstance(w, Fp8Weight):
-            return K.gemm_fp8(a[0], a[1], w.w8, w.sw, out, out_dtype=self.dtype, **kw)
+            return K.gemm_fp8(a[0], a[1], w.w8, w.sw, out, out_dtype=out.dtype if out.dtype != torch.float32 else self.dtype, **kw)
         return K.gemm(a, w, out, **kw)
 
     # ---- which tokens does the bilinear pool read? (mlp_proj.py:57-68 semantics: align_corners=False) ----------------
@@ -287,25 +302,25 @@ class SelectorEngine:
         M = T * P
         Dv, Dvp, Fvp = v.hidden_size, pad64(v.hidden_size), pad64(v.intermediate_size)
         H, hd = v.num_attention_heads, v.head_dim
-        a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.dtype)
+        a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.vdtype)
         x = self._buf("vit_x", (M, Dv), torch.float32)
         K.gemm(a0, w.patch_w, x, mode=K.GEMM_F32, bias=w.patch_b, res=w.pos_table(G), res_mod=P)
         del a0
-        qkv = self._buf("vit_qkv", (M, 3 * Dv), self.dtype)
-        o = self._buf("vit_o", (M, Dvp), self.dtype, zero=True)
-        f = self._buf("vit_f", (M, Fvp), self.dtype)
+        qkv = self._buf("vit_qkv", (M, 3 * Dv), self.vdtype)
+        o = self._buf("vit_o", (M, Dvp), self.vdtype, zero=True)
+        f = self._buf("vit_f", (M, Fvp), self.vdtype)
         scale = hd ** -0.5
         src = self.pool_sources(G, hw) if (hw is not None and self.skip_dead_rows and len(w.vit) > 0) else None
         full_layers = w.vit if src is None else w.vit[:-1]
         st = (P * 3 * Dv, 3 * Dv, hd)
         for lw in full_layers:
-            h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, v.layer_norm_eps)
+            h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, v.layer_norm_eps, self.vdtype)
             self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
             K.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
                         q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
                         variant=self.attn_variant)
             self._gemm(self._operand(o, "vit_o", Dv), lw.out_w, x, mode=K.GEMM_F32, bias=lw.out_b, res=x)
-            h = self._norm(x, lw.ln2_w, lw.ln2_b, "vit_h", Dv, v.layer_norm_eps)
+            h = self._norm(x, lw.ln2_w, lw.ln2_b, "vit_h", Dv, v.layer_norm_eps, self.vdtype)
             self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
             self._gemm(self._operand(f, "vit_f", Fvp), lw.fc2_w, x, mode=K.GEMM_F32, bias=lw.fc2_b, res=x)
         if src is None:
@@ -315,21 +330,21 @@ class SelectorEngine:
         Pc = idx.numel()
         Mc = T * Pc
         lw = w.vit[-1]
-        h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, v.layer_norm_eps)
+        h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, v.layer_norm_eps, self.vdtype)
         self._gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, bias=lw.qkv_b[Dv:])          # K|V for every token
         xq = self._buf("vit_xq", (Mc, Dv), torch.float32)
         K.gather_rows(x, idx, P, T, xq, Dv)
         # LayerNorm is per row: normalising the gathered residual rows equals gathering the normalised rows
-        hq = self._norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq", Dv, v.layer_norm_eps)
-        qc = self._buf("vit_qc", (Mc, Dv), self.dtype)
+        hq = self._norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq", Dv, v.layer_norm_eps, self.vdtype)
+        qc = self._buf("vit_qc", (Mc, Dv), self.vdtype)
         self._gemm(hq, lw.qkv_w[:Dv], qc, mode=K.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
-        oc = self._buf("vit_oc", (Mc, Dvp), self.dtype, zero=True)
+        oc = self._buf("vit_oc", (Mc, Dvp), self.vdtype, zero=True)
         K.attention(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
                     q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
                     variant=self.attn_variant)
         self._gemm(self._operand(oc, "vit_oc", Dv), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
-        hq = self._norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", Dv, v.layer_norm_eps)
-        fc = self._buf("vit_fc", (Mc, Fvp), self.dtype)
+        hq = self._norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", Dv, v.layer_norm_eps, self.vdtype)
+        fc = self._buf("vit_fc", (Mc, Fvp), self.vdtype)
         self._gemm(hq, lw.fc1_w, fc, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
         self._gemm(self._operand(fc, "vit_fc", Fvp), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
         return xq, G, cmap, Pc

@@ -19,9 +19,10 @@ def _draw(specs, device, seed):
     return synth.counter_state_dict(specs, seed, device)
 
 
-def packed_random_weights(cfg: ITGConfig, dtype: torch.dtype, device, seed: int = 0, fp8: bool = False) -> PackedWeights:
+def packed_random_weights(cfg: ITGConfig, dtype: torch.dtype, device, seed: int = 0, fp8: bool = False,
+                          vit_dtype=None) -> PackedWeights:
     device = torch.device(device)
-    pw = PackedWeights(cfg=cfg, dtype=dtype, device=device, fp8=fp8)
+    pw = PackedWeights(cfg=cfg, dtype=dtype, device=device, fp8=fp8, vit_dtype=vit_dtype)
     vspecs = list(synth.vision_param_specs(cfg))
     lspecs = list(synth.llm_param_specs(cfg))
     pw.pack_vision_embeddings(_draw([s for s in vspecs if s[0].startswith("vision_model.embeddings.")], device, seed))
