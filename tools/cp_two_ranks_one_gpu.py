@@ -34,7 +34,14 @@ def worker(rank, world, frames, port, q):
         cfg, eng = build()
         pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
         ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
-        out = ContextParallel(rank, world).forward(eng, ids, pix)
+        cp = ContextParallel(rank, world)
+        fr = cp.local_frames(frames)
+        local = pix[fr.start:fr.stop].clone()                 # every rank hands over ONLY its own frames
+        first = cp.forward(eng, ids, local, total_frames=frames)
+        out = cp.forward(eng, ids, local, total_frames=frames)  # second call: cached gatherer (buffers + compaction index reused)
+        assert torch.equal(first, out) and len(cp._gatherers) == 1
+        whole = cp.forward(eng, ids, pix)                      # the whole video resident: same result
+        assert torch.equal(whole, out)
         torch.cuda.synchronize()
         if rank == 0:
             q.put(out.float().cpu())

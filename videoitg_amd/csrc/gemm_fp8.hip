@@ -273,56 +273,73 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const TI* __restrict__ 
     }
 }
 
-// LayerNorm / RMSNorm fused with the per-token quantiser: y = norm(x) * w (+ b) in fp32, then amax / fp8 as above.  One block
-// per row, the row is held in registers (D <= 4096: 4 values x 4 per thread).
-template <bool RMS>
+// rows of up to 8192 values: ONE WAVE per row, the row stays in registers (single read, no LDS, no block barrier); 4 rows per block
+template <typename TI, int VPL>       // VPL = f32x4 groups per lane: D <= 256 * VPL
+__global__ __launch_bounds__(256) void quant_rows_wave_kernel(const TI* __restrict__ x, long ldx, unsigned char* __restrict__ out, long ldo,
+                                                              float* __restrict__ scale, long M, int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const TI* xr = x + row * ldx;
+    f32x4 v[VPL];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? load4<TI>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3]))));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    unsigned* orow = (unsigned*)(out + row * ldo);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < ldo) orow[c >> 2] = c < D ? pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv) : 0u;
+    }
+}
+
+// LayerNorm / RMSNorm fused with the per-token quantiser: y = norm(x) * w (+ b) in fp32, then amax / fp8 as above.  One WAVE per
+// row (like norm_kernel in elementwise.hip), the row in registers: a single HBM read, no LDS, no block barrier; D <= 256 * VPL.
+template <bool RMS, int VPL>
 __global__ __launch_bounds__(256) void norm_quant_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                          const float* __restrict__ b, unsigned char* __restrict__ out, long ldo,
-                                                         float* __restrict__ scale, int D, float eps) {
-    __shared__ float red[4];
-    __shared__ float red2[4];
-    const long row = blockIdx.x;
+                                                         float* __restrict__ scale, long M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
     const float* xr = x + row * ldx;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 v[4];
+    f32x4 v[VPL];
     float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = threadIdx.x * 4 + i * 1024;
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
         v[i] = c < D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s += v[i][e]; ss += v[i][e] * v[i][e]; }
     }
-    s = wave_sum(s);
-    ss = wave_sum(ss);
-    if (lane == 0) { red[wave] = s; red2[wave] = ss; }
-    __syncthreads();
-    s = red[0] + red[1] + red[2] + red[3];
-    ss = red2[0] + red2[1] + red2[2] + red2[3];
-    __syncthreads();
     float mean = 0.f, rstd;
-    if (RMS) rstd = rsqrtf(ss / D + eps);
+    if (RMS) rstd = rsqrtf(wave_sum(ss) / D + eps);
     else {
-        mean = s / D;
+        mean = wave_sum(s) / D;
         // two-pass variance on the register-resident row (the one-pass form cancels badly on the residual stream's outlier channels)
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = threadIdx.x * 4 + i * 1024;
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (c + e < D) { const float d = v[i][e] - mean; q += d * d; }
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
         }
-        q = wave_sum(q);
-        if (lane == 0) red[wave] = q;
-        __syncthreads();
-        q = red[0] + red[1] + red[2] + red[3];
-        __syncthreads();
-        rstd = rsqrtf(q / D + eps);
+        rstd = rsqrtf(wave_sum(q) / D + eps);
     }
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = threadIdx.x * 4 + i * 1024;
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
         if (c < D) {
             const f32x4 wv = *(const f32x4*)(w + c);
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -334,14 +351,14 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(const float* __restrict
             }
         }
     }
-    amax = block_max_256(amax, red);
+    amax = wave_max(amax);
     const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
     const float inv = 1.0f / sc;
-    if (threadIdx.x == 0) scale[row] = sc;
+    if (lane == 0) scale[row] = sc;
     unsigned* orow = (unsigned*)(out + row * ldo);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = threadIdx.x * 4 + i * 1024;
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
         if (c < ldo) orow[c >> 2] = c < D ? pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv) : 0u;
     }
 }
@@ -376,6 +393,18 @@ extern "C" int vitg_quant_rows_fp8(const void* x, long ldx, int in_dtype, void* 
     if (M <= 0) return 0;
     if (D <= 0 || D % 4 || ldx % 4 || ldo % 16 || ldo < D) return VITG_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
+    if (ldo <= 8192) {                   // one wave per row, row in registers
+        dim3 g4((unsigned)((M + 3) / 4)), b4(256);
+#define QW(T, V) hipLaunchKernelGGL((quant_rows_wave_kernel<T, V>), g4, b4, 0, s, (const T*)x, ldx, (unsigned char*)out8, ldo, scale, M, D)
+#define QWD(T) do { if (ldo <= 1280) QW(T, 5); else if (ldo <= 2048) QW(T, 8); else if (ldo <= 4608) QW(T, 18); else QW(T, 32); } while (0)
+        if (in_dtype == DT_F32) QWD(float);
+        else if (in_dtype == DT_BF16) QWD(bf16_t);
+        else if (in_dtype == DT_F16) QWD(f16_t);
+        else return VITG_ERR_DTYPE;
+#undef QWD
+#undef QW
+        return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+    }
     dim3 grid((unsigned)M), blk(256);
     if (in_dtype == DT_F32) hipLaunchKernelGGL((quant_rows_kernel<float>), grid, blk, 0, s, (const float*)x, ldx, (unsigned char*)out8, ldo, scale, D);
     else if (in_dtype == DT_BF16) hipLaunchKernelGGL((quant_rows_kernel<bf16_t>), grid, blk, 0, s, (const bf16_t*)x, ldx, (unsigned char*)out8, ldo, scale, D);
@@ -390,8 +419,10 @@ extern "C" int vitg_norm_quant_fp8(const float* x, long ldx, const float* w, con
     if (D <= 0 || D > 4096 || D % 4 || ldx % 4 || ldo % 16 || ldo < D || ldo > 4096) return VITG_ERR_ALIGN;
     if (!w) return VITG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)M), blk(256);
-    if (b) hipLaunchKernelGGL((norm_quant_kernel<false>), grid, blk, 0, s, x, ldx, w, b, (unsigned char*)out8, ldo, scale, D, eps);
-    else hipLaunchKernelGGL((norm_quant_kernel<true>), grid, blk, 0, s, x, ldx, w, b, (unsigned char*)out8, ldo, scale, D, eps);
+    dim3 grid((unsigned)((M + 3) / 4)), blk(256);
+#define NQ(R, V) hipLaunchKernelGGL((norm_quant_kernel<R, V>), grid, blk, 0, s, x, ldx, w, b, (unsigned char*)out8, ldo, scale, M, D, eps)
+    if (b) { if (ldo <= 1280) NQ(false, 5); else NQ(false, 16); }
+    else { if (ldo <= 1280) NQ(true, 5); else NQ(true, 16); }
+#undef NQ
     return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
 }
