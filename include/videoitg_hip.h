@@ -75,6 +75,16 @@ int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int 
               const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
               void* stream);
 
+/* Deterministic split-K form of vitg_gemm(mode = VITG_GEMM_F32, act = none) for shapes with FEW output tiles and a long K - the
+ * o / down projections of one rank of the context-parallel LLM (M = 12 860 / 8 rows: 98 tiles of 256 x 256 on 256 CUs).
+ * vitg_gemm_splitk_plan tells how many splits pay off on this device (1 = use vitg_gemm) and how much fp32 workspace they need;
+ * vitg_gemm_splitk runs `splits` blocks per output tile, each over its own K range into its own partial buffer, then
+ * out[m,n] = partial_0 + partial_1 + ... + bias[n] + res[m,n] in that fixed order (no atomics: run-to-run bit-identical).
+ * Same reference call sites as vitg_gemm (o_proj / down_proj + residual add, [3P] modeling_qwen2 via grounding_qwen2.py:135). */
+int vitg_gemm_splitk_plan(int M, int N, int K, int* splits, long* workspace_bytes);
+int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
+                     int ldo, const float* res, int ldr, float* workspace, int splits, void* stream);
+
 /* ---- FP8 weight path (BASELINE.json configs[4]; videoitg_amd/csrc/gemm_fp8.hip) ------------------------------------------------
  * The reference runs fp16 everywhere (/root/reference/eagle/model/builder.py:59), so this is an additional precision tier of the
  * same GEMM call sites as vitg_gemm: weights are stored as OCP e4m3fn bytes with one fp32 scale per OUTPUT CHANNEL (quantised

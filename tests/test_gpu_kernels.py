@@ -348,3 +348,25 @@ def test_attention_key_count_from_device_memory(ops, attn_waves, dtype, H, HKV, 
     want = ref_attention(q[:, :, :real], k[:, :, :real], v[:, :, :real], D ** -0.5)
     got = o_dyn[:real].float().cpu().view(1, real, H, D).permute(0, 2, 1, 3)
     assert (got - want).abs().max().item() <= 6 * EPS16[dtype] * v.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,splits", [(1660, 3584, 3584, 2), (1660, 3584, 18944, 2), (700, 1024, 4096, 4), (300, 520, 2048, 3)])
+def test_gemm_splitk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K, splits):
+    """split-K (o / down projection of one context-parallel rank): same value as the one-pass fp32-residual GEMM up to fp32
+    re-association, bit-identical from run to run (partials are reduced in a fixed order, no atomics)"""
+    a, w = rnd((M, K), 41, dtype=dtype).to(dtype).cuda(), (rnd((N, K), 42, dtype=dtype) * K ** -0.5).to(dtype).cuda()
+    bias, res = rnd((N,), 43).cuda(), rnd((M, N), 44).cuda()
+    want = res.clone()
+    ops.gemm(a, w, want, mode=ops.GEMM_F32, bias=bias, res=want)
+    ws = torch.empty(splits * M * N, dtype=torch.float32, device="cuda")
+    outs = []
+    for _ in range(2):
+        x = res.clone()
+        ops.gemm_splitk(a, w, x, ws, splits, bias=bias, res=x)
+        outs.append(x)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    sp, nb = ops.gemm_splitk_plan(1660, 3584, 18944)
+    assert sp == 2 and nb == 2 * 1660 * 3584 * 4
+    assert ops.gemm_splitk_plan(12860, 3584, 18944)[0] == 1 and ops.gemm_splitk_plan(1660, 3584, 1152)[0] == 1

@@ -210,6 +210,7 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
     g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4; g.Wf = Wf;
+    g.split_k = 1; g.split_stride = 0;
     // bits 1-4 and 6 of gemm_flags are profiling ablations that produce WRONG results; they only take effect in a process that
     // opted in with VITG_PROFILING=1 (tools/ set it), so a stray option or environment variable cannot corrupt a product run
     static const bool profiling = [] { const char* e = getenv("VITG_PROFILING"); return e && atoi(e) != 0; }();
@@ -252,3 +253,61 @@ extern "C" int vitg_gemm_wf(const void* A, int lda, const void* W, int ldw, cons
     return gemm_entry(A, lda, W, ldw, Wf, M, N, K, dtype, mode, bias, act, out, ldo, res, ldr, res_mod, stream);
 }
 #endif
+
+// ---- deterministic split-K for fp32-residual GEMMs with few output tiles ---------------------------------------------------------
+namespace vitg {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, long split_stride, int splits, int ldw,
+                                                            const float* __restrict__ bias, const float* __restrict__ res, int ldr,
+                                                            float* __restrict__ out, int ldo, int N) {
+    const long m = blockIdx.x;
+    for (int n = threadIdx.x * 4; n < N; n += 1024) {
+        f32x4 v = *(const f32x4*)(ws + m * ldw + n);                       // fixed order: partial 0, 1, 2, ... then bias, then residual
+        for (int s = 1; s < splits; ++s) v += *(const f32x4*)(ws + s * split_stride + m * ldw + n);
+        if (bias) v += *(const f32x4*)(bias + n);
+        if (res) v += *(const f32x4*)(res + m * ldr + n);
+        *(f32x4*)(out + m * ldo + n) = v;
+    }
+}
+}  // namespace vitg
+
+extern "C" int vitg_gemm_splitk_plan(int M, int N, int K, int* splits, long* workspace_bytes) {
+    if (!splits || !workspace_bytes) return VITG_ERR_ARG;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    int sp = 1;
+    // worth it only when one round of 256x256 tiles leaves most of the chip idle and every split still has a real K loop
+    if (M >= 256 && N >= 256 && N % 8 == 0 && tiles * 2 <= cus && K >= 2048) {
+        sp = (int)(cus / tiles);
+        if (sp > 4) sp = 4;
+        while (sp > 1 && K / 64 / sp < 16) --sp;
+    }
+    *splits = sp;
+    *workspace_bytes = sp > 1 ? (long)sp * M * N * 4 : 0;
+    return 0;
+}
+
+extern "C" int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias,
+                                float* out, int ldo, const float* res, int ldr, float* workspace, int splits, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (splits < 2 || !workspace) return VITG_ERR_ARG;
+    if (N % 4 || ldo % 4 || (res && ldr % 4)) return VITG_ERR_ALIGN;
+    if (K / BK < splits) return VITG_ERR_SHAPE;
+    set_attrs();
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = nullptr; g.act = VITG_ACT_NONE; g.out = workspace; g.ldo = N; g.res = nullptr; g.ldr = 0; g.res_mod = 0;
+    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4; g.Wf = nullptr; g.flags = 0;
+    g.split_k = splits; g.split_stride = (long)M * N;
+    if (K <= 0 || K % BK != 0) return VITG_ERR_SHAPE;
+    if ((lda % 8) || (ldw % 8)) return VITG_ERR_ALIGN;
+    if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
+    if (!gemm256_applicable(g, VITG_GEMM_F32)) return VITG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (launch_gemm256(g, dtype, VITG_GEMM_F32, s) != 0) return VITG_ERR_LAUNCH;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)M), dim3(256), 0, s, workspace, g.split_stride, splits, N, bias, res, ldr, out, ldo, N);
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}

@@ -32,8 +32,22 @@ constexpr int G2_BM = 256, G2_THREADS = 512;
 #endif                             // main loop; in the product build they are compiled out: every test of g.flags in an interval is a scalar
                                    // branch, and eight of them per read interval cost the phased loop 5-10 % (profiles/r01_gemm_shapes.md section 16)
 template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM>
-__global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g) {
+__global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g_) {
     typedef typename T16<T>::vec8 vec8;
+    GemmArgs g = g_;
+    if constexpr (MODE == MODE_F32) {
+        // split-K (small-M shapes of the context-parallel LLM: 98 tiles on 256 CUs): block y of a tile takes K-tiles [k0, k0 + cnt)
+        // and stores its raw fp32 partial into its own buffer; everything below just sees a shorter K and another output pointer
+        if (g.split_k > 1) {
+            const int sp = blockIdx.y;
+            const int nk_all = g.K / BK, per = nk_all / g.split_k, rem = nk_all % g.split_k;
+            const int k0 = sp * per + min(sp, rem);
+            g.A = (const char*)g.A + (size_t)k0 * BK * 2;
+            g.W = (const char*)g.W + (size_t)k0 * BK * 2;
+            g.K = (per + (sp < rem ? 1 : 0)) * BK;
+            g.out = (float*)g.out + (size_t)sp * g.split_stride;
+        }
+    }
     constexpr bool PROF = VITG_PROFILING_BUILD != 0;
     constexpr int WN = 8 / WM;
     constexpr int MT = BM / WM / 32;                  // 32-row activation tiles per wave
@@ -707,7 +721,8 @@ static int launch256(GemmArgs g, hipStream_t s) {
     if (!cus) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur_dev);
     const int nwg = g.tiles_m * g.tiles_n;
     const bool loop = BN >= 256 && nwg >= 2 * cus && (tuning().gemm_flags & 0x1000000);   // bit24: opt-in until the in-step A/B says otherwise
-    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>), dim3(loop ? cus : nwg), dim3(G2_THREADS), lds, s, g);
+    const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
+    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
 
@@ -768,6 +783,7 @@ template <typename T, int MODE>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     int cfg = tuning().gemm_cfg;
     if (!cfg) cfg = choose_cfg(g, MODE);
+    if (MODE == MODE_F32 && g.split_k > 1) cfg = 6;           // split-K partials: 256x256 tiles (the plan of vitg_gemm_splitk_plan assumes them)
 #if VITG_PROFILING_BUILD
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
 #endif

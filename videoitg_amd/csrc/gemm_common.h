@@ -22,6 +22,8 @@ struct GemmArgs {
     int stagger_ns;           // persistent kernel: tile period estimate for de-phasing the XCDs (0 = off)
     int flags;                // bit0: non-temporal output stores, bit1: (profiling) skip output stores
     const void* Wf;           // fragment-packed copy of W (vitg_pack_weight_fragments) or null
+    int split_k;              // MODE_F32 only: gridDim.y = split_k blocks share one output tile, block y accumulates its K range and
+    long split_stride;        // writes the raw fp32 partial tile to out + y * split_stride floats (vitg_gemm_splitk reduces them)
 };
 
 enum { MODE_STORE16 = 0, MODE_F32 = 1, MODE_SWIGLU = 2 };

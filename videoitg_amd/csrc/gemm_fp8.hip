@@ -382,7 +382,7 @@ extern "C" int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const voi
     GemmArgs& g = ga.g;
     g.A = A8; g.lda = lda; g.W = W8; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
-    g.tiles_m = g.tiles_n = 0; g.stagger_ns = 0; g.group_m = 4; g.Wf = nullptr; g.flags = 0;
+    g.tiles_m = g.tiles_n = 0; g.stagger_ns = 0; g.group_m = 4; g.Wf = nullptr; g.flags = 0; g.split_k = 1; g.split_stride = 0;
     ga.sa = sa; ga.sw = sw;
     const int rc = out_dtype == DT_BF16 ? launch_fp8_t<bf16_t>(ga, mode, (hipStream_t)stream) : launch_fp8_t<f16_t>(ga, mode, (hipStream_t)stream);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;

@@ -214,6 +214,7 @@ class SelectorEngine:
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[str, torch.Tensor] = {}
         self._poolsrc: Dict[tuple, object] = {}
+        self._splitk: Dict[tuple, tuple] = {}        # (M, N, K) -> (splits, workspace bytes) from vitg_gemm_splitk_plan
 
     # workspace: ONE buffer per name, grown to the largest row count seen and handed out as a [:rows] view, so a run over
     # documents with varying prompt lengths / frame counts holds max-size buffers instead of one set per distinct shape.
@@ -265,6 +266,15 @@ class SelectorEngine:
     def _gemm(self, a, w, out: torch.Tensor, **kw) -> torch.Tensor:
         if isinstance(w, Fp8Weight):
             return K.gemm_fp8(a[0], a[1], w.w8, w.sw, out, out_dtype=out.dtype if out.dtype != torch.float32 else self.dtype, **kw)
+        if kw.get("mode") == K.GEMM_F32 and kw.get("act", 0) == 0 and not kw.get("res_mod", 0) and out.dtype == torch.float32:
+            # few output tiles + long K (o / down projection of one context-parallel rank): deterministic split-K
+            M, N, Kd = a.shape[0], w.shape[0], w.shape[1]
+            plan = self._splitk.get((M, N, Kd))
+            if plan is None:
+                plan = self._splitk[(M, N, Kd)] = K.gemm_splitk_plan(M, N, Kd)
+            if plan[0] > 1:
+                ws = self._buf("splitk_ws", (plan[0] * M * N,), torch.float32)
+                return K.gemm_splitk(a, w, out, ws, plan[0], bias=kw.get("bias"), res=kw.get("res"))
         return K.gemm(a, w, out, **kw)
 
     # ---- which tokens does the bilinear pool read? (mlp_proj.py:57-68 semantics: align_corners=False) ----------------

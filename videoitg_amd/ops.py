@@ -90,6 +90,27 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: O
     return out
 
 
+def gemm_splitk_plan(M: int, N: int, K: int):
+    """-> (splits, workspace_bytes): splits == 1 means the plain GEMM is the right call (vitg_gemm_splitk_plan)"""
+    sp, nb = C.c_int(0), C.c_long(0)
+    _lib.call("vitg_gemm_splitk_plan", M, N, K, C.byref(sp), C.byref(nb))
+    return sp.value, nb.value
+
+
+def gemm_splitk(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor, splits: int, *,
+                bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out(fp32) = a @ w.T + bias + res through `splits` K-partials in `workspace` (fp32, >= splits*M*N), fixed summation order"""
+    _req(a)
+    _req(w, a.dtype)
+    _req(out, torch.float32)
+    _req(workspace, torch.float32)
+    M, K, N = a.shape[0], w.shape[1], w.shape[0]
+    assert a.shape[1] == K and workspace.numel() >= splits * M * N
+    _lib.call("vitg_gemm_splitk", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, N, K, dt_code(a.dtype), _ptr(bias), _ptr(out),
+              out.stride(0), _ptr(res), 0 if res is None else res.stride(0), _ptr(workspace), splits, _stream())
+    return out
+
+
 def pad128(n: int) -> int:
     return (n + 127) // 128 * 128
 

@@ -46,6 +46,10 @@ _def("gemm(Tensor a, Tensor w, Tensor(a!) out, int mode, int? n=None, Tensor? bi
          (_raw.gemm(a, w, out, mode=mode, n=n, bias=bias, act=act, res=res, res_mod=res_mod, m=m), None)[1],
      lambda a, w, out, mode, n=None, bias=None, act=0, res=None, res_mod=0, m=None: None)
 
+_def("gemm_splitk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int splits, Tensor? bias=None, Tensor? res=None) -> ()",
+     lambda a, w, out, workspace, splits, bias=None, res=None: (_raw.gemm_splitk(a, w, out, workspace, splits, bias=bias, res=res), None)[1],
+     lambda *a, **k: None)
+
 # ---- norms / rope ----------------------------------------------------------------------------------------------------------
 _def("layernorm(Tensor x, Tensor w, Tensor b, Tensor(a!) out, int d, float eps) -> ()",
      lambda x, w, b, out, d, eps: (_raw.layernorm(x, w, b, out, d, eps), None)[1], lambda x, w, b, out, d, eps: None)
@@ -121,6 +125,13 @@ class _Namespace:
         _ops.gemm(a, w, out, mode, n, bias, act, res, res_mod, m)
         return out
 
+    gemm_splitk_plan = staticmethod(_raw.gemm_splitk_plan)
+
+    @staticmethod
+    def gemm_splitk(a, w, out, workspace, splits, *, bias=None, res=None):
+        _ops.gemm_splitk(a, w, out, workspace, splits, bias, res)
+        return out
+
     @staticmethod
     def layernorm(x, w, b, out, d, eps):
         _ops.layernorm(x, w, b, out, d, eps)
@@ -194,5 +205,5 @@ class _Namespace:
 
 
 K = _Namespace()
-OP_NAMES: List[str] = ["patchify", "gemm", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
+OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
                        "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8"]
