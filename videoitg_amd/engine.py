@@ -79,7 +79,8 @@ class PackedWeights:
     vit_dtype: Optional[torch.dtype] = None         # MFMA input type of the SigLIP tower (None = dtype): the tower tolerates bf16 (8-bit
                                                     # mantissa) inside the 1e-3 score bound, the 28-layer bidirectional LLM does not
                                                     # (profiles/r02_parity.md), so "tower bf16 + LLM fp16" is a supported mix
-    fp8: bool = False                               # BASELINE.json configs[4]: tower / decoder GEMM weights as e4m3fn + per-channel scales
+    fp8: object = False                             # BASELINE.json configs[4]: tower / decoder GEMM weights as e4m3fn + per-channel scales;
+                                                    # True = both parts, "vit" / "llm" = that part only (the other stays 16-bit)
     patch_w: torch.Tensor = None; patch_b: torch.Tensor = None
     pos_native: torch.Tensor = None                # fp32 [P0, Dv]
     pos_cache: Dict[int, torch.Tensor] = field(default_factory=dict)
@@ -96,6 +97,7 @@ class PackedWeights:
         if self.vit_dtype is None:
             self.vit_dtype = self.dtype
         self._packing = self.dtype                  # type the _w16 / _wl helpers currently emit (switched while the tower is packed)
+        self._packing_part = "llm"
 
     def _w16(self, w: torch.Tensor, rows: Optional[int] = None, cols: Optional[int] = None) -> torch.Tensor:
         w = w.to(self.device)
@@ -107,7 +109,8 @@ class PackedWeights:
         """weight of a tower / decoder layer GEMM: 16-bit, or - on the fp8 weight path - e4m3fn bytes + per-output-channel scales
         (quantised from the SAME 16-bit-rounded, zero-padded matrix the 16-bit path would multiply with)"""
         w16 = self._w16(w, rows)
-        if not self.fp8:
+        part = "vit" if self._packing_part == "vit" else "llm"
+        if not (self.fp8 is True or self.fp8 == part):
             return w16
         w8, sw = K.quant_rows_fp8(w16, w16.shape[1], torch.empty((w16.shape[0], K.pad128(w16.shape[1])), dtype=torch.uint8, device=self.device),
                                   torch.empty(w16.shape[0], dtype=torch.float32, device=self.device))
@@ -132,7 +135,7 @@ class PackedWeights:
         fvp = pad64(v.intermediate_size)
         qkv_w = torch.cat([vsd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
         qkv_b = torch.cat([vsd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
-        self._packing = self.vit_dtype
+        self._packing, self._packing_part = self.vit_dtype, "vit"
         self.vit.append(VitLayerW(
             ln1_w=self._f32(vsd[p + "layer_norm1.weight"]), ln1_b=self._f32(vsd[p + "layer_norm1.bias"]),
             qkv_w=self._wl(qkv_w), qkv_b=self._f32(qkv_b),
@@ -141,7 +144,7 @@ class PackedWeights:
             fc1_w=self._wl(vsd[p + "mlp.fc1.weight"], rows=fvp), fc1_b=self._f32(vsd[p + "mlp.fc1.bias"], fvp),
             fc2_w=self._wl(vsd[p + "mlp.fc2.weight"]), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
         ))
-        self._packing = self.dtype
+        self._packing, self._packing_part = self.dtype, "llm"
 
     def pack_projector_and_head(self, sd: SD) -> None:
         pre = "model.mm_projector.out_projection."
@@ -242,7 +245,7 @@ class SelectorEngine:
               dt: Optional[torch.dtype] = None):
         """LayerNorm (b given) / RMSNorm of the fp32 residual rows as the A operand of the next GEMM"""
         M = x.shape[0]
-        if self.w.fp8:
+        if self._part_fp8(name):
             a8 = self._buf(name + "_q8", (M, K.pad128(d)), torch.uint8)
             sa = self._buf(name + "_qs", (M,), torch.float32)
             K.norm_quant_fp8(x, w, b, a8, sa, d, eps)
@@ -254,9 +257,14 @@ class SelectorEngine:
             K.rmsnorm(x, w, h, d, eps)
         return h
 
+    def _part_fp8(self, name: str) -> bool:
+        """workspace names start with vit_ / llm_: is that part on the fp8 weight path?"""
+        f = self.w.fp8
+        return f is True or (isinstance(f, str) and name.startswith(f + "_"))
+
     def _operand(self, t: torch.Tensor, name: str, d: int):
         """a 16-bit activation (attention output, GELU / SwiGLU output) as the A operand of the next GEMM"""
-        if not self.w.fp8:
+        if not self._part_fp8(name):
             return t
         a8 = self._buf(name + "_q8", (t.shape[0], K.pad128(d)), torch.uint8)
         sa = self._buf(name + "_qs", (t.shape[0],), torch.float32)
