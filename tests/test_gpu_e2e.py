@@ -177,7 +177,9 @@ def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,frames", [(2, 9), (3, 8), (8, 19)])
+# (frame counts below 16 keep the single-rank reference on the same 128-tile GEMM kernels as the ranks: at 304 rows it would switch to
+# the 256-tile kernels, which differ from them in fp32 summation order - a kernel-set difference, not a sharding one)
+@pytest.mark.parametrize("world,frames", [(2, 9), (3, 8), (8, 15)])
 def test_context_parallel_multi_rank_on_one_gpu(world, frames):
     """WORLD > 1 with the real kernels: `world` processes share cuda:0 and exchange over gloo (RCCL refuses two ranks on one
     device).  Frame shards are ragged (9 frames / 2 ranks, prompt tokens on the first and last rank), so global positions, the
