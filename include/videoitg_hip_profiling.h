@@ -29,6 +29,25 @@ int vitg_pack_weight_fragments(const void* W, int ldw, int N, int K, void* out, 
 int vitg_gemm_wf(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype, int mode,
                  const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod, void* stream);
 
+/* (round 2; measured SLOWER than the stand-alone norm kernels on every shape of the step - profiles/r02_fused_norm.md - and therefore not
+ * in the product library)  LayerNorm / RMSNorm folded into the GEMMs on either side of it: the stand-alone norm pass (read the fp32 residual stream, write a
+ * 16-bit copy) disappears.  With y = norm(x) = (x - mean) * rstd * gamma + beta feeding a Linear W (+ bias b):
+ *     W y + b  =  rstd * ( W (gamma * x)  -  mean * s )  +  c,      s[n] = sum_k gamma[k] W[n,k],   c = W beta + b   (both fp32, load time)
+ * PRODUCER (vitg_gemm_norm_producer) = vitg_gemm(mode F32, act none, res given) that additionally writes xh = round16(out * next_gamma)
+ * and, per row and per group of `cols` output columns (vitg_gemm_norm_plan; 0 = shape not covered, use the stand-alone norm),
+ * the partial statistics (mean, M2) of out: partials[m][N / cols][2].  vitg_norm_stats_finalize combines them (Chan's formula) into
+ * stats[m] = (mean, rstd) - for rms != 0: (0, rsqrt(mean(x^2) + eps)).  CONSUMER (vitg_gemm_norm_consumer) = vitg_gemm(mode STORE16 /
+ * SWIGLU) on A = xh with out = epilogue(rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]); colsum = s (LayerNorm) or NULL (RMSNorm),
+ * bias = c.  Replaces [3P] SigLIP layer_norm1/2 and Qwen2RMSNorm together with the Linear layers around them
+ * (clip_encoder.py:146, grounding_qwen2.py:135). */
+int vitg_gemm_norm_plan(int M, int N, int K, int* cols_per_partial);
+int vitg_gemm_norm_producer(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
+                            int ldo, const float* res, int ldr, int res_mod, const float* next_gamma, void* xh, int ldxh,
+                            float* partials, void* stream);
+int vitg_norm_stats_finalize(const float* partials, long M, int P, int cols, float eps, int rms, float* stats, void* stream);
+int vitg_gemm_norm_consumer(const void* XH, int lda, const void* W, int ldw, int M, int N, int K, int dtype, int mode, const float* bias,
+                            int act, void* out, int ldo, const float* stats, const float* colsum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

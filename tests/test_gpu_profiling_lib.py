@@ -1,10 +1,12 @@
 """-m gpu, ONLY with VITG_PROFILING_LIB=1 and libvideoitg_hip_prof.so built (videoitg_amd/csrc/build.sh --profiling): the research
 GEMM variants of round 1 (fragment-packed weights, persistent kernel with deferred epilogue) stay bit-identical to the shipped
 kernels.  Not part of the product test matrix: the product library does not contain these entry points."""
+import math
 import os
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("VITG_PROFILING_LIB", "0") in ("", "0"), reason="profiling library not selected")]
@@ -103,3 +105,113 @@ def test_gemm_persistent_deferred_epilogue_swiglu_bit_identical(ops, dtype, M, F
     assert torch.isfinite(outs[13].float()).all() and torch.equal(outs[13], outs[6])
 
 
+# ---- LayerNorm / RMSNorm folded into the GEMMs around it (vitg_gemm_norm_*) --------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,res_mod", [(1024, 1152, 1152, 0), (2048, 1152, 4352, 0), (300, 3584, 3584, 0), (1458, 1152, 640, 729), (700, 256, 256, 0)])
+def test_fused_norm_producer(ops, dtype, M, N, K, res_mod):
+    """out must equal the plain fp32-residual GEMM bit for bit; xh = round16(out * gamma); finalised statistics = the row mean /
+    rstd of out (LayerNorm) and rsqrt(mean(out^2) + eps) (RMSNorm) to fp32 accuracy"""
+    cols = ops.gemm_norm_plan(M, N, K)
+    assert cols in (64, 96) and N % cols == 0
+    a, w = rnd((M, K), 51, dtype=dtype).to(dtype).cuda(), (rnd((N, K), 52, dtype=dtype) * K ** -0.5).to(dtype).cuda()
+    bias, gamma = rnd((N,), 53).cuda(), (1 + 0.1 * rnd((N,), 54)).cuda()
+    res = (rnd((res_mod or M, N), 55) * 3 + 0.5).cuda()
+    want = torch.empty((M, N), device="cuda") if res_mod else res.clone()
+    ops.gemm(a, w, want, mode=ops.GEMM_F32, bias=bias, res=res if res_mod else want, res_mod=res_mod)
+    out = torch.empty((M, N), device="cuda") if res_mod else res.clone()
+    xh = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    P = N // cols
+    part = torch.empty(M * P * 2, device="cuda")
+    ops.gemm_norm_producer(a, w, out, res=res if res_mod else out, next_gamma=gamma, xh=xh, partials=part, bias=bias, res_mod=res_mod)
+    assert torch.equal(out, want)
+    want_xh = (out * gamma)
+    assert ((xh.float() - want_xh).abs() <= EPS16[dtype] * want_xh.abs() + 1e-7).all()      # one rounding to 16 bit, nothing more
+    for rms in (False, True):
+        stats = torch.empty(M * 2, device="cuda")
+        ops.norm_stats_finalize(part, M, P, cols, 1e-6, rms, stats)
+        st = stats.view(M, 2).double().cpu()
+        o = out.double().cpu()
+        if rms:
+            assert (st[:, 0] == 0).all()
+            assert torch.allclose(st[:, 1], torch.rsqrt((o * o).mean(-1) + 1e-6), rtol=2e-6, atol=0)
+        else:
+            assert torch.allclose(st[:, 0], o.mean(-1), rtol=0, atol=3e-6 * o.abs().max().item())
+            assert torch.allclose(st[:, 1], torch.rsqrt(o.var(-1, unbiased=False) + 1e-6), rtol=5e-6, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,act", [(1024, 3456, 1152, 0), (1000, 4352, 1152, 1), (300, 4608, 3584, 0), (512, 384, 256, 1)])
+def test_fused_norm_consumer_layernorm(ops, dtype, M, N, K, act):
+    """epilogue(rstd * (xh @ W^T - mean * s) + c) == Linear(LayerNorm(x)) up to the 16-bit rounding of xh = x * gamma"""
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn((M, K), generator=g) * 2 + 0.3 * torch.randn((M, 1), generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    w = (torch.randn((N, K), generator=g) * K ** -0.5).to(dtype)
+    b = 0.1 * torch.randn(N, generator=g)
+    xh = (x * gamma).to(dtype)
+    mean, rstd = x.mean(-1), torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
+    stats = torch.stack([mean, rstd], 1).contiguous().cuda()
+    wf = w.float()
+    colsum, c = (wf @ gamma).cuda(), (wf @ beta + b).cuda()
+    out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    ops.gemm_norm_consumer(xh.cuda(), w.cuda(), out, mode=ops.GEMM_STORE16, stats=stats.view(-1), colsum=colsum, bias=c,
+                           act=ops.ACT_GELU_TANH if act else ops.ACT_NONE)
+    # reference with the SAME rounded operand (what the kernel is asked to compute), then against the true LayerNorm path
+    ref = rstd[:, None] * (xh.float() @ wf.t() - mean[:, None] * colsum.cpu()) + c.cpu()
+    true = torch.nn.functional.layer_norm(x, (K,), gamma, beta, 1e-6) @ wf.t() + b
+    if act:
+        from oracle.videoitg_oracle import gelu_tanh
+        ref, true = gelu_tanh(ref), gelu_tanh(true)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= EPS16[dtype] * ref.abs().max().item() + 2e-3
+    assert (got - true).abs().max().item() <= 6 * EPS16[dtype] * max(1.0, true.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_norm_consumer_rmsnorm_swiglu(ops, dtype):
+    M, F_, K = 600, 1024, 512
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn((M, K), generator=g) * 3
+    gamma = 1 + 0.1 * torch.randn(K, generator=g)
+    gate, up = (torch.randn((F_, K), generator=g) * K ** -0.5).to(dtype), (torch.randn((F_, K), generator=g) * K ** -0.5).to(dtype)
+    gu = torch.cat([gate.view(F_ // 32, 1, 32, K), up.view(F_ // 32, 1, 32, K)], 1).reshape(2 * F_, K)
+    xh = (x * gamma).to(dtype)
+    rstd = torch.rsqrt((x * x).mean(-1) + 1e-6)
+    stats = torch.stack([torch.zeros(M), rstd], 1).contiguous().cuda()
+    out = torch.empty((M, F_), dtype=dtype, device="cuda")
+    ops.gemm_norm_consumer(xh.cuda(), gu.cuda(), out, mode=ops.GEMM_SWIGLU, stats=stats.view(-1))
+    h = xh.float() * rstd[:, None]
+    want = torch.nn.functional.silu(h @ gate.float().t()) * (h @ up.float().t())
+    assert (out.float().cpu() - want).abs().max().item() <= 2 * EPS16[dtype] * want.abs().max().item() + 2e-3
+
+
+@pytest.mark.parametrize("name", ["depth16_224", "c1_64x384"])
+def test_fused_norm_forward_matches_unfused_and_oracle(golden_dir, name):
+    """LayerNorm / RMSNorm folded into the neighbouring GEMMs (engine.fuse_norm) at full depth and width: same scores as the
+    stand-alone-norm path to well inside the tolerance, and the 1e-3 gate against the complete oracle pass still holds (fp16)."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig
+    from videoitg_amd.engine import SelectorEngine
+    from videoitg_amd.synth_device import packed_random_weights
+    import json
+    path = os.path.join(golden_dir, f"full_{name}.json")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    rec = json.load(open(path))
+    cfg = ITGConfig()
+    eng = SelectorEngine(packed_random_weights(cfg, torch.float16, "cuda:0", seed=rec["weight_seed"]))
+    ids, pix = synth.workload_inputs(cfg, rec["frames"], rec["resolution"], rec["prompt_len"], rec["pixel_seed"])
+    pix = pix.half().cuda()
+    outs = {}
+    for fuse in (False, True):
+        eng.fuse_norm = fuse
+        outs[fuse] = eng.forward(ids, None, [pix])[0].view(-1).float().cpu()
+    assert sum(1 for v in eng._normplan.values() if v > 0) >= 3                          # the fused kernels really ran
+    want = torch.tensor(rec["logits"])
+    sg = torch.sigmoid
+    d_uf = (sg(outs[True]) - sg(outs[False])).abs().max().item()
+    d_or = (sg(outs[True]) - sg(want)).abs().max().item()
+    print(f"fused norm {name}: max|dscore| vs unfused {d_uf:.2e}, vs oracle {d_or:.2e} (unfused vs oracle {(sg(outs[False]) - sg(want)).abs().max().item():.2e})")
+    assert d_uf <= 5e-4 and d_or <= 1e-3
+    eng.release_workspace()

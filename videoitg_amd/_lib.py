@@ -55,6 +55,10 @@ PROFILING_SIGNATURES = {
     "vitg_gemm_wf": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "vitg_weight_fragments_bytes": [_i, _i, C.POINTER(C.c_long)],
     "vitg_pack_weight_fragments": [_p, _i, _i, _i, _p, _p],
+    "vitg_gemm_norm_plan": [_i, _i, _i, C.POINTER(C.c_int)],
+    "vitg_gemm_norm_producer": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _i, _p, _p, _i, _p, _p],
+    "vitg_norm_stats_finalize": [_p, _l, _i, _i, _f, _i, _p, _p],
+    "vitg_gemm_norm_consumer": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p],
 }
 
 _lib = None

@@ -195,9 +195,14 @@ static void set_attrs() {
 #undef SETA
 }
 
+struct NormFusion {               // fused normalisation around a GEMM (see GemmArgs::nrm_*): producer or consumer fields, never both
+    const float* gamma = nullptr; void* xh = nullptr; int ldxh = 0; float* part = nullptr; int P = 0;
+    const float* stats = nullptr; const float* colsum = nullptr;
+};
+
 static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype,
                       int mode, const float* bias, int act, void* out, int ldo,
-                      const float* res, int ldr, int res_mod, void* stream) {
+                      const float* res, int ldr, int res_mod, void* stream, const NormFusion* nf = nullptr) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || K % BK != 0) return VITG_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8)) return VITG_ERR_ALIGN;
@@ -206,11 +211,19 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     if (mode != VITG_GEMM_SWIGLU && (N % 4 != 0 || ldo % 4 != 0)) return VITG_ERR_ALIGN;
     if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
     set_attrs();
-    GemmArgs g;
+    GemmArgs g = {};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
     g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4; g.Wf = Wf;
     g.split_k = 1; g.split_stride = 0;
+    if (nf) {                                // (callers exist in the profiling build only)
+        g.nrm_gamma = nf->gamma; g.nrm_xh = nf->xh; g.nrm_ldxh = nf->ldxh; g.nrm_part = nf->part; g.nrm_P = nf->P;
+        g.nrm_stats = nf->stats; g.nrm_colsum = nf->colsum;
+        // the fused forms live in the 256-tile kernels' staged epilogues only
+        if (tuning().gemm_tile == 128 || !gemm256_applicable(g, mode)) return VITG_ERR_SHAPE;
+        const int rc = launch_gemm256(g, dtype, mode, (hipStream_t)stream);
+        return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+    }
     // bits 1-4 and 6 of gemm_flags are profiling ablations that produce WRONG results; they only take effect in a process that
     // opted in with VITG_PROFILING=1 (tools/ set it), so a stray option or environment variable cannot corrupt a product run
     static const bool profiling = [] { const char* e = getenv("VITG_PROFILING"); return e && atoi(e) != 0; }();
@@ -297,7 +310,7 @@ extern "C" int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, 
     if (N % 4 || ldo % 4 || (res && ldr % 4)) return VITG_ERR_ALIGN;
     if (K / BK < splits) return VITG_ERR_SHAPE;
     set_attrs();
-    GemmArgs g;
+    GemmArgs g = {};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = nullptr; g.act = VITG_ACT_NONE; g.out = workspace; g.ldo = N; g.res = nullptr; g.ldr = 0; g.res_mod = 0;
     g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4; g.Wf = nullptr; g.flags = 0;
@@ -311,3 +324,69 @@ extern "C" int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, 
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)M), dim3(256), 0, s, workspace, g.split_stride, splits, N, bias, res, ldr, out, ldo, N);
     return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
 }
+
+#if VITG_PROFILING_BUILD
+// ---- LayerNorm / RMSNorm folded into the GEMMs on either side of it (round 2; measured slower than the stand-alone norm pass, kept
+//      in the profiling library: include/videoitg_hip_profiling.h, profiles/r02_fused_norm.md) ------------------------------------------
+namespace vitg {
+// one thread per row: Chan-combine the P equal-sized partials (mean_p, M2_p) -> (mean, rstd); RMSNorm: (0, rsqrt(E[x^2] + eps))
+__global__ __launch_bounds__(256) void norm_stats_finalize_kernel(const float* __restrict__ part, long M, int P, int cols, float eps, int rms,
+                                                                  float* __restrict__ stats) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const f32x2* p = (const f32x2*)(part + (size_t)m * P * 2);
+    float sm = 0.f;
+    for (int i = 0; i < P; ++i) sm += p[i][0];
+    const float mean = sm / P;
+    float m2 = 0.f;
+    for (int i = 0; i < P; ++i) { const float d = p[i][0] - mean; m2 += p[i][1] + cols * d * d; }
+    const float D = (float)P * cols;
+    f32x2 o;
+    if (rms) { o[0] = 0.f; o[1] = rsqrtf((m2 + D * mean * mean) / D + eps); }
+    else { o[0] = mean; o[1] = rsqrtf(m2 / D + eps); }
+    *(f32x2*)(stats + 2 * m) = o;
+}
+}  // namespace vitg
+
+extern "C" int vitg_gemm_norm_plan(int M, int N, int K, int* cols_per_partial) {
+    if (!cols_per_partial) return VITG_ERR_ARG;
+    GemmArgs g = {};
+    g.M = M; g.N = N; g.K = K; g.ldo = N; g.ldr = N; g.res = (const float*)1;
+    int cols = (K > 0 && K % 64 == 0) ? gemm256_norm_cols(g) : 0;
+    if (cols && N % cols) cols = 0;                      // every partial must cover `cols` real columns
+    *cols_per_partial = cols;
+    return 0;
+}
+
+extern "C" int vitg_gemm_norm_producer(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias,
+                                       float* out, int ldo, const float* res, int ldr, int res_mod, const float* next_gamma, void* xh,
+                                       int ldxh, float* partials, void* stream) {
+    if (!res || !next_gamma || !xh || !partials) return VITG_ERR_ARG;
+    if (ldxh % 8) return VITG_ERR_ALIGN;
+    int cols = 0;
+    (void)vitg_gemm_norm_plan(M, N, K, &cols);
+    if (!cols) return VITG_ERR_SHAPE;
+    NormFusion nf;
+    nf.gamma = next_gamma; nf.xh = xh; nf.ldxh = ldxh; nf.part = partials; nf.P = N / cols;
+    return gemm_entry(A, lda, W, ldw, nullptr, M, N, K, dtype, VITG_GEMM_F32, bias, VITG_ACT_NONE, out, ldo, res, ldr, res_mod, stream, &nf);
+}
+
+extern "C" int vitg_norm_stats_finalize(const float* partials, long M, int P, int cols, float eps, int rms, float* stats, void* stream) {
+    if (M <= 0) return 0;
+    if (!partials || !stats || P <= 0 || cols <= 0) return VITG_ERR_ARG;
+    hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, M, P, cols,
+                       eps, rms, stats);
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}
+
+extern "C" int vitg_gemm_norm_consumer(const void* XH, int lda, const void* W, int ldw, int M, int N, int K, int dtype, int mode,
+                                       const float* bias, int act, void* out, int ldo, const float* stats, const float* colsum,
+                                       void* stream) {
+    if (!stats) return VITG_ERR_ARG;
+    if (mode != VITG_GEMM_STORE16 && mode != VITG_GEMM_SWIGLU) return VITG_ERR_ARG;
+    if (mode == VITG_GEMM_SWIGLU && colsum) return VITG_ERR_ARG;       // RMSNorm only in front of the SwiGLU GEMM
+    NormFusion nf;
+    nf.stats = stats; nf.colsum = colsum;
+    return gemm_entry(XH, lda, W, ldw, nullptr, M, N, K, dtype, mode, bias, act, out, ldo, nullptr, 0, 0, stream, &nf);
+}
+#endif   // VITG_PROFILING_BUILD (fused norm)

@@ -31,7 +31,7 @@ constexpr int G2_BM = 256, G2_THREADS = 512;
 #define VITG_PROFILING_BUILD 0     // build.sh -DVITG_PROFILING_BUILD=1 compiles the ablation switches (gemm_flags bits 1-4, 6, 9, 15, 18) into the
 #endif                             // main loop; in the product build they are compiled out: every test of g.flags in an interval is a scalar
                                    // branch, and eight of them per read interval cost the phased loop 5-10 % (profiles/r01_gemm_shapes.md section 16)
-template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM>
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM, bool NRM = false>
 __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kernel(GemmArgs g_) {
     typedef typename T16<T>::vec8 vec8;
     GemmArgs g = g_;
@@ -420,7 +420,73 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
         GemmArgs ge = g;
         ge.res = nullptr;
         constexpr int SB = 32 * NT * 128;
+        if constexpr (NRM) {
+            // ---- fused-norm PRODUCER: final values (residual + acc + bias) are in registers in the MFMA layout --------------------
+            const int frow_ = lane & 31, fh_ = lane >> 5;
+            if (g.bias) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int n = n0 + wc * (NT * 32) + nt * 32 + q4 * 8 + fh_ * 4;
+                        if (n < g.N) {
+                            const f32x4 bv = *(const f32x4*)(g.bias + n);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[nt][mt][q4 * 4 + e] += bv[e];
+                        }
+                    }
+                ge.bias = nullptr;
+            }
+            // partial row statistics over this wave's NT*32 columns: a row's values sit in lanes l and l^32; (mean, M2 about
+            // that mean) per partial, combined by norm_stats_finalize with Chan's formula (no E[x^2] - mean^2 cancellation)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float sm = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sm += acc[nt][mt][r];
+                sm += __shfl_xor(sm, 32, 64);
+                const float mean = sm * (1.0f / (NT * 32));
+                float q = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float d = acc[nt][mt][r] - mean; q += d * d; }
+                q += __shfl_xor(q, 32, 64);
+                const int m = m0 + wr * (MT * 32) + mt * 32 + frow_;
+                // nrm_P = N / (NT*32) real partials per row (host); a wave column block past N (last tile of a ragged N) has none
+                const int pidx = tn * WN + wc;
+                if (fh_ == 0 && m < g.M && pidx < g.nrm_P) *(f32x2*)(g.nrm_part + ((size_t)m * g.nrm_P + pidx) * 2) = f32x2{mean, q};
+            }
+            epilogue_staged<T, MODE_F32, MT, NT>(ge, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+            // 16-bit copy scaled by the NEXT norm's weight: the operand of the GEMM behind that norm
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int n = n0 + wc * (NT * 32) + nt * 32 + q4 * 8 + fh_ * 4;
+                    f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+                    if (n < g.N) gv = *(const f32x4*)(g.nrm_gamma + n);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[nt][mt][q4 * 4 + e] *= gv[e];
+                }
+            GemmArgs gx = ge;
+            gx.out = g.nrm_xh; gx.ldo = g.nrm_ldxh; gx.act = VITG_ACT_NONE;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // the 16-bit staging windows of the waves overlap their fp32 windows
+            constexpr int HALF = (MT / 2) * 32 * (NT * 64 + ((NT & (NT - 1)) ? 16 : 0));
+            static_assert(MT % 2 == 0 && 8 * HALF <= STAGES * STAGE, "16-bit staging of the fused-norm producer must fit in the ring");
+            epilogue_staged<T, MODE_STORE16, MT, NT, 0, MT / 2>(gx, acc, smem + wave * HALF, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+            epilogue_staged<T, MODE_STORE16, MT, NT, MT / 2, MT / 2>(gx, acc, smem + wave * HALF, m0 + wr * (MT * 32) + (MT / 2) * 32,
+                                                                       n0 + wc * (NT * 32), lane);
+        } else {
         epilogue_staged<T, MODE_F32, MT, NT>(ge, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+        }
     } else if constexpr (MODE == MODE_F32) {
         // fp32 residual update: a lane already owns 16 contiguous bytes per accumulator quad; direct read-modify-write
         // measured faster than staging (the staged form serialises LDS round trip + residual load latency per pass).
@@ -454,15 +520,15 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
             // flags bit18 (profiling, wrong results): every tile stores over tile (0,0) - same store instructions, but the output
             // stays in L2 (no HBM write-back stream, no eviction of operand panels): separates issue cost from memory-side cost
             const int m0e = (PROF && (g.flags & 0x40000)) ? 0 : m0, n0e = (PROF && (g.flags & 0x40000)) ? 0 : n0;
-            epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0e + wr * (MT * 32), n0e + wc * (NT * 32), lane);
+            epilogue_staged<T, MODE, MT, NT, 0, MT, NRM>(g, acc, smem + wave * STAGE_BYTES, m0e + wr * (MT * 32), n0e + wc * (NT * 32), lane);
         } else {
             // 256x384 tile: the wave's 128x96 outputs are staged in two 64-row halves (the same wave writes and reads its
             // private region, in order, so the second half may reuse it)
             constexpr int HALF = (MT / 2) * 32 * (NT * 64 + ((NT & (NT - 1)) ? 16 : 0));     // padded rows when NT is not a power of two
             static_assert(MT % 2 == 0 && 8 * HALF <= STAGES * STAGE, "epilogue staging must fit in the ring");
-            epilogue_staged<T, MODE, MT, NT, 0, MT / 2>(g, acc, smem + wave * HALF, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
-            epilogue_staged<T, MODE, MT, NT, MT / 2, MT / 2>(g, acc, smem + wave * HALF, m0 + wr * (MT * 32) + (MT / 2) * 32,
-                                                               n0 + wc * (NT * 32), lane);
+            epilogue_staged<T, MODE, MT, NT, 0, MT / 2, NRM>(g, acc, smem + wave * HALF, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+            epilogue_staged<T, MODE, MT, NT, MT / 2, MT / 2, NRM>(g, acc, smem + wave * HALF, m0 + wr * (MT * 32) + (MT / 2) * 32,
+                                                                    n0 + wc * (NT * 32), lane);
         }
     }
     if (vb + (int)gridDim.x < nwg_) {                    // another tile follows: every wave is done with the ring / its staging region
@@ -701,14 +767,14 @@ static int launch256p(GemmArgs g, hipStream_t s) {
 
 #endif   // VITG_PROFILING_BUILD (persistent cfg 4)
 
-template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM>
+template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM, bool NRM = false>
 static int launch256(GemmArgs g, hipStream_t s) {
     constexpr int lds = STAGES * (BM * BK * 2 + BN * BK * 2);
     static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     if (cur_dev != done_dev) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM, NRM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done_dev = cur_dev;
     }
     g.tiles_m = ceil_div(g.M, BM);
@@ -722,7 +788,7 @@ static int launch256(GemmArgs g, hipStream_t s) {
     const int nwg = g.tiles_m * g.tiles_n;
     const bool loop = BN >= 256 && nwg >= 2 * cus && (tuning().gemm_flags & 0x1000000);   // bit24: opt-in until the in-step A/B says otherwise
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
-    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G2_THREADS), lds, s, g);
+    hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM, NRM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
 
@@ -779,10 +845,16 @@ static int choose_cfg(const GemmArgs& g, int mode) {
     return cfg;
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool NRM = false>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     int cfg = tuning().gemm_cfg;
     if (!cfg) cfg = choose_cfg(g, MODE);
+    if constexpr (NRM) {                     // fused-norm instantiations exist for the four shipped tile shapes only
+        if (cfg == 10 && g.M >= 384) return launch256<T, MODE, 256, 2, 2, 64, false, 1, 384, true>(g, s);
+        if (cfg == 9 && MODE != MODE_SWIGLU && g.N >= 384) return launch256<T, MODE, 384, 2, 2, 64, false, 1, G2_BM, true>(g, s);
+        if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32, false, 0, G2_BM, true>(g, s);
+        return launch256<T, MODE, 256, 2, 2, 64, false, 1, G2_BM, true>(g, s);
+    }
     if (MODE == MODE_F32 && g.split_k > 1) cfg = 6;           // split-K partials: 256x256 tiles (the plan of vitg_gemm_splitk_plan assumes them)
 #if VITG_PROFILING_BUILD
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
@@ -822,9 +894,27 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
 
 template <typename T>
 static int launch256_t(const GemmArgs& g, int mode, hipStream_t s) {
+#if VITG_PROFILING_BUILD
+    // fused norm (measured SLOWER than the stand-alone norm kernel, profiles/r02_fused_norm.md): profiling library only
+    if (g.nrm_gamma || g.nrm_stats) {        // producer (F32) or consumer (16-bit outputs)
+        if (mode == MODE_SWIGLU) return launch256_m<T, MODE_SWIGLU, true>(g, s);
+        if (mode == MODE_F32) return launch256_m<T, MODE_F32, true>(g, s);
+        return launch256_m<T, MODE_STORE16, true>(g, s);
+    }
+#endif
     if (mode == MODE_SWIGLU) return launch256_m<T, MODE_SWIGLU>(g, s);
     if (mode == MODE_F32) return launch256_m<T, MODE_F32>(g, s);
     return launch256_m<T, MODE_STORE16>(g, s);
+}
+
+// columns covered by one partial of the fused-norm producer for this shape (= BN / WN of the tile shape auto mode picks), 0 when the
+// 256-tile kernels do not take the shape
+int gemm256_norm_cols(const GemmArgs& g) {
+    if (!gemm256_applicable(g, MODE_F32)) return 0;
+    int cfg = tuning().gemm_cfg;
+    if (!cfg) cfg = choose_cfg(g, MODE_F32);
+    if (cfg == 9 && g.N >= 384) return 96;
+    return 64;                                // 256x256, 384x256 (4 waves across 256 columns) and 256x128 (2 waves across 128)
 }
 
 int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s) {

@@ -22,6 +22,16 @@ struct GemmArgs {
     int stagger_ns;           // persistent kernel: tile period estimate for de-phasing the XCDs (0 = off)
     int flags;                // bit0: non-temporal output stores, bit1: (profiling) skip output stores
     const void* Wf;           // fragment-packed copy of W (vitg_pack_weight_fragments) or null
+    // fused normalisation (round 2; NRM instantiations only).  PRODUCER = MODE_F32 with the residual in the accumulator: besides
+    // out = acc + bias (+ residual) it writes xh[m,n] = round16(out[m,n] * nrm_gamma[n]) - the operand of the GEMM that follows the
+    // next LayerNorm / RMSNorm - and, per wave column block, the partial row statistics (mean, M2) of out.  CONSUMER = 16-bit output
+    // modes fed with xh: out = epilogue(rstd[m] * (acc - mean[m] * nrm_colsum[n]) + bias) with (mean, rstd) from the finalised stats.
+    const float* nrm_gamma;   // producer: weight of the norm that follows [N]
+    void* nrm_xh; int nrm_ldxh;   // producer: 16-bit copy
+    float* nrm_part;          // producer: [M][nrm_P][2] partial (mean, M2) over the wave's NT*32 columns
+    int nrm_P;                // producer: partials per row = N / (columns per wave block), set by the host entry
+    const float* nrm_stats;   // consumer: [M][2] (mean, rstd)
+    const float* nrm_colsum;  // consumer: s[n] = sum_k gamma[k] W[n,k] (LayerNorm) or null (RMSNorm: no mean term)
     int split_k;              // MODE_F32 only: gridDim.y = split_k blocks share one output tile, block y accumulates its K range and
     long split_stride;        // writes the raw fp32 partial tile to out + y * split_stride floats (vitg_gemm_splitk reduces them)
 };
@@ -89,11 +99,20 @@ __device__ __forceinline__ void epilogue_swiglu_quad(const GemmArgs& g, int m, i
 // two - and >= 32*NT*128 bytes for fp32 output).
 // Requires out/res leading dimensions and n_base to keep 16-B alignment (checked by the host code).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int MODE, int MT, int NT, int MT0 = 0, int MTN = MT>
+template <typename T, int MODE, int MT, int NT, int MT0 = 0, int MTN = MT, bool NRM = false>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)[NT][MT], char* stage, int m_base, int n_base,
                                                 int lane) {
     // processes accumulator row-tiles mt in [MT0, MT0 + MTN); m_base is the row of mt = MT0
     const int frow = lane & 31, fh = lane >> 5;
+    // NRM consumer: this lane's rows carry (mean, rstd) of the norm folded into this GEMM
+    float nmu[MTN], nrs[MTN];
+    if constexpr (NRM && MODE != MODE_F32) {
+#pragma unroll
+        for (int i = 0; i < MTN; ++i) {
+            const f32x2 st = *(const f32x2*)(g.nrm_stats + 2 * (size_t)min(m_base + i * 32 + frow, g.M - 1));
+            nmu[i] = st[0]; nrs[i] = st[1];
+        }
+    }
     if constexpr (MODE == MODE_F32) {
         constexpr int CH = NT * 8;                        // 16-B chunks (4 floats) per row
         constexpr int RB = NT * 128;                      // row bytes
@@ -153,12 +172,24 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                 for (int q4 = 0; q4 < 4; ++q4) {
                     f32x4 v;
                     if constexpr (MODE == MODE_SWIGLU) {
+                        if constexpr (NRM) {                   // RMSNorm folded in: gate and up are both scaled by the row's rstd
+                            const float rs = nrs[mt - MT0];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[0][mt][q4 * 4 + e]) * acc[NT - 1][mt][q4 * 4 + e];
+                            for (int e = 0; e < 4; ++e) v[e] = silu_f(rs * acc[0][mt][q4 * 4 + e]) * (rs * acc[NT - 1][mt][q4 * 4 + e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[0][mt][q4 * 4 + e]) * acc[NT - 1][mt][q4 * 4 + e];
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][q4 * 4 + e];
                         const int n = n_base + nt * 32 + q4 * 8 + fh * 4;
+                        if constexpr (NRM) {
+                            f32x4 sn = {0.f, 0.f, 0.f, 0.f};
+                            if (g.nrm_colsum && n < g.N) sn = *(const f32x4*)(g.nrm_colsum + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = nrs[mt - MT0] * (v[e] - nmu[mt - MT0] * sn[e]);
+                        }
                         if (g.bias && n < g.N) v += *(const f32x4*)(g.bias + n);
                         if (g.act == VITG_ACT_GELU_TANH) {
 #pragma unroll
@@ -199,6 +230,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 
 int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s);   // gemm256.hip
 bool gemm256_applicable(const GemmArgs& g, int mode);
+int gemm256_norm_cols(const GemmArgs& g);                                       // gemm256.hip
 int launch_gemm_w4(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_w4.hip
 bool gemm_w4_applicable(const GemmArgs& g, int mode);
 int launch_gemm_wf(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_wf.hip

@@ -378,7 +378,7 @@ extern "C" int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const voi
     if (mode == VITG_GEMM_SWIGLU && (N % 64 != 0)) return VITG_ERR_SHAPE;
     if (N % 8 != 0 || ldo % 8 != 0 || (res && ldr % 4 != 0)) return VITG_ERR_ALIGN;
     if (out_dtype != DT_BF16 && out_dtype != DT_F16) return VITG_ERR_DTYPE;     // type of the 16-bit outputs (ignored for VITG_GEMM_F32)
-    Gemm8Args ga;
+    Gemm8Args ga = {};
     GemmArgs& g = ga.g;
     g.A = A8; g.lda = lda; g.W = W8; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;

@@ -12,6 +12,7 @@ Reference call sites mirrored: clip_encoder.py:123-154 (tower, hidden_states[-2]
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -53,12 +54,15 @@ class Fp8Weight:
 
 @dataclass
 class VitLayerW:
-    ln1_w: torch.Tensor; ln1_b: torch.Tensor
-    qkv_w: torch.Tensor; qkv_b: torch.Tensor
-    out_w: torch.Tensor; out_b: torch.Tensor
-    ln2_w: torch.Tensor; ln2_b: torch.Tensor
-    fc1_w: torch.Tensor; fc1_b: torch.Tensor
-    fc2_w: torch.Tensor; fc2_b: torch.Tensor
+    # fused-norm consumers (16-bit path): s[n] = sum_k gamma[k] W[n,k] and c = W beta + bias of the GEMM behind each LayerNorm
+    qkv_cs: Optional[torch.Tensor] = None; qkv_c: Optional[torch.Tensor] = None
+    fc1_cs: Optional[torch.Tensor] = None; fc1_c: Optional[torch.Tensor] = None
+    ln1_w: torch.Tensor = None; ln1_b: torch.Tensor = None
+    qkv_w: torch.Tensor = None; qkv_b: torch.Tensor = None
+    out_w: torch.Tensor = None; out_b: torch.Tensor = None
+    ln2_w: torch.Tensor = None; ln2_b: torch.Tensor = None
+    fc1_w: torch.Tensor = None; fc1_b: torch.Tensor = None
+    fc2_w: torch.Tensor = None; fc2_b: torch.Tensor = None
 
 
 @dataclass
@@ -145,6 +149,15 @@ class PackedWeights:
             fc2_w=self._wl(vsd[p + "mlp.fc2.weight"]), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
         ))
         self._packing, self._packing_part = self.dtype, "llm"
+        lw = self.vit[-1]
+        if not isinstance(lw.qkv_w, Fp8Weight):
+            # load-time constants of the fused LayerNorm consumers, from the 16-bit-rounded weights the MFMA will see
+            Dv = v.hidden_size
+            for wname, bname, gam, bet, cs, cc in (("qkv_w", "qkv_b", lw.ln1_w, lw.ln1_b, "qkv_cs", "qkv_c"),
+                                                  ("fc1_w", "fc1_b", lw.ln2_w, lw.ln2_b, "fc1_cs", "fc1_c")):
+                wf = getattr(lw, wname)[:, :Dv].float()
+                setattr(lw, cs, (wf @ gam).contiguous())
+                setattr(lw, cc, (wf @ bet + getattr(lw, bname)).contiguous())
 
     def pack_projector_and_head(self, sd: SD) -> None:
         pre = "model.mm_projector.out_projection."
@@ -214,6 +227,11 @@ class SelectorEngine:
         self.device = weights.device
         self.attn_variant = attn_variant
         self.skip_dead_rows = True        # last tower layer only on the tokens the pool reads (see vit_forward)
+        # LayerNorm / RMSNorm folded into the GEMMs around them (vitg_gemm_norm_*).  Measured 4 % SLOWER on the step than the stand-alone
+        # norm kernels (profiles/r02_fused_norm.md), so the kernels live in the profiling library and this switch only exists there.
+        from . import _lib as _l
+        self.fuse_norm = _l.PROFILING and os.environ.get("VITG_FUSE_NORM", "0") not in ("", "0")
+        self._normplan: Dict[tuple, int] = {}
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[str, torch.Tensor] = {}
         self._poolsrc: Dict[tuple, object] = {}
@@ -271,6 +289,32 @@ class SelectorEngine:
         K.quant_rows_fp8(t, d, a8, sa)
         return a8, sa
 
+    def _producer(self, a, w, x: torch.Tensor, *, bias, res, gamma: Optional[torch.Tensor], name: str, eps: float, rms: bool,
+                  dt: torch.dtype, res_mod: int = 0):
+        """x = a @ w.T + bias + res (the fp32 residual update).  With fuse_norm and a shape the fused kernels cover, the same launch
+        also emits the operand and the row statistics of the norm that FOLLOWS (weight `gamma`): returns (xh, stats) for
+        `_consumer`; otherwise runs the plain GEMM and returns None (the caller then normalises x with the stand-alone kernel)."""
+        fused = self.fuse_norm and gamma is not None and not isinstance(w, Fp8Weight)
+        if fused:
+            M, N, Kd = a.shape[0], w.shape[0], w.shape[1]
+            key = (M, N, Kd)
+            cols = self._normplan.get(key)
+            if cols is None:
+                cols = K.gemm_norm_plan(M, N, Kd)
+                if cols and res_mod == 0 and K.gemm_splitk_plan(M, N, Kd)[0] > 1:
+                    cols = 0                                   # few-tile shapes go through split-K instead
+                self._normplan[key] = cols
+            if cols:
+                P = N // cols
+                xh = self._buf(name + "_xh", (M, pad64(N)), dt, zero=True)
+                part = self._buf(name + "_npart", (M * P * 2,), torch.float32)
+                stats = self._buf(name + "_nstat", (M * 2,), torch.float32)
+                K.gemm_norm_producer(a, w, x, res=res, next_gamma=gamma, xh=xh, partials=part, bias=bias, res_mod=res_mod)
+                K.norm_stats_finalize(part, M, P, cols, eps, rms, stats)
+                return xh, stats
+        self._gemm(a, w, x, mode=K.GEMM_F32, bias=bias, res=res, res_mod=res_mod)
+        return None
+
     def _gemm(self, a, w, out: torch.Tensor, **kw) -> torch.Tensor:
         if isinstance(w, Fp8Weight):
             return K.gemm_fp8(a[0], a[1], w.w8, w.sw, out, out_dtype=out.dtype if out.dtype != torch.float32 else self.dtype, **kw)
@@ -322,25 +366,38 @@ class SelectorEngine:
         H, hd = v.num_attention_heads, v.head_dim
         a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.vdtype)
         x = self._buf("vit_x", (M, Dv), torch.float32)
-        K.gemm(a0, w.patch_w, x, mode=K.GEMM_F32, bias=w.patch_b, res=w.pos_table(G), res_mod=P)
-        del a0
-        qkv = self._buf("vit_qkv", (M, 3 * Dv), self.vdtype)
-        o = self._buf("vit_o", (M, Dvp), self.vdtype, zero=True)
-        f = self._buf("vit_f", (M, Fvp), self.vdtype)
-        scale = hd ** -0.5
+        eps, vdt = v.layer_norm_eps, self.vdtype
         src = self.pool_sources(G, hw) if (hw is not None and self.skip_dead_rows and len(w.vit) > 0) else None
         full_layers = w.vit if src is None else w.vit[:-1]
+        # `pend` = (xh, stats) when the GEMM that produced x also emitted the operand / statistics of the next LayerNorm (fuse_norm)
+        pend = self._producer(a0, w.patch_w, x, bias=w.patch_b, res=w.pos_table(G), res_mod=P, gamma=w.vit[0].ln1_w if w.vit else None,
+                              name="vit", eps=eps, rms=False, dt=vdt)
+        del a0
+        qkv = self._buf("vit_qkv", (M, 3 * Dv), vdt)
+        o = self._buf("vit_o", (M, Dvp), vdt, zero=True)
+        f = self._buf("vit_f", (M, Fvp), vdt)
+        scale = hd ** -0.5
         st = (P * 3 * Dv, 3 * Dv, hd)
-        for lw in full_layers:
-            h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, v.layer_norm_eps, self.vdtype)
-            self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
+        for li, lw in enumerate(full_layers):
+            if pend is not None:
+                K.gemm_norm_consumer(pend[0], lw.qkv_w, qkv, mode=K.GEMM_STORE16, stats=pend[1], colsum=lw.qkv_cs, bias=lw.qkv_c)
+            else:
+                h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, eps, vdt)
+                self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
             K.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
                         q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
                         variant=self.attn_variant)
-            self._gemm(self._operand(o, "vit_o", Dv), lw.out_w, x, mode=K.GEMM_F32, bias=lw.out_b, res=x)
-            h = self._norm(x, lw.ln2_w, lw.ln2_b, "vit_h", Dv, v.layer_norm_eps, self.vdtype)
-            self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
-            self._gemm(self._operand(f, "vit_f", Fvp), lw.fc2_w, x, mode=K.GEMM_F32, bias=lw.fc2_b, res=x)
+            pend = self._producer(self._operand(o, "vit_o", Dv), lw.out_w, x, bias=lw.out_b, res=x, gamma=lw.ln2_w, name="vit", eps=eps,
+                                  rms=False, dt=vdt)
+            if pend is not None:
+                K.gemm_norm_consumer(pend[0], lw.fc1_w, f, mode=K.GEMM_STORE16, stats=pend[1], colsum=lw.fc1_cs, bias=lw.fc1_c,
+                                     act=K.ACT_GELU_TANH)
+            else:
+                h = self._norm(x, lw.ln2_w, lw.ln2_b, "vit_h", Dv, eps, vdt)
+                self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
+            nxt = w.vit[li + 1].ln1_w if li + 1 < len(w.vit) else None          # the norm in front of the NEXT layer's qkv
+            pend = self._producer(self._operand(f, "vit_f", Fvp), lw.fc2_w, x, bias=lw.fc2_b, res=x, gamma=nxt, name="vit", eps=eps,
+                                  rms=False, dt=vdt)
         if src is None:
             return x, G, None, 0
         # ---- last needed layer on compact query rows -------------------------------------------------------------
@@ -348,21 +405,25 @@ class SelectorEngine:
         Pc = idx.numel()
         Mc = T * Pc
         lw = w.vit[-1]
-        h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, v.layer_norm_eps, self.vdtype)
-        self._gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, bias=lw.qkv_b[Dv:])          # K|V for every token
+        if pend is not None:                                                       # K|V for every token
+            K.gemm_norm_consumer(pend[0], lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, stats=pend[1], colsum=lw.qkv_cs[Dv:],
+                                 bias=lw.qkv_c[Dv:])
+        else:
+            h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, eps, vdt)
+            self._gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, bias=lw.qkv_b[Dv:])
         xq = self._buf("vit_xq", (Mc, Dv), torch.float32)
         K.gather_rows(x, idx, P, T, xq, Dv)
         # LayerNorm is per row: normalising the gathered residual rows equals gathering the normalised rows
-        hq = self._norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq", Dv, v.layer_norm_eps, self.vdtype)
-        qc = self._buf("vit_qc", (Mc, Dv), self.vdtype)
+        hq = self._norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq", Dv, eps, vdt)
+        qc = self._buf("vit_qc", (Mc, Dv), vdt)
         self._gemm(hq, lw.qkv_w[:Dv], qc, mode=K.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
-        oc = self._buf("vit_oc", (Mc, Dvp), self.vdtype, zero=True)
+        oc = self._buf("vit_oc", (Mc, Dvp), vdt, zero=True)
         K.attention(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
                     q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
                     variant=self.attn_variant)
         self._gemm(self._operand(oc, "vit_oc", Dv), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
-        hq = self._norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", Dv, v.layer_norm_eps, self.vdtype)
-        fc = self._buf("vit_fc", (Mc, Fvp), self.vdtype)
+        hq = self._norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", Dv, eps, vdt)
+        fc = self._buf("vit_fc", (Mc, Fvp), vdt)
         self._gemm(hq, lw.fc1_w, fc, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
         self._gemm(self._operand(fc, "vit_fc", Fvp), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
         return xq, G, cmap, Pc
@@ -410,9 +471,14 @@ class SelectorEngine:
         cos, sin = cos[pos0:pos0 + N], sin[pos0:pos0 + N]
         scale = hd ** -0.5
         kvw = 2 * nkv * hd
-        for lw in w.llm:
-            h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps)
-            self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
+        pend = None                                       # layer 0 normalises the assembled embeddings with the stand-alone kernel
+        fuse = kv_gather is None                          # (the context-parallel ranks take the split-K path for o / down instead)
+        for li, lw in enumerate(w.llm):
+            if pend is not None:
+                K.gemm_norm_consumer(pend[0], lw.qkv_w, qkv, mode=K.GEMM_STORE16, stats=pend[1], bias=lw.qkv_b)
+            else:
+                h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps)
+                self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
             K.rope_(qkv, cos, sin, nq + nkv, hd)
             if kv_gather is None:
                 K.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
@@ -423,10 +489,16 @@ class SelectorEngine:
                 K.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
                             head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, kvw, hd), v_strides=(0, kvw, hd),
                             o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
-            self._gemm(self._operand(o, "llm_o", nq * hd), lw.o_w, x, mode=K.GEMM_F32, res=x)
-            h = self._norm(x, lw.post_ln, None, "llm_h", D, cfg.rms_norm_eps)
-            self._gemm(h, lw.gu_w, f, mode=K.GEMM_SWIGLU)
-            self._gemm(self._operand(f, "llm_f", Fp), lw.down_w, x, mode=K.GEMM_F32, res=x)
+            pend = self._producer(self._operand(o, "llm_o", nq * hd), lw.o_w, x, bias=None, res=x, gamma=lw.post_ln if fuse else None,
+                                  name="llm", eps=cfg.rms_norm_eps, rms=True, dt=self.dtype)
+            if pend is not None:
+                K.gemm_norm_consumer(pend[0], lw.gu_w, f, mode=K.GEMM_SWIGLU, stats=pend[1])
+            else:
+                h = self._norm(x, lw.post_ln, None, "llm_h", D, cfg.rms_norm_eps)
+                self._gemm(h, lw.gu_w, f, mode=K.GEMM_SWIGLU)
+            nxt = w.llm[li + 1].in_ln if (fuse and li + 1 < len(w.llm)) else None
+            pend = self._producer(self._operand(f, "llm_f", Fp), lw.down_w, x, bias=None, res=x, gamma=nxt, name="llm",
+                                  eps=cfg.rms_norm_eps, rms=True, dt=self.dtype)
         out = self._buf("llm_out", (N, D), torch.float32)
         K.rmsnorm(x, w.norm_w, out, D, cfg.rms_norm_eps)
         return out

@@ -90,6 +90,44 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: O
     return out
 
 
+def gemm_norm_plan(M: int, N: int, K: int) -> int:
+    """output columns per partial of the fused-norm producer for this shape; 0 = not covered (use the stand-alone norm)"""
+    c = C.c_int(0)
+    _lib.call("vitg_gemm_norm_plan", M, N, K, C.byref(c))
+    return c.value
+
+
+def gemm_norm_producer(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, res: torch.Tensor, next_gamma: torch.Tensor,
+                       xh: torch.Tensor, partials: torch.Tensor, bias: Optional[torch.Tensor] = None, res_mod: int = 0) -> torch.Tensor:
+    """out(fp32) = a @ w.T + bias + res;  xh = round16(out * next_gamma);  partials[m, p] = (mean, M2) of out[m, p*cols:(p+1)*cols]"""
+    _req(a); _req(w, a.dtype); _req(out, torch.float32); _req(res, torch.float32); _req(next_gamma, torch.float32)
+    _req(xh, a.dtype); _req(partials, torch.float32)
+    M, K, N = a.shape[0], w.shape[1], w.shape[0]
+    assert a.shape[1] == K and xh.shape[0] >= M and xh.stride(1) == 1
+    _lib.call("vitg_gemm_norm_producer", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, N, K, dt_code(a.dtype), _ptr(bias), _ptr(out),
+              out.stride(0), _ptr(res), res.stride(0), res_mod, _ptr(next_gamma), _ptr(xh), xh.stride(0), _ptr(partials), _stream())
+    return out
+
+
+def norm_stats_finalize(partials: torch.Tensor, M: int, P: int, cols: int, eps: float, rms: bool, stats: torch.Tensor) -> torch.Tensor:
+    _req(partials, torch.float32); _req(stats, torch.float32)
+    _lib.call("vitg_norm_stats_finalize", _ptr(partials), M, P, cols, eps, 1 if rms else 0, _ptr(stats), _stream())
+    return stats
+
+
+def gemm_norm_consumer(xh: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, stats: torch.Tensor,
+                       colsum: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                       n: Optional[int] = None) -> torch.Tensor:
+    """out = epilogue(rstd[m] * (xh @ w.T - mean[m] * colsum) + bias)  (16-bit output modes)"""
+    _req(xh); _req(w, xh.dtype); _req(out, xh.dtype); _req(stats, torch.float32)
+    M, K = xh.shape[0], w.shape[1]
+    N = w.shape[0] if n is None else n
+    assert xh.shape[1] == K
+    _lib.call("vitg_gemm_norm_consumer", _ptr(xh), xh.stride(0), _ptr(w), w.stride(0), M, N, K, dt_code(xh.dtype), mode, _ptr(bias), act,
+              _ptr(out), out.stride(0), _ptr(stats), _ptr(colsum), _stream())
+    return out
+
+
 def gemm_splitk_plan(M: int, N: int, K: int):
     """-> (splits, workspace_bytes): splits == 1 means the plain GEMM is the right call (vitg_gemm_splitk_plan)"""
     sp, nb = C.c_int(0), C.c_long(0)

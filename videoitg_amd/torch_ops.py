@@ -50,6 +50,22 @@ _def("gemm_splitk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int 
      lambda a, w, out, workspace, splits, bias=None, res=None: (_raw.gemm_splitk(a, w, out, workspace, splits, bias=bias, res=res), None)[1],
      lambda *a, **k: None)
 
+# ---- norm folded into the GEMMs around it (profiling library only: measured slower than the stand-alone norm kernels)
+if _raw._lib.PROFILING:
+  _def("gemm_norm_producer(Tensor a, Tensor w, Tensor(a!) out, Tensor res, Tensor next_gamma, Tensor(b!) xh, Tensor(c!) partials, "
+       "Tensor? bias=None, int res_mod=0) -> ()",
+       lambda a, w, out, res, next_gamma, xh, partials, bias=None, res_mod=0:
+           (_raw.gemm_norm_producer(a, w, out, res=res, next_gamma=next_gamma, xh=xh, partials=partials, bias=bias, res_mod=res_mod), None)[1],
+       lambda *a, **k: None)
+  _def("norm_stats_finalize(Tensor partials, int M, int P, int cols, float eps, bool rms, Tensor(a!) stats) -> ()",
+       lambda partials, M, P, cols, eps, rms, stats: (_raw.norm_stats_finalize(partials, M, P, cols, eps, rms, stats), None)[1],
+       lambda *a, **k: None)
+  _def("gemm_norm_consumer(Tensor xh, Tensor w, Tensor(a!) out, int mode, Tensor stats, Tensor? colsum=None, Tensor? bias=None, "
+       "int act=0, int? n=None) -> ()",
+       lambda xh, w, out, mode, stats, colsum=None, bias=None, act=0, n=None:
+           (_raw.gemm_norm_consumer(xh, w, out, mode=mode, stats=stats, colsum=colsum, bias=bias, act=act, n=n), None)[1],
+       lambda *a, **k: None)
+
 # ---- norms / rope ----------------------------------------------------------------------------------------------------------
 _def("layernorm(Tensor x, Tensor w, Tensor b, Tensor(a!) out, int d, float eps) -> ()",
      lambda x, w, b, out, d, eps: (_raw.layernorm(x, w, b, out, d, eps), None)[1], lambda x, w, b, out, d, eps: None)
@@ -126,6 +142,22 @@ class _Namespace:
         return out
 
     gemm_splitk_plan = staticmethod(_raw.gemm_splitk_plan)
+    gemm_norm_plan = staticmethod(_raw.gemm_norm_plan)
+
+    @staticmethod
+    def gemm_norm_producer(a, w, out, *, res, next_gamma, xh, partials, bias=None, res_mod=0):
+        _ops.gemm_norm_producer(a, w, out, res, next_gamma, xh, partials, bias, res_mod)
+        return out
+
+    @staticmethod
+    def norm_stats_finalize(partials, M, P, cols, eps, rms, stats):
+        _ops.norm_stats_finalize(partials, M, P, cols, eps, rms, stats)
+        return stats
+
+    @staticmethod
+    def gemm_norm_consumer(xh, w, out, *, mode, stats, colsum=None, bias=None, act=0, n=None):
+        _ops.gemm_norm_consumer(xh, w, out, mode, stats, colsum, bias, act, n)
+        return out
 
     @staticmethod
     def gemm_splitk(a, w, out, workspace, splits, *, bias=None, res=None):
