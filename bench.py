@@ -310,6 +310,18 @@ def main():
 
     timer = GemmTimer()
     ops.gemm = timer.wrap(ops.gemm)
+    # the other kernel classes of the step, timed the same way (HIP events around every launch on the launch stream): attention per
+    # head size (MFMA-bound) and the norm kernels (HBM-bound) - north_star asks for both rooflines; reported as `roofline_other`
+    t_attn = {72: GemmTimer(), 128: GemmTimer()}
+    raw_attention = ops.attention
+
+    def timed_attention(*a, **k):
+        return t_attn.get(k.get("head_dim"), t_attn[128]).wrap(raw_attention)(*a, **k)
+    ops.attention = timed_attention
+    t_ln, t_rms = GemmTimer(), GemmTimer()
+    ops.layernorm = t_ln.wrap(ops.layernorm)
+    ops.rmsnorm = t_rms.wrap(ops.rmsnorm)
+    side_timers = [t_attn[72], t_attn[128], t_ln, t_rms]
 
     graphed = None
     if args.graph and cp is None:
@@ -336,12 +348,16 @@ def main():
         step()
     barrier()
     timer.enabled = True
+    for st_ in side_timers:
+        st_.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         order, last_logits = step()
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    for st_ in side_timers:
+        st_.enabled = False
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -388,6 +404,39 @@ def main():
             "top32": sorted(order[:32]),
         }
         out["parity"] = parity_block(T, R, args.prompt_len, args.seed, last_logits, order) if args.config == "full" else None
+        if world == 1:
+            v = cfg.vision
+            G_ = R // v.patch_size
+            P_ = G_ * G_
+            es = 2                                                            # 16-bit activations
+            n72, ms72 = t_attn[72].summary()
+            n128, ms128 = t_attn[128].summary()
+            nln, msln = t_ln.summary()
+            nrm, msrm = t_rms.summary()
+            HBM_PEAK = 8000.0                                                 # GB/s, MI355X_MICROARCH.md
+            other = {}
+            if n72:                                                           # executed: the last tower layer runs its queries on the pooled tokens only
+                other["attention_hd72"] = {"bound": "mfma", "achieved": round(fl["vit_attn"] * args.steps / (ms72 * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
+                                           "unit": "TFLOP/s", "launches": n72, "avg_launch_ms": round(ms72 / n72, 4),
+                                           "share_of_step": round(ms72 / (dt * 1e3), 3), "flops": "algorithmic 4 S^2 d per head (72 of the 80/96 padded lanes)"}
+                other["attention_hd72"]["frac"] = round(other["attention_hd72"]["achieved"] / MFMA_PEAK_TFLOPS, 4)
+            if n128:
+                other["attention_hd128"] = {"bound": "mfma", "achieved": round(fl["llm_attn"] * args.steps / (ms128 * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
+                                            "unit": "TFLOP/s", "launches": n128, "avg_launch_ms": round(ms128 / n128, 4),
+                                            "share_of_step": round(ms128 / (dt * 1e3), 3)}
+                other["attention_hd128"]["frac"] = round(other["attention_hd128"]["achieved"] / MFMA_PEAK_TFLOPS, 4)
+            if nln:                                                           # 4 B read + 2 B written per element of the fp32 residual row
+                by = (2 * cfg.num_vit_layers_needed() - 1) * T * P_ * v.hidden_size * (4 + es)      # dense launches (the compact last-layer ones are ~1 %)
+                other["layernorm"] = {"bound": "hbm", "achieved": round(by * args.steps / (msln * 1e-3) / 1e9, 1), "peak": HBM_PEAK, "unit": "GB/s",
+                                      "launches": nln, "avg_launch_ms": round(msln / nln, 4), "share_of_step": round(msln / (dt * 1e3), 3),
+                                      "bytes": "algorithmic: 4 B read + 2 B written per element (dense launches)"}
+                other["layernorm"]["frac"] = round(other["layernorm"]["achieved"] / HBM_PEAK, 4)
+            if nrm:
+                by = (2 * cfg.num_hidden_layers * (4 + es) + 8) * fl["N"] * cfg.hidden_size
+                other["rmsnorm"] = {"bound": "hbm", "achieved": round(by * args.steps / (msrm * 1e-3) / 1e9, 1), "peak": HBM_PEAK, "unit": "GB/s",
+                                    "launches": nrm, "avg_launch_ms": round(msrm / nrm, 4), "share_of_step": round(msrm / (dt * 1e3), 3)}
+                other["rmsnorm"]["frac"] = round(other["rmsnorm"]["achieved"] / HBM_PEAK, 4)
+            out["roofline_other"] = other
         if world == 1 and not args.no_secondary:
             # What the matrix pipe sustains on this box with NO memory traffic, on zero and on random operands: the shader clock under
             # MFMA load is power managed and data dependent (probe.hip; profiles/r01_gemm_shapes.md section 13), so `peak` (nominal)
