@@ -50,6 +50,8 @@ def _worker(rank, world, port, ids, T, out):
     pre, post = ids[:pos], ids[pos + 1:]
     plan = make_plan(world, T, hw * hw, pre.numel(), post.numel())
     fr = plan.frames[rank]
+    from videoitg_amd.parallel import ContextParallel
+    assert ContextParallel(rank, world).local_frames(T) == fr          # what a caller that shards the pixels itself hands over
     feats = O.siglip_tower(pix[fr.start:fr.stop], vsd, patch=v.patch_size, num_heads=v.num_attention_heads,
                            num_layers=v.num_hidden_layers, select_layer=cfg.mm_vision_select_layer)
     pooled = O.bilinear_pool(feats, hw)
@@ -95,11 +97,11 @@ def _worker(rank, world, port, ids, T, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ids,T", [([-200, 5, 6, 7, 8, 9], 8), ([11, 12, -200, 5, 6], 7)])
-def test_context_parallel_matches_single_process(tmp_path, ids, T):
+@pytest.mark.parametrize("world,ids,T", [(2, [-200, 5, 6, 7, 8, 9], 8), (2, [11, 12, -200, 5, 6], 7), (3, [11, -200, 5, 6, 7], 8)])
+def test_context_parallel_matches_single_process(tmp_path, world, ids, T):
     ids_t = torch.tensor(ids)
     out = str(tmp_path / "logits.pt")
-    mp.spawn(_worker, args=(2, _free_port(), ids_t, T, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ids_t, T, out), nprocs=world, join=True)
     got = torch.load(out)
     cfg = tiny_config(vision_token_num=72)
     sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
