@@ -310,6 +310,7 @@ def main():
 
     timer = GemmTimer()
     ops.gemm = timer.wrap(ops.gemm)
+    ops.gemm_splitk = timer.wrap(ops.gemm_splitk)       # (the o / down projections of a context-parallel rank; includes their reduce kernel)
     # the other kernel classes of the step, timed the same way (HIP events around every launch on the launch stream): attention per
     # head size (MFMA-bound) and the norm kernels (HBM-bound) - north_star asks for both rooflines; reported as `roofline_other`
     t_attn = {72: GemmTimer(), 128: GemmTimer()}
