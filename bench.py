@@ -274,12 +274,19 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path for the product)"
+    if os.environ.get("VITG_BENCH_SINGLE_DEVICE", "0") not in ("", "0"):
+        local = 0                               # dry run of the N > 1 code path on a one-GPU box (with VITG_DIST_BACKEND=gloo: RCCL refuses
+                                                # two ranks on one device); timings of such a run mean nothing
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("VITG_DIST_BACKEND", "nccl")          # "nccl" = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from videoitg_amd import ops, synth
     from videoitg_amd.config import ITGConfig, tiny_config
