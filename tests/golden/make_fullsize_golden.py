@@ -37,20 +37,23 @@ CASES = {
     "b0_512x384": (512, 384, 60),
     "c1_64x384": (64, 384, 60),
     "depth16_224": (16, 224, 60),
+    # robustness: other weights (seed 1), other pixels, a 23-token prompt - the dtype decision must not hinge on one draw
+    "depth16_224_s1": (16, 224, 23, 1, 777),
+    "depth24_280_s2": (24, 280, 41, 2, 4242),
 }
 
 
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     for name in sys.argv[1:]:
-        T, R, L = CASES[name]
+        T, R, L, wseed, pseed = (CASES[name] + (0, 1234))[:5]
         cfg = ITGConfig()
-        ids, pix = fullsize.workload_inputs(cfg, T, R, L)
+        ids, pix = fullsize.workload_inputs(cfg, T, R, L, pseed)
         t0 = time.time()
         with torch.inference_mode():
-            out = fullsize.streaming_forward(cfg, ids, pix, seed=0, log=lambda m: print(f"[{name} +{time.time() - t0:.0f}s] {m}", flush=True))
+            out = fullsize.streaming_forward(cfg, ids, pix, seed=wseed, log=lambda m: print(f"[{name} +{time.time() - t0:.0f}s] {m}", flush=True))
         rk = fullsize.ranking_summary(out["logits"], 32)
-        rec = dict(case=name, frames=T, resolution=R, prompt_len=L, weight_seed=0, pixel_seed=1234, prompt_seed=4321,
+        rec = dict(case=name, frames=T, resolution=R, prompt_len=L, weight_seed=wseed, pixel_seed=pseed, prompt_seed=4321,
                    llm_tokens=out["N"], logits=[float(x) for x in out["logits"].tolist()], **rk, checks=out["checks"],
                    oracle=dict(kind="oracle/videoitg_oracle.py streamed by oracle/fullsize.py, torch CPU fp32",
                                torch=torch.__version__, threads=torch.get_num_threads(), seconds=out["seconds"]))

@@ -18,7 +18,7 @@ import torch
 
 SCORE_TOL = 1e-3
 TOL = {torch.float16: SCORE_TOL, torch.bfloat16: 2.5e-3}
-CASES = ["depth16_224", "c1_64x384", "b0_512x384", "c2_512x448"]
+CASES = ["depth16_224", "depth16_224_s1", "depth24_280_s2", "c1_64x384", "b0_512x384", "c2_512x448"]
 
 
 def load_case(golden_dir, name):
