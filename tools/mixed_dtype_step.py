@@ -13,13 +13,17 @@ cases = sys.argv[1:] or ["c2_512x448"]
 cfg = ITGConfig()
 dev = torch.device("cuda:0")
 F, B = torch.float16, torch.bfloat16
+recs = {c: json.load(open(os.path.join(ROOT, "tests", "golden", f"full_{c}.json"))) for c in cases
+        if os.path.exists(os.path.join(ROOT, "tests", "golden", f"full_{c}.json"))}
 for name, (ldt, vdt) in {"fp16": (F, F), "bf16": (B, B), "tower bf16 + llm fp16": (F, B)}.items():
-    eng = SelectorEngine(packed_random_weights(cfg, ldt, dev, seed=0, vit_dtype=vdt))
-    for case in cases:
-        path = os.path.join(ROOT, "tests", "golden", f"full_{case}.json")
-        if not os.path.exists(path):
-            continue
-        rec = json.load(open(path))
+    eng, eng_seed = None, None
+    for case, rec in recs.items():
+        if eng_seed != rec["weight_seed"]:                       # fixtures with other weight seeds get their own model
+            if eng is not None:
+                eng.release_workspace()
+            eng, eng_seed = None, rec["weight_seed"]
+            torch.cuda.empty_cache()
+            eng = SelectorEngine(packed_random_weights(cfg, ldt, dev, seed=eng_seed, vit_dtype=vdt))
         ids, pix = synth.workload_inputs(cfg, rec["frames"], rec["resolution"], rec["prompt_len"], rec["pixel_seed"])
         pix = pix.to(vdt).to(dev)
         want = torch.tensor(rec["logits"])
