@@ -7,7 +7,7 @@ oracle saw; no oracle code runs here.
 
 Gate (north_star): max |sigmoid score - oracle| <= 1e-3 and an identical Top-K index set for the HEADLINE dtype fp16 (the
 reference's own inference type, eagle/model/builder.py:59).  bf16 is the secondary tier: 8 instead of 11 mantissa bits on every
-MFMA operand cost it 1.4e-3 at 512 x 448^2 (measured, profiles/r02_parity.md), so it is held to a STATED 2.5e-3.  Both bounds
+MFMA operand cost it 1.4e-3 at 512 x 448^2 and 1.7e-3 at 512 x 384^2 (measured, profiles/r02_parity.md), so it is held to a STATED 2.5e-3.  Both bounds
 are fixed numbers - neither comes from a model of this implementation's own rounding.
 """
 import json
