@@ -301,7 +301,7 @@ def test_mfma_probe_runs_and_zero_operands_are_not_slower(ops):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [6, 9, 10])
 def test_gemm_software_tile_loop_bit_identical(ops, dtype, cfg):
-    """gemm_flags bit24: one block per CU walks the tile list instead of one hardware block per tile - same bits, all three epilogues"""
+    """one block per CU walking the tile list (default) vs one hardware block per tile (gemm_flags bit24) - same bits, all three epilogues"""
     M, N, K = 40000, 1152, 640                                                  # 157 x 5 (x 3 for the 384-wide tile) >= 2 tiles per CU
     a, w, b = rnd((M, K), 51, dtype=dtype).to(dtype).cuda(), rnd((N, K), 52, K ** -0.5, dtype=dtype).to(dtype).cuda(), rnd((N,), 53, 0.1, torch.float32).cuda()
     x = rnd((M, N), 54, 1.0, torch.float32).cuda()

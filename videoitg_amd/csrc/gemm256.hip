@@ -63,7 +63,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     constexpr int W_INSTR = W_BYTES / 1024 / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Tile loop.  Launched with one block per tile this runs once; launched with one block per CU (launch256: "software relaunch",
-    // gemm_flags bit24 / auto for long tile lists) the block walks every gridDim.x-th tile of the same XCD-aware order and
+    // default for long tile lists; gemm_flags bit24 turns it off) the block walks every gridDim.x-th tile of the same XCD-aware order and
     // simply starts over - sources, accumulators, first DMA - where the hardware would have launched a fresh block.  Measured on
     // the persistent kernel of gemm_pe.hip: this alone is worth +8-11 % on long-K shapes (profiles/r01_gemm_shapes.md section 15).
     const int nwg_ = g.tiles_m * g.tiles_n;
@@ -786,7 +786,9 @@ static int launch256(GemmArgs g, hipStream_t s) {
     static int cus = 0;
     if (!cus) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur_dev);
     const int nwg = g.tiles_m * g.tiles_n;
-    const bool loop = BN >= 256 && nwg >= 2 * cus && (tuning().gemm_flags & 0x1000000);   // bit24: opt-in until the in-step A/B says otherwise
+    // default since round 2: in-step A/B in fp16, two alternations: 734.8 -> 732.7 ms, GEMM 1073 -> 1079 TF/s (gpurun_out/r02_ab_flags.log);
+    // gemm_flags bit24 switches back to one hardware block per tile (A/B and the bit-identity test)
+    const bool loop = BN >= 256 && nwg >= 2 * cus && !(tuning().gemm_flags & 0x1000000);
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
     hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM, NRM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
