@@ -1,0 +1,47 @@
+"""CPU: the pure-Python parts of bench.py - FLOP accounting (SURVEY.md 8d figures), executed-FLOP correction, parity block."""
+import importlib.util
+import json
+import os
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_algorithmic_flops_match_the_survey():
+    from videoitg_amd.config import ITGConfig
+    cfg = ITGConfig()
+    fl = bench.algorithmic_flops(cfg, 512, 448, 60)
+    assert fl["N"] == 12860 and fl["hw"] == 5 and fl["P"] == 1024
+    assert abs(fl["total"] / 1e12 - 714.8) < 0.5                      # R = 448 -> 714.8 TFLOP per video
+    fl0 = bench.algorithmic_flops(cfg, 512, 384, 60)
+    assert abs(fl0["total"] / 1e12 - 563.3) < 0.5                     # B0
+    fl1 = bench.algorithmic_flops(cfg, 64, 384, 60)
+    assert fl1["hw"] == 16 and abs(fl1["total"] / 1e12 - 364.8) < 0.5  # C1
+    assert bench.algorithmic_flops(cfg, 16, 448, 60)["hw"] == 32      # T <= 22 at a 32 x 32 grid: no pooling (actual-grid clamp)
+
+
+def test_executed_gemm_flops_subtract_only_the_dead_rows():
+    from videoitg_amd.config import ITGConfig
+    cfg = ITGConfig()
+    fl = bench.algorithmic_flops(cfg, 512, 448, 60)
+    ex = bench.executed_gemm_flops(cfg, 512, 448, 60, True)
+    v = cfg.vision
+    skipped = 512 * 2.0 * (1024 - 100) * (2 * v.hidden_size ** 2 + 2 * v.hidden_size * v.intermediate_size)   # 100 of 1024 tokens feed the 5x5 pool
+    assert abs((fl["gemm"] - ex) - skipped) < 1e6 and 0.015 < skipped / fl["gemm"] < 0.03
+    assert bench.executed_gemm_flops(cfg, 512, 448, 60, False) == fl["gemm"]
+    assert bench.executed_gemm_flops(cfg, 16, 448, 60, True) == bench.algorithmic_flops(cfg, 16, 448, 60)["gemm"]   # nothing pooled, nothing skipped
+
+
+def test_parity_block_against_the_committed_fixture():
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "full_c2_512x448.json")))
+    lg = torch.tensor(rec["logits"])
+    blk = bench.parity_block(512, 448, 60, 0, lg, rec["order"])
+    assert blk["fixture"].endswith("full_c2_512x448.json") and blk["pass"] and blk["max_abs_dscore"] == 0.0 and blk["top32_set_match"]
+    off = lg + 0.02                                                    # a 2e-2 logit shift moves scores by up to 5e-3: fails the 1e-3 gate
+    assert not bench.parity_block(512, 448, 60, 0, off, rec["order"])["pass"]
+    assert bench.parity_block(512, 448, 60, 0, off, rec["order"], tol=0.15)["pass"]
+    assert bench.parity_block(100, 448, 60, 0, lg[:100], list(range(100))) is None      # no fixture for this workload
