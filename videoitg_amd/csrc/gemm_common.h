@@ -20,6 +20,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int group_m;              // gemm256: M-tiles per group of the XCD-aware tile order
     int stagger_ns;           // persistent kernel: tile period estimate for de-phasing the XCDs (0 = off)
+    int stagger_blocks;       // gemm_wf, two blocks per CU: blocks of the initial fill that take part in the de-phasing
     int flags;                // bit0: non-temporal output stores, bit1: (profiling) skip output stores
     const void* Wf;           // fragment-packed copy of W (vitg_pack_weight_fragments) or null
     // fused normalisation (round 2; NRM instantiations only).  PRODUCER = MODE_F32 with the residual in the accumulator: besides

@@ -25,14 +25,43 @@
 
 namespace vitg {
 
-constexpr int WF_THREADS = 512, WF_BM = 256, WF_BN = 256, WF_BK = 64, WF_ASTAGES = 4, WF_RING = 8;
+constexpr int WF_BN = 256, WF_BK = 64, WF_ASTAGES = 4, WF_RING = 8;
 
-template <typename T, int MODE, int ABL = 0>      // ABL (profiling, wrong results): 1 no fragment loads, 2 no DMA in steady state
-__global__ __launch_bounds__(WF_THREADS, 2) void gemm_wf_kernel(GemmArgs g) {
+// WF_BM = 256: one 8-wave block per CU (2 M x 4 N waves), the round-1 kernel.
+// WF_BM = 128 (round 2, gemm_flags bit25): FOUR waves per block (1 M x 4 N, the same 128x64 wave tile) and TWO independent blocks per
+// CU - the activation ring is 4 x 16 KiB per block, so two fit the 160 KiB of LDS now that the weights bypass it.  The two blocks of
+// a CU are not in phase, so one block's epilogue / prologue (27 % of an 18-K-tile tile) runs under the other's main loop instead of
+// leaving the matrix pipe idle (profiles/r02_mfma_util.md).  Per wave nothing changes (4 DMA pieces + 8 fragment loads per K-tile:
+// the counted waits below hold for both shapes); there is simply no second wave group inside the block.
+// De-phasing of the two co-resident blocks (WF_BM = 128): identical tiles take identical time, so two blocks that start together
+// stay in phase and reach their epilogues together - which is exactly what the second block was meant to avoid.  Every block of the
+// initial fill draws a ticket per physical CU (XCC id + HW_ID se/sh/cu bits); the odd ticket sleeps stagger_ns before it starts.
+// Later blocks inherit the phase of the block they replace.
+__device__ unsigned wf_tickets[4096];
+
+template <typename T, int MODE, int ABL = 0, int WF_BM = 256>      // ABL (profiling, wrong results): 1 no fragment loads, 2 no DMA in steady state
+__global__ __launch_bounds__(2 * WF_BM, 2) void gemm_wf_kernel(GemmArgs g) {
+    constexpr int NWAVES = WF_BM / 32;
+    if constexpr (WF_BM == 128) {
+        if (g.stagger_ns > 0 && (int)blockIdx.x < g.stagger_blocks) {
+            __shared__ int odd;
+            if (threadIdx.x == 0) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);      // HW_REG_HW_ID bits [15:8]: cu / sh / se
+                const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);                // HW_REG_XCC_ID bits [3:0]
+                odd = atomicAdd(&wf_tickets[((xcc & 15) << 8) | (hw & 255)], 1u) & 1;
+            }
+            __syncthreads();
+            if (odd) {
+                const unsigned long long t0 = wall_clock64();                                   // 100 MHz
+                const unsigned long long ticks = (unsigned long long)g.stagger_ns / 10;
+                while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+            }
+        }
+    }
     typedef typename T16<T>::vec8 vec8;
     constexpr int MT = 4, NT = 2, KS = 4, ROWB = 128, CPR = 8, RPI = 8;
     constexpr int A_BYTES = WF_BM * ROWB;                // 32 KiB per stage
-    constexpr int A_INSTR = A_BYTES / 1024 / 8;          // 4 DMA pieces per wave per K-tile
+    constexpr int A_INSTR = A_BYTES / 1024 / NWAVES;     // 4 DMA pieces per wave per K-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,7 +204,7 @@ __global__ __launch_bounds__(WF_THREADS, 2) void gemm_wf_kernel(GemmArgs g) {
         epilogue_staged<T, MODE_F32, MT, NT>(g, acc, smem + wave * SB, m_base, n_base, lane);
     } else {
         constexpr int SB = MT * 32 * (MODE == MODE_SWIGLU ? 1 : NT) * 64;
-        static_assert(8 * SB <= WF_ASTAGES * A_BYTES, "epilogue staging must fit in the ring");
+        static_assert(NWAVES * SB <= WF_ASTAGES * A_BYTES, "epilogue staging must fit in the ring");
         epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * SB, m_base, n_base, lane);
     }
 }
@@ -195,17 +224,26 @@ __global__ __launch_bounds__(256) void pack_wf_kernel(const char* __restrict__ W
     *(u32x4*)(out + c * 16) = v;
 }
 
-template <typename T, int MODE, int ABL = 0>
-static int launch_wf_tm(const GemmArgs& g, hipStream_t s) {
+template <typename T, int MODE, int ABL = 0, int WF_BM = 256>
+static int launch_wf_tm(GemmArgs g, hipStream_t s) {
     constexpr int LDS = WF_ASTAGES * WF_BM * WF_BK * 2;
     static int done_dev = -1;
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     if (cur_dev != done_dev) {
-        (void)hipFuncSetAttribute((const void*)gemm_wf_kernel<T, MODE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_wf_kernel<T, MODE, ABL, WF_BM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         done_dev = cur_dev;
     }
-    hipLaunchKernelGGL((gemm_wf_kernel<T, MODE, ABL>), dim3(g.tiles_m * g.tiles_n), dim3(WF_THREADS), LDS, s, g);
+    g.tiles_m = ceil_div(g.M, WF_BM);
+    if (WF_BM == 128) {
+        static int cus = 0;
+        if (!cus) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur_dev);
+        g.stagger_blocks = 2 * cus;                      // the initial fill: two blocks per CU
+        // half of what a 128 x 256 tile takes while it shares its CU (~1.1 us per K-tile) unless gemm_stagger gives ns explicitly
+        const int st = tuning().gemm_stagger;
+        g.stagger_ns = st > 1 ? st : st == 1 ? (g.K / 64) * 550 + 3000 : 0;
+    }
+    hipLaunchKernelGGL((gemm_wf_kernel<T, MODE, ABL, WF_BM>), dim3(g.tiles_m * g.tiles_n), dim3(2 * WF_BM), LDS, s, g);
     return (int)hipGetLastError();
 }
 
@@ -218,7 +256,7 @@ bool gemm_wf_applicable(const GemmArgs& g, int mode) {
 
 int launch_gemm_wf(const GemmArgs& g_in, int dtype, int mode, hipStream_t s) {
     GemmArgs g = g_in;
-    g.tiles_m = ceil_div(g.M, WF_BM);
+    g.tiles_m = ceil_div(g.M, 256);
     g.tiles_n = ceil_div(g.N, WF_BN);
     g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
     const int abl = (g.flags >> 16) & 3;                 // profiling only (gemm.hip masks these bits in product runs)
@@ -229,6 +267,13 @@ int launch_gemm_wf(const GemmArgs& g_in, int dtype, int mode, hipStream_t s) {
             case 3: return launch_wf_tm<bf16_t, MODE_STORE16, 3>(g, s);
             default: break;
         }
+    }
+    if (tuning().gemm_flags & 0x2000000) {               // bit25: two independent 4-wave blocks per CU (128 x 256 tiles)
+#define WF_GO2(T)                                                                                    \
+    (mode == MODE_STORE16 ? launch_wf_tm<T, MODE_STORE16, 0, 128>(g, s)                              \
+                          : mode == MODE_F32 ? launch_wf_tm<T, MODE_F32, 0, 128>(g, s) : launch_wf_tm<T, MODE_SWIGLU, 0, 128>(g, s))
+        return dtype == DT_BF16 ? WF_GO2(bf16_t) : WF_GO2(f16_t);
+#undef WF_GO2
     }
 #define WF_GO(T)                                                                                     \
     (mode == MODE_STORE16 ? launch_wf_tm<T, MODE_STORE16>(g, s)                                      \
