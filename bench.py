@@ -563,7 +563,10 @@ def main():
                 "what": "e4m3fn weights (per output channel) + per-token e4m3fn activations into the tower/decoder GEMMs; attention, "
                         "residual stream, norms as in the 16-bit path",
                 "roofline": {"kernel": "gemm_fp8_kernel", "bound": "mfma", "achieved": round(ach8, 1), "peak": 5000.0, "unit": "TFLOP/s",
-                             "frac": round(ach8 / 5000.0, 4), "launches": n8, "avg_launch_ms": round(ms8 / max(n8, 1), 4)},
+                             "frac": round(ach8 / 5000.0, 4), "launches": n8, "avg_launch_ms": round(ms8 / max(n8, 1), 4),
+                             "mfma_only_probe": {"zero_operands": round(ops.mfma_probe_fp8_tflops(False), 1),
+                                                 "random_operands": round(ops.mfma_probe_fp8_tflops(True), 1), "unit": "TFLOP/s",
+                                                 "what": "v_mfma_scale_f32_32x32x64_f8f6f4-only kernel, 8 waves/CU; power-managed clock"}},
                 "parity_vs_oracle": parity_block(T, R, args.prompt_len, args.seed, o8["logits"], o8["order"], tol=0.15),
                 "vs_16bit_hip": {"max_abs_dscore": round((torch.sigmoid(got8) - torch.sigmoid(ref16)).abs().max().item(), 5),
                                  "top32_overlap": len(set(o8["order"][:32]) & set(order[:32]))}}

@@ -109,7 +109,8 @@ int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const void* W8, int 
 /* Profiling aid (no reference counterpart, not on the product path): launches an MFMA-only kernel (blocks x 512 threads, 16
  * v_mfma_f32_32x32x16 per wave and iteration) whose operands are the 8 fragments of `pool` (8 x 64 lanes x 16 bytes, caller
  * filled: zeros, random, ...); *flops receives the flop count of the launch.  bench.py times it to report the MFMA rate the
- * device sustains on zero and on random operands (power-managed clock; videoitg_amd/csrc/probe.hip).  out: blocks*512 floats. */
+ * device sustains on zero and on random operands (power-managed clock; videoitg_amd/csrc/probe.hip).  out: blocks*512 floats.
+ * dtype 3 = the fp8 weight path's instruction (v_mfma_scale_f32_32x32x64_f8f6f4 on e4m3 bytes, 16 per wave and iteration). */
 int vitg_mfma_probe(const void* pool, int dtype, int blocks, int iters, float* out, double* flops, void* stream);
 
 /* out[m, 0..ldo) = LayerNorm(x[m, 0..D)) * w + b  (fp32 stats, eps inside rsqrt), columns D..ldo-1 zeroed.

@@ -216,6 +216,29 @@ def pack_weight_fragments(w: torch.Tensor, n: Optional[int] = None) -> torch.Ten
     return out
 
 
+def mfma_probe_fp8_tflops(random_operands: bool, ms_target: float = 60.0) -> float:
+    """the same probe on the fp8 weight path's MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 bytes)"""
+    import ctypes
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pool = torch.zeros(8 * 64 * 16, dtype=torch.uint8, device=dev)
+    if random_operands:                                   # finite e4m3 values of ordinary magnitude (no NaN encodings: exponent field < 15)
+        pool = (torch.randint(0, 120, pool.shape, device=dev) | (torch.randint(0, 2, pool.shape, device=dev) << 7)).to(torch.uint8)
+    blocks = torch.cuda.get_device_properties(dev).multi_processor_count
+    out = torch.empty(blocks * 512, dtype=torch.float32, device=dev)
+    fl = ctypes.c_double(0.0)
+    iters, tf = 1000, 0.0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call("vitg_mfma_probe", _ptr(pool), 3, blocks, iters, _ptr(out), ctypes.byref(fl), _stream())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        tf = fl.value / ms / 1e9
+        iters = max(500, int(iters * ms_target / max(ms, 1e-3)))
+    return tf
+
+
 def mfma_probe_tflops(dtype: torch.dtype, random_operands: bool, ms_target: float = 60.0) -> float:
     """MFMA-only rate the device sustains (profiling aid, vitg_mfma_probe): zeros vs random operands differ because the shader
     clock under MFMA load is power managed.  Runs for ~3 x ms_target; returns the last measurement in TFLOP/s."""
