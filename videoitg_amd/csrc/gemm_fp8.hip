@@ -133,24 +133,37 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
                 fa[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                // the next K-tile goes into the other stage (last read one interval ago by the sibling group): half of the pieces
-                // in each of the two read phases
+            if (more && pp == 0) {
+                // the next K-tile goes into the other stage (free since the sibling group's last read, one interval ago): ALL pieces in
+                // the FIRST read phase.  A K-tile is only two intervals here, and the pieces must have landed at the end of the second:
+                // issuing half of them in the second read phase made group B wait for its DMA right after issuing it (matrix pipe
+                // 47 % busy on 8192^3 at 1.93 GHz, i.e. not even power-limited; tools/profile_fp8_gemm.sh)
 #pragma unroll
-                for (int j = 0; j < LPT; ++j)
-                    if (j / (LPT / 2) == pp) issue_one(kt + 1, j);
+                for (int j = 0; j < LPT; ++j) issue_one(kt + 1, j);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (pp == F8_KS - 1 && more && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            // The MFMA intrinsic is a pure function of registers: without the two fences below LLVM sinks all 16 MFMAs of a K-tile past
+            // the barriers to the bottom of the loop (seen in the ISA: `s_setprio 1; s_setprio 0` with nothing between them), both wave
+            // groups then fire their MFMAs at the same time and nobody reads fragments meanwhile - matrix pipe 47 % busy at 1.93 GHz.
+            // An empty asm with the accumulators as in/out operands pins "computed before here" / "not started before here".
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, one, 0, one);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (pp == F8_KS - 1 && more && !grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
