@@ -48,6 +48,12 @@ int vitg_norm_stats_finalize(const float* partials, long M, int P, int cols, flo
 int vitg_gemm_norm_consumer(const void* XH, int lda, const void* W, int ldw, int M, int N, int K, int dtype, int mode, const float* bias,
                             int act, void* out, int ldo, const float* stats, const float* colsum, void* stream);
 
+/* Timeline of the 256-tile GEMM kernel.  While a buffer is set, waves 0 and 4 (one per wave group) of the first `blocks` blocks of
+ * every vitg_gemm launch on that kernel write the 100 MHz real-time counter into buf[((block*2 + group)*4 + tile)*32 + slot] for their
+ * first four tiles: slot 0 tile start, 1 first K-tile landed, 2+kt end of K-tile kt (kt < 24), 28 epilogue begins, 29 epilogue stores
+ * issued, 30 tile done, 31 shader-clock counter at tile start.  buf = NULL switches it off.  (tools/gemm_timeline.py) */
+int vitg_gemm_timeline_buffer(void* buf, int blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,7 @@ PROFILING_SIGNATURES = {
     "vitg_gemm_norm_producer": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _i, _p, _p, _i, _p, _p],
     "vitg_norm_stats_finalize": [_p, _l, _i, _i, _f, _i, _p, _p],
     "vitg_gemm_norm_consumer": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p],
+    "vitg_gemm_timeline_buffer": [_p, _i],
 }
 
 _lib = None

@@ -195,6 +195,11 @@ static void set_attrs() {
 #undef SETA
 }
 
+#if VITG_PROFILING_BUILD
+static unsigned long long* g_stamp_buf = nullptr;      // vitg_gemm_timeline_buffer
+static int g_stamp_blocks = 0;
+#endif
+
 struct NormFusion {               // fused normalisation around a GEMM (see GemmArgs::nrm_*): producer or consumer fields, never both
     const float* gamma = nullptr; void* xh = nullptr; int ldxh = 0; float* part = nullptr; int P = 0;
     const float* stats = nullptr; const float* colsum = nullptr;
@@ -216,6 +221,9 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
     g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4; g.Wf = Wf;
     g.split_k = 1; g.split_stride = 0;
+#if VITG_PROFILING_BUILD
+    g.stamps = g_stamp_buf; g.stamp_blocks = g_stamp_blocks;
+#endif
     if (nf) {                                // (callers exist in the profiling build only)
         g.nrm_gamma = nf->gamma; g.nrm_xh = nf->xh; g.nrm_ldxh = nf->ldxh; g.nrm_part = nf->part; g.nrm_P = nf->P;
         g.nrm_stats = nf->stats; g.nrm_colsum = nf->colsum;
@@ -258,6 +266,14 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
                          const float* res, int ldr, int res_mod, void* stream) {
     return gemm_entry(A, lda, W, ldw, nullptr, M, N, K, dtype, mode, bias, act, out, ldo, res, ldr, res_mod, stream);
 }
+
+#if VITG_PROFILING_BUILD
+// Timeline of the 256-tile kernel (gemm256.hip `stamp`): buf holds blocks x 2 wave groups x 4 tiles x 32 slots of u64; nullptr = off.
+extern "C" int vitg_gemm_timeline_buffer(void* buf, int blocks) {
+    g_stamp_buf = (unsigned long long*)buf; g_stamp_blocks = buf ? blocks : 0;
+    return 0;
+}
+#endif
 
 #if VITG_PROFILING_BUILD
 extern "C" int vitg_gemm_wf(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype,

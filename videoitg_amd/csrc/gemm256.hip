@@ -78,6 +78,20 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     int tm, tn;
     block_to_tile(vb, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    // Timeline (profiling build, vitg_gemm_timeline_buffer): waves 0 and 4 of the first stamp_blocks blocks record the 100 MHz
+    // real-time counter at the tile's phase boundaries and after every K-tile, for their first four tiles.
+    // slots: 0 tile start, 1 first K-tile landed, 2+kt end of K-tile kt (kt < 24), 28 epilogue begins, 29 epilogue stores issued,
+    // 30 tile done (LDS drained, barrier), 31 shader-clock counter at tile start
+    const int tile_i_ = (vb - (int)blockIdx.x) / (int)gridDim.x;
+    auto stamp = [&](int slot) {
+        if constexpr (PROF) {
+            if (g.stamps && (int)blockIdx.x < g.stamp_blocks && tile_i_ < 4 && (wave & 3) == 0 && lane == 0)
+                g.stamps[(((size_t)blockIdx.x * 2 + (wave >> 2)) * 4 + tile_i_) * 32 + slot] =
+                    slot == 31 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    stamp(0);
+    stamp(31);
 
     // ---- DMA assignment: one instruction = RPI rows x ROWB bytes; lane -> (row = lane / CPR, LDS chunk slot = lane % CPR)
     // chunk swizzle: BK=32: (row>>3)&3, BK=64: (row>>1)&7 -- both invariant under row += 32 and conflict-free for the
@@ -261,6 +275,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
         const bool grpB = wr == 1;
         if constexpr (PH != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        stamp(1);
         if (grpB) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PH == 3) {
@@ -331,6 +346,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (kt < 24) stamp(2 + kt);
         }
         } else {
         // PH == 2: two k-steps (16 MFMAs, ~512 pipe cycles) per interval, 4 barriers per K-tile.  A: R(kt,q) in interval
@@ -413,6 +429,7 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
 #undef G2_WAIT_OLDER
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
+    stamp(28);
     if (MODE == MODE_F32 && acc_from_res && !(PROF && (g.flags & 16))) {
         // the residual is already in the accumulator: write-only fp32 tile through the LDS transpose -> full-row stores
         // (+1.5...4 % over per-lane 16-B stores; flags bit4 selects the direct form for A/B)
@@ -531,11 +548,13 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
                                                                     n0 + wc * (NT * 32), lane);
         }
     }
+    stamp(29);
     if (vb + (int)gridDim.x < nwg_) {                    // another tile follows: every wave is done with the ring / its staging region
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(30);
     }   // tile loop
 }
 

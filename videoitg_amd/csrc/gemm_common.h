@@ -20,6 +20,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int group_m;              // gemm256: M-tiles per group of the XCD-aware tile order
     int stagger_ns;           // persistent kernel: tile period estimate for de-phasing the XCDs (0 = off)
+    unsigned long long* stamps; // profiling build: per-block timeline (vitg_gemm_timeline_buffer), nullptr = off
+    int stamp_blocks;         // blocks that record (the first stamp_blocks of the grid), 4 tiles x 2 wave groups x 32 slots each
     int stagger_blocks;       // gemm_wf, two blocks per CU: blocks of the initial fill that take part in the de-phasing
     int flags;                // bit0: non-temporal output stores, bit1: (profiling) skip output stores
     const void* Wf;           // fragment-packed copy of W (vitg_pack_weight_fragments) or null

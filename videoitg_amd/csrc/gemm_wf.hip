@@ -94,6 +94,11 @@ __global__ __launch_bounds__(2 * WF_BM, 2) void gemm_wf_kernel(GemmArgs g) {
     // wave-uniform (SGPR pair); a wave whose 64 columns lie past N re-reads the last pair of tiles (its results are not stored)
     const int ntile0 = min((n0 + wc * 64) / 32, ceil_div(g.N, 64) * 2 - 2);
     const char* wf_base = (const char*)g.Wf + ((size_t)ntile0 * nk16) * 1024;
+    {   // the "s" operands below need the compiler to KNOW this is wave-uniform
+        const unsigned long long wb = (unsigned long long)wf_base;
+        wf_base = (const char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wb >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)wb));
+    }
     const unsigned wf_lane = lane * 16, wf_tile = (unsigned)nk16 * 1024u;
     vec8 wq[WF_RING][NT];
     // asm loads: the compiler must not track these (it would wait for them in ITS order); the counted waits below do
