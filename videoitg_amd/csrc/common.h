@@ -86,7 +86,8 @@ struct Tuning {
     int gemm_tile;     // 0 auto | 128 | 256
     int gemm_cfg;      // 0 auto | 1 256x256x32 ring-4 | 2 256x128x32 ring-3 | 3 256x256x64 ring-2 | 4 persistent 256x256x64
     int gemm_flags;    // bit0 non-temporal stores; bits 1-3 profiling ablations (wrong results)
-    int gemm_stagger;  // persistent kernel: de-phase XCDs
+    int gemm_stagger;  // fp32-residual GEMMs in the tile loop: start the tile groups a third of a tile period apart (0 off, 1 = estimated period, > 1 = ns);
+                       // +6 % on the out-proj shape alone, nothing measurable in the step (profiles/r02_gemm_timeline.md): default off
     int gemm_group;    // gemm256: M-tiles per tile-order group (0 = default 4)
     int attn_waves;    // 0 auto | 4 | 8
     int attn_pipe;     // 0 off (default) | 1 cross-tile pipelined hd-72 variant

@@ -67,6 +67,22 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
     // simply starts over - sources, accumulators, first DMA - where the hardware would have launched a fresh block.  Measured on
     // the persistent kernel of gemm_pe.hip: this alone is worth +8-11 % on long-K shapes (profiles/r01_gemm_shapes.md section 15).
     const int nwg_ = g.tiles_m * g.tiles_n;
+    if constexpr (MODE == MODE_F32) {
+        // fp32-residual shapes in the tile loop: every tile is [residual tile -> accumulators: HBM read burst][main loop: operand
+        // stream only][stores: HBM write burst] and all CUs walk these phases in lock-step (residual phase 28 us at 3.6 TB/s where a
+        // lone CU needs 9 us, profiles/r02_gemm_timeline.md).  Starting the tile groups a third of a tile period apart spreads the
+        // bursts; the blocks of one group (group_m x tiles_n tiles sharing operand panels in L2) keep a common phase.
+        if (g.stagger_ns > 0) {
+            int tm0, tn0;
+            block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.group_m, tm0, tn0);
+            const int ph = (tm0 / g.group_m) % 3;
+            if (ph) {
+                const unsigned long long t0 = wall_clock64();                                  // 100 MHz
+                const unsigned long long ticks = (unsigned long long)g.stagger_ns * ph / 30;   // ns -> 10-ns ticks, thirds
+                while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+            }
+        }
+    }
     for (int vb = blockIdx.x; vb < nwg_; vb += gridDim.x) {
     // per-lane quantities are re-derived from an opaque copy of the thread id in every pass: hoisted out of the loop they would all
     // stay live through the main loop (72-90 spilled registers on the wide tiles)
@@ -809,6 +825,10 @@ static int launch256(GemmArgs g, hipStream_t s) {
     // gemm_flags bit24 switches back to one hardware block per tile (A/B and the bit-identity test)
     const bool loop = BN >= 256 && nwg >= 2 * cus && !(tuning().gemm_flags & 0x1000000);
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
+    // gemm_stagger (default off: +6 % on the out-proj shape timed alone, 725.8 / 731.8 vs 734.7 / 732.6 ms in the step, tools/ab_stagger.sh;
+    // 1 = estimate the tile period, > 1 = tile period in ns): de-phase the tile groups of the fp32-residual shapes
+    const int stag = tuning().gemm_stagger;
+    g.stagger_ns = (MODE == MODE_F32 && loop && splits == 1 && stag > 0) ? (stag > 1 ? stag : (g.K / 64) * 2400 + 40000) : 0;
     hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM, NRM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
