@@ -18,15 +18,31 @@ SECS = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
 
 
 def find_hwmon():
-    best = None
+    """hwmon directory of the GPU this process computes on (cuda:0): matched by PCI address - /sys/class/drm lists every GPU and
+    partition of the box, and card0 is not necessarily ours"""
+    want = None
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    except Exception:
+        pass
+    cands = []
     for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
         names = os.listdir(d)
         p = next((os.path.join(d, n) for n in ("power1_average", "power1_input") if n in names), None)
-        if p:
-            best = dict(dir=d, power=p, cap=os.path.join(d, "power1_cap") if "power1_cap" in names else None,
-                        sclk=os.path.join(d, "freq1_input") if "freq1_input" in names else None)
-            break
-    return best
+        if not p:
+            continue
+        pci = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))
+        cands.append(dict(dir=d, pci=pci, power=p, cap=os.path.join(d, "power1_cap") if "power1_cap" in names else None,
+                          sclk=os.path.join(d, "freq1_input") if "freq1_input" in names else None))
+    for c in cands:
+        if want and c["pci"].lower().startswith(want):
+            c["matched"] = True
+            return c
+    if cands:
+        cands[0]["matched"] = False                     # could not match: say so in the output
+        return cands[0]
+    return None
 
 
 def read_num(path):
@@ -78,21 +94,26 @@ def phase(name, fn, hw):
     print(f"{name:34s}: {n:4d} calls in {dt:5.1f} s ({dt / max(n, 1) * 1e3:8.2f} ms each)  {snap}", flush=True)
 
 
-hw = find_hwmon()
-print("hwmon:", hw, flush=True)
-if hw and hw["cap"]:
-    print(f"power cap: {read_num(hw['cap']) / 1e6:.0f} W", flush=True)
-dev = torch.device("cuda:0")
-cfg = ITGConfig()
-eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=0))
-ids, pix = synth.workload_inputs(cfg, 512, 448, 60, 1234)
-pix = pix.to(torch.float16).to(dev)
-eng.forward(ids, None, [pix]); torch.cuda.synchronize()
-phase("idle (sleep)", lambda: time.sleep(0.2), hw)
-phase("fp16 step 512x448 (headline)", lambda: eng.forward(ids, None, [pix]), hw)
-phase("MFMA-only probe, zero operands", lambda: ops.mfma_probe_tflops(torch.float16, False, 40.0), hw)
-phase("MFMA-only probe, random operands", lambda: ops.mfma_probe_tflops(torch.float16, True, 40.0), hw)
-a = torch.randn((8192, 8192), device=dev).half(); w = (torch.randn((8192, 8192), device=dev) / 90).half(); o = torch.empty((8192, 8192), dtype=torch.float16, device=dev)
-def g():
-    for _ in range(50): ops.gemm(a, w, o, mode=0)
-phase("8192^3 fp16 GEMM loop", g, hw)
+def main():
+    hw = find_hwmon()
+    print("hwmon:", hw, flush=True)
+    if hw and hw["cap"]:
+        print(f"power cap: {read_num(hw['cap']) / 1e6:.0f} W", flush=True)
+    dev = torch.device("cuda:0")
+    cfg = ITGConfig()
+    eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=0))
+    ids, pix = synth.workload_inputs(cfg, 512, 448, 60, 1234)
+    pix = pix.to(torch.float16).to(dev)
+    eng.forward(ids, None, [pix]); torch.cuda.synchronize()
+    phase("idle (sleep)", lambda: time.sleep(0.2), hw)
+    phase("fp16 step 512x448 (headline)", lambda: eng.forward(ids, None, [pix]), hw)
+    phase("MFMA-only probe, zero operands", lambda: ops.mfma_probe_tflops(torch.float16, False, 40.0), hw)
+    phase("MFMA-only probe, random operands", lambda: ops.mfma_probe_tflops(torch.float16, True, 40.0), hw)
+    a = torch.randn((8192, 8192), device=dev).half(); w = (torch.randn((8192, 8192), device=dev) / 90).half(); o = torch.empty((8192, 8192), dtype=torch.float16, device=dev)
+    def g():
+        for _ in range(50): ops.gemm(a, w, o, mode=0)
+    phase("8192^3 fp16 GEMM loop", g, hw)
+
+
+if __name__ == "__main__":
+    main()
