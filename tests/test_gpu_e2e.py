@@ -196,6 +196,24 @@ def test_context_parallel_multi_rank_on_one_gpu(world, frames):
     assert (got - want).abs().max().item() <= 1e-5
 
 
+def test_context_parallel_fp8_weight_path_on_one_gpu():
+    """BASELINE.json configs[4] names the fp8 weight path at 1 AND 8 GPUs: the context-parallel forward on fp8 weights (per-token
+    activation scales are row-local, so sharding the rows changes nothing but the kernels' block partition).  Three ranks on one GPU
+    over gloo against the single-rank fp8 forward; the bound is the fp8 tier's own (an fp32 rounding difference in front of a
+    quantiser can move an e4m3 code)."""
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import cp_two_ranks_one_gpu as mod
+    got, want = mod.run(3, 8, port=29551, fp8=True)
+    assert got.shape == want.shape == (8,) and torch.isfinite(got).all()
+    d = (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item()
+    print(f"context-parallel fp8, 3 ranks: max|dscore| vs single-rank fp8 = {d:.2e}")
+    assert d <= 5e-2, d
+
+
 @pytest.mark.parametrize("vit_layers,llm_layers", [(3, 2), (9, 8)])
 def test_full_width_reduced_depth_parity(vit_layers, llm_layers):
     """Real layer widths (SigLIP 1152/4304/16x72, Qwen2 3584/18944, 28 q / 4 kv heads x128, pos-emb interpolation to a
