@@ -282,7 +282,10 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
 }
 
 // called by vitg_attention (attention.hip); hd 72 only (hd 128 runs the software-pipelined kernel)
-int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, hipStream_t s) {
+// waves = 8: 256 queries per block, two blocks per CU.  waves = 16: 512 queries per block, ONE block per CU sharing one K/V ring - the same
+// 4 waves per SIMD (each SIMD holds two group-A and two group-B waves), half the K/V bytes streamed out of L2 per query.
+int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, hipStream_t s) {
+    if (waves == 16) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 16>(a, batch, heads, s) : launch_ab<f16_t, 72, 16>(a, batch, heads, s);
     return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8>(a, batch, heads, s) : launch_ab<f16_t, 72, 8>(a, batch, heads, s);
 }
 
