@@ -325,6 +325,7 @@ def main():
     timer8 = GemmTimer()                                # --fp8: the layer GEMMs run here; patch-embed / projector stay on ops.gemm
     if args.fp8:
         ops.gemm_fp8 = timer8.wrap(ops.gemm_fp8)
+        ops.gemm_fp8_mx = timer8.wrap(ops.gemm_fp8_mx)  # (the tower MLP pair on MX block scales)
     # the other kernel classes of the step, timed the same way (HIP events around every launch on the launch stream): attention per
     # head size (MFMA-bound) and the norm kernels (HBM-bound) - north_star asks for both rooflines; reported as `roofline_other`
     t_attn = {72: GemmTimer(), 128: GemmTimer()}
@@ -559,8 +560,9 @@ def main():
             # priced against the dense fp8 peak.  A separate precision tier: reported beside `value`, never as `value`.
             eng8 = SelectorEngine(packed_random_weights(cfg, dtype, dev, seed=args.seed, fp8=True))
             t8 = GemmTimer()
-            raw_fp8 = ops.gemm_fp8
+            raw_fp8, raw_fp8_mx = ops.gemm_fp8, ops.gemm_fp8_mx
             ops.gemm_fp8 = t8.wrap(ops.gemm_fp8)
+            ops.gemm_fp8_mx = t8.wrap(ops.gemm_fp8_mx)
             o8 = {}
 
             def step_8():
@@ -576,7 +578,7 @@ def main():
             torch.cuda.synchronize()
             d8 = (time.perf_counter() - t4) / 2
             t8.enabled = False
-            ops.gemm_fp8 = raw_fp8
+            ops.gemm_fp8, ops.gemm_fp8_mx = raw_fp8, raw_fp8_mx
             n8, ms8 = t8.summary()
             v = cfg.vision
             layer_gemm = executed_gemm_flops(cfg, T, R, ids.shape[1] - 1, eng8.skip_dead_rows) - fl["patch"] - fl["proj"]
@@ -585,8 +587,8 @@ def main():
             got8 = o8["logits"].float().cpu().view(-1)
             out["secondary"]["fp8"] = {
                 "value": round(T / d8, 2), "unit": "frames/s", "ms_per_step": round(d8 * 1e3, 2),
-                "what": "e4m3fn weights (per output channel) + per-token e4m3fn activations into the tower/decoder GEMMs; attention, "
-                        "residual stream, norms as in the 16-bit path",
+                "what": "e4m3fn weights (per output channel) + per-token e4m3fn activations into the tower/decoder GEMMs (the tower's GELU "
+                        "output as e4m3 + MX block scales straight from fc1's epilogue); attention, residual stream, norms as in the 16-bit path",
                 "roofline": {"kernel": "gemm_fp8_kernel", "bound": "mfma", "achieved": round(ach8, 1), "peak": 5000.0, "unit": "TFLOP/s",
                              "frac": round(ach8 / 5000.0, 4), "launches": n8, "avg_launch_ms": round(ms8 / max(n8, 1), 4),
                              "mfma_only_probe": {"zero_operands": round(ops.mfma_probe_fp8_tflops(False), 1),

@@ -106,6 +106,21 @@ int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const void* W8, int 
                   int out_dtype, int mode, const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
                   void* stream);
 
+/* MX forms of vitg_gemm_fp8: activations that stay e4m3 BETWEEN two GEMMs carry OCP-MX block scales - one E8M0 byte (scale 2^(b-127)) per
+ * 32 consecutive elements of a row, which v_mfma_scale_f32_32x32x64_f8f6f4 consumes as an operand - instead of a per-token fp32 scale
+ * that only a separate pass over the finished row can compute.  Scale array layout: [K/128][ld][4] bytes, i.e. the four block scales
+ * of the 128-deep K-tile kt of row m are the dword at byte ((kt * ld + m) * 4) (ld >= M).  Exactly one of a_mx / o_mx is non-NULL:
+ *   o_mx (producer; mode VITG_GEMM_STORE16): out = e4m3 bytes [M][ldo] (ldo BYTES, multiple of 128, columns N..ldo-1 written as zeros)
+ *        and, per 32-column block, the E8M0 exponent e = ceil(log2(max|v| / 448)) of v = act(sa*sw*acc + bias), out = e4m3(v * 2^-e)
+ *        (round to nearest even, no saturation by construction); o_mx holds ldo/128 planes of ld_omx rows;
+ *   a_mx (consumer; mode VITG_GEMM_F32, act none): A8 is such an output, a_mx its block scales (K/128 planes of ld_amx rows), sa is
+ *        ignored; out = sw[n] * sum_k 2^(e[m,k/32]) A8[m,k] W8[n,k] + bias + res.
+ * Used for the tower MLP on the fp8 path (fc1 + GELU emits the operand of fc2: [3P] SiglipMLP via clip_encoder.py:146): removes the
+ * stand-alone quantiser pass over the GELU output and halves that tensor's bytes. */
+int vitg_gemm_fp8_mx(const void* A8, int lda, const float* sa, const void* a_mx, int ld_amx, const void* W8, int ldw, const float* sw,
+                     int M, int N, int K, int out_dtype, int mode, const float* bias, int act, void* out, int ldo, void* o_mx,
+                     int ld_omx, const float* res, int ldr, void* stream);
+
 /* Profiling aid (no reference counterpart, not on the product path): launches an MFMA-only kernel (blocks x 512 threads, 16
  * v_mfma_f32_32x32x16 per wave and iteration) whose operands are the 8 fragments of `pool` (8 x 64 lanes x 16 bytes, caller
  * filled: zeros, random, ...); *flops receives the flop count of the launch.  bench.py times it to report the MFMA rate the

@@ -15,7 +15,9 @@ that DESIGN.md quotes and that tests/test_numerics_budget.py checks on CPU:
   tower / decoder layer GEMMs (qkv, out, fc1, fc2; qkv, o, gate/up, down) the weight is quantised per OUTPUT CHANNEL and the
   activation per TOKEN to OCP e4m3fn (scale = amax * fp32(1/448), value * (1/scale) rounded to nearest even, clamp +-448), exactly
   the arithmetic of ``quant_rows_kernel`` / ``norm_quant_kernel``; norm outputs are quantised from their fp32 value (the fused
-  kernel never rounds them to 16 bit), attention / GELU / SwiGLU outputs from their 16-bit value.
+  kernel never rounds them to 16 bit), attention / GELU / SwiGLU outputs from their 16-bit value.  With ``fp8_mx`` (the product's
+  default) the tower's GELU output reaches fc2 as e4m3 + OCP-MX block scales written by fc1's epilogue (``vitg_gemm_fp8_mx``): one
+  power-of-two scale per 32 consecutive values, e = ceil(log2(amax / 448)), quantised from the fp32 value (``q8_mx_rows``).
 
 Comparing each against the fp32 oracle gives (a) the rounding noise the product SHOULD show if its kernels are
 otherwise exact and (b) the noise the reference's own fp16 run carries.
@@ -32,8 +34,8 @@ from . import videoitg_oracle as O
 
 
 class Q:
-    def __init__(self, dtype: Optional[torch.dtype], mode: str):
-        self.dtype, self.mode = dtype, mode
+    def __init__(self, dtype: Optional[torch.dtype], mode: str, fp8_mx: bool = True):
+        self.dtype, self.mode, self.fp8_mx = dtype, mode, fp8_mx
 
     def mm(self, t):       # MFMA-input rounding (both modes)
         return t if self.dtype is None else t.to(self.dtype).float()
@@ -47,6 +49,11 @@ class Q:
 
     def a_act(self, t):    # an already 16-bit-rounded activation as GEMM operand
         return q8_rows(t) if self.mode == "fp8" else t
+
+    def a_gelu(self, t):   # the tower's GELU output (fp32 in) as fc2's operand
+        if self.mode == "fp8":
+            return q8_mx_rows(t) if self.fp8_mx else q8_rows(self.mm(t))
+        return self.mm(t)
 
     def w(self, t):        # a layer GEMM weight (rows = output channels)
         return q8_rows(t) if self.mode == "fp8" else t
@@ -64,6 +71,23 @@ def q8_rows(t: torch.Tensor) -> torch.Tensor:
     return q * sc
 
 
+def q8_mx_rows(t: torch.Tensor) -> torch.Tensor:
+    """OCP-MX e4m3 quantise-dequantise along the last dimension with the arithmetic of the MX epilogue of gemm_fp8.hip: blocks of 32,
+    E8M0 exponent e = ceil(log2(amax * fp32(1/448))) taken from the float's bits (exponent field + 1 if any mantissa bit is set),
+    e >= -126, q = RNE(x * 2^-e) as e4m3fn"""
+    t = t.float()
+    n = t.shape[-1]
+    pad = (-n) % 32
+    tb = F.pad(t, (0, pad)).reshape(*t.shape[:-1], -1, 32)
+    amax = tb.abs().amax(-1, keepdim=True)
+    bits = (amax * _INV448).view(torch.int32)
+    e = ((bits >> 23) & 255) - 127 + ((bits & 0x7FFFFF) != 0).to(torch.int32)
+    e = torch.clamp(e, min=-126)
+    inv = torch.exp2(-e.float())
+    q = (tb * inv).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * torch.exp2(e.float())
+    return q.reshape(*t.shape[:-1], -1)[..., :n]
+
+
 def _attn(q, k, v, scale, qz: Q, q_chunk=1024):
     rep = q.shape[1] // k.shape[1]
     k, v = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
@@ -78,8 +102,8 @@ def _attn(q, k, v, scale, qz: Q, q_chunk=1024):
 
 
 def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tensor], dtype=torch.float16,
-            mode: str = "product"):
-    qz = Q(dtype, mode)
+            mode: str = "product", fp8_mx: bool = True):
+    qz = Q(dtype, mode, fp8_mx)
     v = cfg.vision
     images = [im if im.dim() == 4 else im.unsqueeze(0) for im in images]
     pix = qz.mm(torch.cat(list(images), 0).float())
@@ -99,8 +123,8 @@ def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tens
         o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz)).transpose(1, 2).reshape(T, -1, Dv)
         x = qz.every(x + qz.every(F.linear(qz.a_act(o), qz.w(vsd[p + "self_attn.out_proj.weight"]), vsd[p + "self_attn.out_proj.bias"])))
         h = qz.a_norm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm2.weight"], vsd[p + "layer_norm2.bias"], v.layer_norm_eps))
-        f = qz.mm(O.gelu_tanh(qz.every(F.linear(h, qz.w(vsd[p + "mlp.fc1.weight"]), vsd[p + "mlp.fc1.bias"]))))
-        x = qz.every(x + qz.every(F.linear(qz.a_act(f), qz.w(vsd[p + "mlp.fc2.weight"]), vsd[p + "mlp.fc2.bias"])))
+        f = qz.a_gelu(O.gelu_tanh(qz.every(F.linear(h, qz.w(vsd[p + "mlp.fc1.weight"]), vsd[p + "mlp.fc1.bias"]))))
+        x = qz.every(x + qz.every(F.linear(f, qz.w(vsd[p + "mlp.fc2.weight"]), vsd[p + "mlp.fc2.bias"])))
     feats = torch.split(x, [im.shape[0] for im in images], 0)
     # ---- projector
     pre = "model.mm_projector.out_projection."

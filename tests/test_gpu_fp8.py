@@ -195,3 +195,67 @@ def test_fp8_full_depth_vs_oracle(golden_dir, name):
           f"{len(top(outs[True]) & set(rec['topk']))}/{k}, with bf16 HIP {len(top(outs[True]) & top(outs[False]))}/{k}")
     assert torch.isfinite(outs[True]).all()
     assert d_or <= FP8_VS_ORACLE_TOL, d_or
+
+
+def _mx_scales(sc: torch.Tensor, M: int) -> torch.Tensor:
+    """block-scale tensor [K/128, rows, 4] (one dword per row and K-tile) -> int32 exponents [M, K/32]"""
+    return sc.cpu()[:, :M].permute(1, 0, 2).reshape(M, -1).to(torch.int32) - 127
+
+
+def _mx_dequant(q8: torch.Tensor, sc: torch.Tensor, n: int) -> torch.Tensor:
+    """e4m3 bytes [M, >= n] + E8M0 block scales -> fp32 [M, n]"""
+    v = q8.cpu().view(torch.float8_e4m3fn).float()
+    blocks = (n + 31) // 32
+    s = torch.exp2(_mx_scales(sc, q8.shape[0])[:, :blocks].float()).repeat_interleave(32, dim=1)
+    return (v[:, :blocks * 32] * s)[:, :n]
+
+
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("M,N1,K1,N2", [(300, 4304, 1152, 1152), (1000, 576, 256, 384), (257, 1152, 128, 1152)])
+def test_gemm_fp8_mx_producer_and_consumer(M, N1, K1, N2, act):
+    """fc1 -> fc2 on MX block scales (vitg_gemm_fp8_mx): the producer's bytes + scales decode to the 16-bit result of the plain fp8 GEMM
+    within e4m3's half ulp of the block's scaled range (and the padding columns are zero bytes); the consumer equals fp32 arithmetic on
+    the decoded operands."""
+    from videoitg_amd import ops
+    g = torch.Generator().manual_seed(M + N1 + act)
+    a = (torch.randn((M, K1), generator=g) * (0.5 + torch.rand((M, 1), generator=g))).half().cuda()
+    w1 = (torch.randn((N1, K1), generator=g) * K1 ** -0.5).half().cuda()
+    b1 = (torch.randn(N1, generator=g) * 0.1).cuda()
+    a8, sa = ops.quant_rows_fp8(a, K1)
+    w18, sw1 = ops.quant_rows_fp8(w1, K1)
+    Np = ops.pad128(N1)
+    y16 = torch.empty((M, Np), dtype=torch.float16, device="cuda")
+    ops.gemm_fp8(a8, sa, w18, sw1, y16, mode=ops.GEMM_STORE16, out_dtype=torch.float16, bias=b1, act=act)
+    q = torch.full((M, Np), 0x55, dtype=torch.uint8, device="cuda")
+    sc = torch.full((Np // 128, M, 4), 0xEE, dtype=torch.uint8, device="cuda")
+    ops.gemm_fp8_mx(a8, w18, sw1, q, out_dtype=torch.float16, sa=sa, o_mx=sc, bias=b1, act=act)
+    torch.cuda.synchronize()
+    assert (q[:, N1:] == 0).all()                                  # K padding of the next GEMM
+    want = y16[:, :N1].float().cpu()
+    got = _mx_dequant(q, sc, N1)
+    blocks = (N1 + 31) // 32
+    pad = blocks * 32 - N1
+    wb = torch.nn.functional.pad(want, (0, pad)).view(M, blocks, 32)
+    amax = wb.abs().amax(-1)
+    # exponent = ceil(log2(amax / 448)) computed from the fp32 values in the kernel, from the fp16-rounded ones here: identical except
+    # where the rounding crosses a power of two
+    e_want = torch.ceil(torch.log2(torch.clamp(amax, min=1e-30) / 448.0)).to(torch.int32)
+    e_got = _mx_scales(sc, M)[:, :blocks]
+    live = amax > 0
+    assert ((e_got - e_want).abs()[live] <= 1).all()
+    assert ((e_got == e_want)[live].float().mean() > 0.98)
+    # |decoded - 16-bit result| <= half an e4m3 ulp at the top of the block's binade (2^e * 16) + the fp16 rounding of the reference
+    bound = (torch.exp2(e_got.float()) * 16.0 + 2e-3 * amax + 1e-6).repeat_interleave(32, dim=1)[:, :N1]
+    err = (got - want).abs()
+    assert (err <= bound).all(), (err / bound).max()
+    # ---- consumer
+    w2 = (torch.randn((N2, N1), generator=g) * N1 ** -0.5).half().cuda()
+    w28, sw2 = ops.quant_rows_fp8(w2, N1)
+    b2 = (torch.randn(N2, generator=g) * 0.1).cuda()
+    res = torch.randn((M, N2), generator=g).cuda()
+    out = res.clone()
+    ops.gemm_fp8_mx(q, w28, sw2, out, out_dtype=torch.float16, a_mx=sc, bias=b2, res=out)
+    w2f = w28[:, :N1].cpu().view(torch.float8_e4m3fn).double() * sw2.cpu().double()[:, None]
+    ref = got.double() @ w2f.t() + b2.cpu().double() + res.cpu().double()
+    d = (out.cpu().double() - ref).abs().max().item()
+    assert d <= 1e-4 * ref.abs().max().item() + 1e-4, d

@@ -14,8 +14,8 @@
 // barrier cadence - and twice the flops.  Operands by LDS-DMA (saddr form), 2-stage ring, waves 4-7 one barrier behind waves 0-3
 // so that one wave per SIMD owns the matrix pipe while its sibling reads fragments / issues DMA.
 //
-// Fragment layout of the f8f6f4 MFMA (32x32x64, fp8): lane l holds row (l & 31) and the 32 consecutive K bytes
-// [32 (l >> 5), +32) of the 64-deep step, for A and B alike - so any K order inside the instruction pairs A with B correctly.
+// Fragment layout of the f8f6f4 MFMA (32x32x64, fp8): lane l = (row l & 31, h = l >> 5) holds K bytes [16 h, +16) and [32 + 16 h, +16)
+// of the 64-deep step in its registers 0-3 / 4-7, for A and B alike (see the fragment offsets below).
 // C/D layout is the shape's (same as 32x32x16): lane (token = l & 31, h = l >> 5) holds features 8 (r >> 2) + 4 h + (r & 3).
 #include "gemm_common.h"
 
@@ -25,6 +25,11 @@ struct Gemm8Args {
     GemmArgs g;               // A / W are fp8 bytes; lda / ldw in BYTES (multiples of 16); K a multiple of 128
     const float* sa;          // [M] per-token activation scales
     const float* sw;          // [N] per-output-channel weight scales (row order of W8, i.e. interleaved for SwiGLU)
+    // MX block scales (one E8M0 byte per 32 consecutive K elements of a row; the scaled MFMA consumes them directly):
+    // layout [K/128][ld][4] bytes: the four block scales of one 128-deep K-tile of row m sit in ONE dword at ((kt * ld + m) * 4), so the 32
+    // token rows of a fragment read one 128-B line per K-tile (a row-major [M][K/32] array cost 32 lines per load instruction)
+    const unsigned char* a_mx; int ld_amx;   // MXA kernels: A8 is block-scaled; ld_amx >= M rows per K-tile plane; sa unused
+    unsigned char* o_mx; int ld_omx;         // MXO kernels: the output is e4m3 bytes [M][ldo] + block scales in the same layout (the next GEMM's A8 / a_mx)
 };
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -32,8 +37,14 @@ typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int F8_THREADS = 512, F8_ROWB = 128, F8_KS = 2, F8_STAGES = 2;
 
-template <typename T, int MODE, int BM, int BN>
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d);      // (defined with the row quantisers below)
+
+// MXA: the activation operand carries MX block scales (ga.a_mx) instead of a per-token scale.  MXO (MODE_STORE16 only): the output
+// leaves as e4m3 bytes + MX block scales computed in the epilogue - what the producer of the NEXT GEMM's operand would otherwise write
+// as 16 bits and a stand-alone quantiser pass would read back (fc1 -> fc2: 1.8 ms per tower layer).
+template <typename T, int MODE, int BM, int BN, bool MXA = false, bool MXO = false>
 __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
+    static_assert(!MXO || MODE == MODE_STORE16, "MX output exists for the plain 16-bit-output mode only");
     const GemmArgs& g = ga.g;
     constexpr int WM = 2, WN = 4;
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
@@ -89,7 +100,11 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment byte offsets: row*128 + ((chunk ^ swz(row)) << 4), chunk = 4 ks + 2 h (and chunk + 1 = the same address ^ 16)
+    // fragment byte offsets: row*128 + ((chunk ^ swz(row)) << 4).  Hardware K order of the 64-deep fp8 step (probed with one-hot
+    // operands and block scales, tools/ubench/mfma_mx_kmap.hip): registers 0-3 of lane (row, h) are k = 16 h .. +15 of the FIRST
+    // 32-block, registers 4-7 are k = 32 + 16 h .. +15 of the SECOND, and the block scale of the first / second block is taken from
+    // lanes 0-31 / 32-63.  So the two 16-B reads of a lane are chunks 4 ks + h and 4 ks + 2 + h of the row.  (Without block scales any
+    // K order that is the same for both operands would do - round 2's first version read 32 contiguous bytes per lane.)
     const int frow = lane & 31, fh = lane >> 5;
     int a_off[F8_KS][2], w_off[F8_KS][2];
     {
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
         for (int ks = 0; ks < F8_KS; ++ks)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int ch = ((ks * 4 + fh * 2 + u) ^ sw) << 4;
+                const int ch = ((ks * 4 + u * 2 + fh) ^ sw) << 4;
                 a_off[ks][u] = (wr * (MT * 32) + frow) * F8_ROWB + ch;
                 w_off[ks][u] = A_BYTES + (wc * (NT * 32) + frow) * F8_ROWB + ch;
             }
@@ -109,6 +124,19 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
 
     i32x8 fa[MT], fw[NT];
     const int one = 0x7F7F7F7F;                         // E8M0 127 = 2^0 in every byte: block scales off
+    // MXA: per K-tile (128 = 4 blocks of 32) one dword of scale bytes per token row; lane (row, h) needs bytes 2 pp + h of it for k-step
+    // pp -> shifted right by 8 h once, then opsel 0 / 2 picks the byte.  The dword of the NEXT K-tile is fetched with its DMA.
+    unsigned sc_off[MXA ? MT : 1];
+    int sc_cur[MXA ? MT : 1], sc_nxt[MXA ? MT : 1];
+    const unsigned char* const sc_base = MXA ? ga.a_mx + (size_t)m0 * 4 : nullptr;
+    const size_t sc_plane = MXA ? (size_t)ga.ld_amx * 4 : 0;        // bytes per K-tile plane
+    if constexpr (MXA) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            sc_off[mt] = (unsigned)(min(wr * (MT * 32) + mt * 32 + frow, g.M - 1 - m0) * 4);
+            sc_cur[mt] = (int)(*(const unsigned*)(sc_base + sc_off[mt]) >> (8 * fh));
+        }
+    }
     const bool grpB = wr == 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -140,6 +168,14 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
                 // 47 % busy on 8192^3 at 1.93 GHz, i.e. not even power-limited; tools/profile_fp8_gemm.sh)
 #pragma unroll
                 for (int j = 0; j < LPT; ++j) issue_one(kt + 1, j);
+                if constexpr (MXA) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {          // raw dwords: any use here would make the compiler wait for the DMA pieces issued above as well
+                        unsigned off = sc_off[mt];
+                        asm volatile("" : "+v"(off));               // saddr form: uniform base + K-tile advance in SGPRs, 32-bit lane offset
+                        sc_nxt[mt] = (int)*(const unsigned*)(sc_base + (size_t)(kt + 1) * sc_plane + off);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (pp == F8_KS - 1 && more && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -158,8 +194,11 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, one, 0, one);
+                for (int mt = 0; mt < MT; ++mt) {
+                    if constexpr (!MXA) acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, one, 0, one);
+                    else if (pp == 0) acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, one, 0, sc_cur[mt]);
+                    else acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, one, 2, sc_cur[mt]);
+                }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -170,6 +209,15 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (MXA) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                // (landed: both groups passed their vmcnt(0) of this K-tile.)  The opaque copy pins the shift HERE: left alone, LLVM sinks it
+                // into the next iteration behind that iteration's DMA issue and guards it with vmcnt(0) - a full DMA round trip per K-tile
+                sc_cur[mt] = (int)((unsigned)sc_nxt[mt] >> (8 * fh));
+                asm volatile("" : "+v"(sc_cur[mt]));
+            }
+        }
     }
     if (!grpB) __builtin_amdgcn_s_barrier();            // pairs group B's extra barrier
 
@@ -177,7 +225,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
     {
         float sam[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) sam[mt] = ga.sa[min(m0 + wr * (MT * 32) + mt * 32 + frow, g.M - 1)];
+        for (int mt = 0; mt < MT; ++mt) sam[mt] = MXA ? 1.0f : ga.sa[min(m0 + wr * (MT * 32) + mt * 32 + frow, g.M - 1)];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -197,6 +245,69 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
         constexpr int SB = 32 * NT * 128;
         static_assert(8 * SB <= F8_STAGES * STAGE, "fp32 staging must fit in the ring");
         epilogue_staged<T, MODE_F32, MT, NT>(g, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+    } else if constexpr (MXO) {
+        // ---- MX output: bias + activation in fp32, then per (token row, 32-column block = one MFMA tile nt): amax over the lane's 16 values
+        // and its lane ^ 32 partner's 16, E8M0 exponent e = ceil(log2(amax / 448)) (no saturation), q = e4m3(v * 2^-e); bytes staged
+        // through wave-private LDS into 16-B row stores, one scale byte per block.  Columns >= N are written as zeros (they are the K
+        // padding of the next GEMM).
+        static_assert(NT == 2, "MX epilogue is written for the 128 x 64 wave tile");
+        constexpr int RB = NT * 32;                         // staged bytes per row
+        char* stg = smem + wave * (MT * 32 * RB);
+        const int m_base = m0 + wr * (MT * 32), n_base = n0 + wc * (NT * 32);
+        unsigned char* const ob = (unsigned char*)g.out;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            unsigned sc2 = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[16];
+                float amax = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int n = n_base + nt * 32 + q4 * 8 + fh * 4;
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = acc[nt][mt][q4 * 4 + e];
+                    if (g.bias && n < g.N) t += *(const f32x4*)(g.bias + n);
+                    if (g.act == VITG_ACT_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = gelu_tanh_f(t[e]);
+                    } else if (g.act == VITG_ACT_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = gelu_erf_f(t[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = n < g.N ? t[e] : 0.f;
+                        v[q4 * 4 + e] = x;
+                        amax = fmaxf(amax, fabsf(x));
+                    }
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const unsigned bits = __float_as_uint(amax * (1.0f / 448.0f));
+                int ex = (int)((bits >> 23) & 255u) - 127 + ((bits & 0x7fffffu) ? 1 : 0);
+                ex = max(ex, -126);                          // amax = 0 (or denormal): any scale will do, the bytes are zero
+                const float inv = __uint_as_float((unsigned)(127 - ex) << 23);
+                sc2 |= (unsigned)(ex + 127) << (8 * nt);
+                const int row = mt * 32 + frow;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *(unsigned*)(stg + row * RB + nt * 32 + q4 * 8 + fh * 4) =
+                        pack4_fp8(v[q4 * 4] * inv, v[q4 * 4 + 1] * inv, v[q4 * 4 + 2] * inv, v[q4 * 4 + 3] * inv);
+            }
+            const int m = m_base + mt * 32 + frow;
+            if (fh == 0 && m < g.M && n_base < g.ldo)            // n_base is a multiple of 64: this wave's two blocks are half a K-tile dword
+                *(unsigned short*)(ga.o_mx + ((size_t)(n_base / 128) * ga.ld_omx + m) * 4 + (n_base / 32) % 4) = (unsigned short)sc2;
+        }
+        // the same wave reads back what it wrote (LDS ops of one wave complete in order): 16-B chunks, 4 per row
+#pragma unroll
+        for (int i = 0; i < MT * 32 * (RB / 16) / 64; ++i) {
+            const int idx = i * 64 + lane;
+            const int row = idx / (RB / 16), c = idx % (RB / 16);
+            const u32x4 q = *(const u32x4*)(stg + row * RB + c * 16);
+            const int m = m_base + row, n = n_base + c * 16;
+            if (m < g.M && n + 16 <= g.ldo) *(u32x4*)(ob + (size_t)m * g.ldo + n) = q;
+        }
     } else {
         constexpr int STAGE_BYTES = MT * 32 * (MODE == MODE_SWIGLU ? 1 : NT) * 64;
         static_assert(8 * STAGE_BYTES <= F8_STAGES * STAGE, "16-bit staging must fit in the ring");
@@ -204,25 +315,29 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
     }
 }
 
-template <typename T, int MODE, int BM, int BN>
+template <typename T, int MODE, int BM, int BN, bool MXA = false, bool MXO = false>
 static int launch_fp8(Gemm8Args ga, hipStream_t s) {
     constexpr int lds = F8_STAGES * (BM + BN) * F8_ROWB;
     static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     if (cur_dev != done_dev) {
-        (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<T, MODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<T, MODE, BM, BN, MXA, MXO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         done_dev = cur_dev;
     }
     ga.g.tiles_m = ceil_div(ga.g.M, BM);
     ga.g.tiles_n = ceil_div(ga.g.N, BN);
     ga.g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
-    hipLaunchKernelGGL((gemm_fp8_kernel<T, MODE, BM, BN>), dim3(ga.g.tiles_m * ga.g.tiles_n), dim3(F8_THREADS), lds, s, ga);
+    hipLaunchKernelGGL((gemm_fp8_kernel<T, MODE, BM, BN, MXA, MXO>), dim3(ga.g.tiles_m * ga.g.tiles_n), dim3(F8_THREADS), lds, s, ga);
     return (int)hipGetLastError();
 }
 
 template <typename T>
 static int launch_fp8_t(const Gemm8Args& ga, int mode, hipStream_t s) {
+    // MX forms: the two the tower's MLP needs - a block-scaled activation operand into the fp32-residual GEMM (fc2) and the plain
+    // 16-bit-output GEMM emitting block-scaled e4m3 instead (fc1); vitg_gemm_fp8_mx refuses the other combinations
+    if (ga.a_mx) return launch_fp8<T, MODE_F32, 256, 256, true, false>(ga, s);
+    if (ga.o_mx) return launch_fp8<T, MODE_STORE16, 256, 256, false, true>(ga, s);
     if (mode == MODE_SWIGLU) return launch_fp8<T, MODE_SWIGLU, 256, 256>(ga, s);
     if (mode == MODE_F32) return launch_fp8<T, MODE_F32, 256, 256>(ga, s);
     return launch_fp8<T, MODE_STORE16, 256, 256>(ga, s);
@@ -397,6 +512,34 @@ extern "C" int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const voi
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
     g.tiles_m = g.tiles_n = 0; g.stagger_ns = 0; g.group_m = 4; g.Wf = nullptr; g.flags = 0; g.split_k = 1; g.split_stride = 0;
     ga.sa = sa; ga.sw = sw;
+    const int rc = out_dtype == DT_BF16 ? launch_fp8_t<bf16_t>(ga, mode, (hipStream_t)stream) : launch_fp8_t<f16_t>(ga, mode, (hipStream_t)stream);
+    return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+}
+
+// MX forms of vitg_gemm_fp8 (see include/videoitg_hip.h): exactly one of a_mx (consumer, mode F32) / o_mx (producer, mode STORE16)
+extern "C" int vitg_gemm_fp8_mx(const void* A8, int lda, const float* sa, const void* a_mx, int ld_amx, const void* W8, int ldw, const float* sw,
+                                int M, int N, int K, int out_dtype, int mode, const float* bias, int act, void* out, int ldo, void* o_mx,
+                                int ld_omx, const float* res, int ldr, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || K % F8_ROWB != 0) return VITG_ERR_SHAPE;
+    if ((lda % 16) || (ldw % 16) || lda < K || ldw < K) return VITG_ERR_ALIGN;
+    if (!A8 || !W8 || !sw || !out) return VITG_ERR_ARG;
+    if ((a_mx != nullptr) == (o_mx != nullptr)) return VITG_ERR_ARG;
+    if (out_dtype != DT_BF16 && out_dtype != DT_F16) return VITG_ERR_DTYPE;
+    if (a_mx) {                                         // block-scaled activations into the fp32-residual GEMM
+        if (mode != VITG_GEMM_F32 || act != VITG_ACT_NONE) return VITG_ERR_ARG;
+        if (ld_amx < M) return VITG_ERR_ALIGN;
+        if (N % 8 != 0 || ldo % 8 != 0 || (res && ldr % 4 != 0)) return VITG_ERR_ALIGN;
+    } else {                                            // e4m3 + block scales out
+        if (mode != VITG_GEMM_STORE16 || !sa) return VITG_ERR_ARG;
+        if (N % 8 != 0 || ldo % 128 != 0 || ldo < N || ld_omx < M) return VITG_ERR_ALIGN;
+    }
+    Gemm8Args ga = {};
+    GemmArgs& g = ga.g;
+    g.A = A8; g.lda = lda; g.W = W8; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = 0;
+    g.tiles_m = g.tiles_n = 0; g.stagger_ns = 0; g.group_m = 4; g.Wf = nullptr; g.flags = 0; g.split_k = 1; g.split_stride = 0;
+    ga.sa = sa; ga.sw = sw; ga.a_mx = (const unsigned char*)a_mx; ga.ld_amx = ld_amx; ga.o_mx = (unsigned char*)o_mx; ga.ld_omx = ld_omx;
     const int rc = out_dtype == DT_BF16 ? launch_fp8_t<bf16_t>(ga, mode, (hipStream_t)stream) : launch_fp8_t<f16_t>(ga, mode, (hipStream_t)stream);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
 }

@@ -231,6 +231,9 @@ class SelectorEngine:
         # norm kernels (profiles/r02_fused_norm.md), so the kernels live in the profiling library and this switch only exists there.
         from . import _lib as _l
         self.fuse_norm = _l.PROFILING and os.environ.get("VITG_FUSE_NORM", "0") not in ("", "0")
+        # fp8 tower: fc1 (+ GELU) hands its output to fc2 as e4m3 + MX block scales straight from its epilogue (vitg_gemm_fp8_mx) instead
+        # of 16 bits + a stand-alone per-token quantiser pass; VITG_FP8_MX=0 keeps the per-token form (A/B, tests)
+        self.fp8_mx = os.environ.get("VITG_FP8_MX", "1") not in ("", "0")
         self._normplan: Dict[tuple, int] = {}
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[str, torch.Tensor] = {}
@@ -288,6 +291,14 @@ class SelectorEngine:
         sa = self._buf(name + "_qs", (t.shape[0],), torch.float32)
         K.quant_rows_fp8(t, d, a8, sa)
         return a8, sa
+
+    def _mlp_fp8_mx(self, h, fc1_w: "Fp8Weight", fc1_b, fc2_w: "Fp8Weight", fc2_b, x: torch.Tensor, name: str) -> None:
+        """x += fc2(gelu_tanh(fc1(h))) with the hidden activation kept as e4m3 + MX block scales between the two GEMMs"""
+        M, kp = h[0].shape[0], fc2_w.w8.shape[1]
+        f8 = self._buf(name + "_f8", (M, kp), torch.uint8)
+        fsc = self._buf(name + "_fsc", (kp // 128, M, 4), torch.uint8)
+        K.gemm_fp8_mx(h[0], fc1_w.w8, fc1_w.sw, f8, out_dtype=self.vdtype, sa=h[1], o_mx=fsc, bias=fc1_b, act=K.ACT_GELU_TANH)
+        K.gemm_fp8_mx(f8, fc2_w.w8, fc2_w.sw, x, out_dtype=self.vdtype, a_mx=fsc, bias=fc2_b, res=x)
 
     def _producer(self, a, w, x: torch.Tensor, *, bias, res, gamma: Optional[torch.Tensor], name: str, eps: float, rms: bool,
                   dt: torch.dtype, res_mod: int = 0):
@@ -394,6 +405,10 @@ class SelectorEngine:
                                      act=K.ACT_GELU_TANH)
             else:
                 h = self._norm(x, lw.ln2_w, lw.ln2_b, "vit_h", Dv, eps, vdt)
+                if self.fp8_mx and isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight):
+                    self._mlp_fp8_mx(h, lw.fc1_w, lw.fc1_b, lw.fc2_w, lw.fc2_b, x, "vit")
+                    pend = None
+                    continue
                 self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
             nxt = w.vit[li + 1].ln1_w if li + 1 < len(w.vit) else None          # the norm in front of the NEXT layer's qkv
             pend = self._producer(self._operand(f, "vit_f", Fvp), lw.fc2_w, x, bias=lw.fc2_b, res=x, gamma=nxt, name="vit", eps=eps,
@@ -423,6 +438,9 @@ class SelectorEngine:
                     variant=self.attn_variant)
         self._gemm(self._operand(oc, "vit_oc", Dv), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
         hq = self._norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", Dv, eps, vdt)
+        if self.fp8_mx and isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight):
+            self._mlp_fp8_mx(hq, lw.fc1_w, lw.fc1_b, lw.fc2_w, lw.fc2_b, xq, "vit_c")
+            return xq, G, cmap, Pc
         fc = self._buf("vit_fc", (Mc, Fvp), vdt)
         self._gemm(hq, lw.fc1_w, fc, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
         self._gemm(self._operand(fc, "vit_fc", Fvp), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)

@@ -203,6 +203,42 @@ def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Ten
     return out
 
 
+def gemm_fp8_mx(a8: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, out: torch.Tensor, *, out_dtype: torch.dtype,
+                sa: Optional[torch.Tensor] = None, a_mx: Optional[torch.Tensor] = None, o_mx: Optional[torch.Tensor] = None,
+                n: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
+                m: Optional[int] = None) -> torch.Tensor:
+    """MX forms of gemm_fp8 (vitg_gemm_fp8_mx).  Block scales live in a uint8 [K/128, rows >= M, 4] tensor (one dword per row and
+    128-deep K-tile).  Producer: o_mx given, out uint8 [M, ldo] (ldo % 128 == 0) receives e4m3 bytes, sa = per-token scales of a8.
+    Consumer: a_mx given (block scales of a8), out fp32 [M, N] (+ bias + res)."""
+    _req(a8, torch.uint8)
+    _req(w8, torch.uint8)
+    _req(sw, torch.float32)
+    M = a8.shape[0] if m is None else m
+    N = w8.shape[0] if n is None else n
+    K = w8.shape[1]
+    assert a8.shape[1] == K and a8.stride(1) == 1 and w8.stride(1) == 1 and out.stride(1) == 1
+    assert (a_mx is None) != (o_mx is None)
+    if o_mx is not None:
+        _req(out, torch.uint8)
+        _req(o_mx, torch.uint8)
+        _req(sa, torch.float32)
+        mode = GEMM_STORE16
+    else:
+        _req(out, torch.float32)
+        _req(a_mx, torch.uint8)
+        mode = GEMM_F32
+    if bias is not None:
+        _req(bias, torch.float32)
+    if res is not None:
+        _req(res, torch.float32)
+    for t in (a_mx, o_mx):
+        assert t is None or (t.dim() == 3 and t.shape[2] == 4 and t.stride(2) == 1 and t.stride(1) == 4 and t.stride(0) == 4 * t.shape[1])
+    _lib.call("vitg_gemm_fp8_mx", _ptr(a8), a8.stride(0), _ptr(sa), _ptr(a_mx), 0 if a_mx is None else a_mx.shape[1], _ptr(w8), w8.stride(0),
+              _ptr(sw), M, N, K, dt_code(out_dtype), mode, _ptr(bias), act, _ptr(out), out.stride(0), _ptr(o_mx),
+              0 if o_mx is None else o_mx.shape[1], _ptr(res), 0 if res is None else res.stride(0), _stream())
+    return out
+
+
 def pack_weight_fragments(w: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
     """MFMA-fragment-ordered copy of w[:n] [N,K] for gemm(..., wf=...) (vitg_pack_weight_fragments; profiling library only)"""
     import ctypes

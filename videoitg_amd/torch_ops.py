@@ -10,7 +10,7 @@ raises ``NotImplementedError`` from the dispatcher (the product has no CPU path)
 
 ``SelectorEngine`` launches through this module (``videoitg_amd.engine.K``); ``videoitg_amd.ops`` stays the raw binding.
 Names are the build's choice: patchify, gemm, layernorm, rmsnorm, rope_, attention, bilinear_pool,
-gather_rows, embed_gather, pool_score, rank, preprocess_u8, bce_loss, quant_rows_fp8, norm_quant_fp8, gemm_fp8.
+gather_rows, embed_gather, pool_score, rank, preprocess_u8, bce_loss, quant_rows_fp8, norm_quant_fp8, gemm_fp8, gemm_fp8_mx.
 """
 from __future__ import annotations
 
@@ -118,6 +118,13 @@ _def("gemm_fp8(Tensor a8, Tensor sa, Tensor w8, Tensor sw, Tensor(a!) out, int m
      "int act=0, Tensor? res=None, int res_mod=0, int? m=None) -> ()",
      lambda a8, sa, w8, sw, out, mode, out_dtype, n=None, bias=None, act=0, res=None, res_mod=0, m=None:
          (_raw.gemm_fp8(a8, sa, w8, sw, out, mode=mode, out_dtype=_DT[out_dtype], n=n, bias=bias, act=act, res=res, res_mod=res_mod, m=m),
+          None)[1],
+     lambda *a, **k: None)
+
+_def("gemm_fp8_mx(Tensor a8, Tensor w8, Tensor sw, Tensor(a!) out, int out_dtype, Tensor? sa=None, Tensor? a_mx=None, Tensor(b!)? o_mx=None, "
+     "int? n=None, Tensor? bias=None, int act=0, Tensor? res=None, int? m=None) -> ()",
+     lambda a8, w8, sw, out, out_dtype, sa=None, a_mx=None, o_mx=None, n=None, bias=None, act=0, res=None, m=None:
+         (_raw.gemm_fp8_mx(a8, w8, sw, out, out_dtype=_DT[out_dtype], sa=sa, a_mx=a_mx, o_mx=o_mx, n=n, bias=bias, act=act, res=res, m=m),
           None)[1],
      lambda *a, **k: None)
 
@@ -232,10 +239,15 @@ class _Namespace:
         return out
 
     @staticmethod
+    def gemm_fp8_mx(a8, w8, sw, out, *, out_dtype, sa=None, a_mx=None, o_mx=None, n=None, bias=None, act=0, res=None, m=None):
+        _ops.gemm_fp8_mx(a8, w8, sw, out, _CODE[out_dtype], sa, a_mx, o_mx, n, bias, act, res, m)
+        return out
+
+    @staticmethod
     def preprocess_u8(frames, size, out_dtype=torch.float32):
         return _ops.preprocess_u8(frames, size, _CODE[out_dtype])
 
 
 K = _Namespace()
 OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
-                       "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8"]
+                       "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx"]
