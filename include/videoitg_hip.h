@@ -110,13 +110,15 @@ int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const void* W8, int 
  * 32 consecutive elements of a row, which v_mfma_scale_f32_32x32x64_f8f6f4 consumes as an operand - instead of a per-token fp32 scale
  * that only a separate pass over the finished row can compute.  Scale array layout: [K/128][ld][4] bytes, i.e. the four block scales
  * of the 128-deep K-tile kt of row m are the dword at byte ((kt * ld + m) * 4) (ld >= M).  Exactly one of a_mx / o_mx is non-NULL:
- *   o_mx (producer; mode VITG_GEMM_STORE16): out = e4m3 bytes [M][ldo] (ldo BYTES, multiple of 128, columns N..ldo-1 written as zeros)
+ *   o_mx (producer; mode VITG_GEMM_STORE16, or VITG_GEMM_SWIGLU with N/2 output columns): out = e4m3 bytes [M][ldo] (ldo BYTES, multiple
+ *        of 128, columns past the last output column written as zeros)
  *        and, per 32-column block, the E8M0 exponent e = ceil(log2(max|v| / 448)) of v = act(sa*sw*acc + bias), out = e4m3(v * 2^-e)
  *        (round to nearest even, no saturation by construction); o_mx holds ldo/128 planes of ld_omx rows;
  *   a_mx (consumer; mode VITG_GEMM_F32, act none): A8 is such an output, a_mx its block scales (K/128 planes of ld_amx rows), sa is
  *        ignored; out = sw[n] * sum_k 2^(e[m,k/32]) A8[m,k] W8[n,k] + bias + res.
- * Used for the tower MLP on the fp8 path (fc1 + GELU emits the operand of fc2: [3P] SiglipMLP via clip_encoder.py:146): removes the
- * stand-alone quantiser pass over the GELU output and halves that tensor's bytes. */
+ * Used for both MLPs on the fp8 path (fc1 + GELU emits the operand of fc2: [3P] SiglipMLP via clip_encoder.py:146; gate/up + SwiGLU emits
+ * the operand of down: [3P] Qwen2MLP via grounding_qwen2.py:135): removes the stand-alone quantiser pass over the hidden activation and
+ * halves that tensor's bytes. */
 int vitg_gemm_fp8_mx(const void* A8, int lda, const float* sa, const void* a_mx, int ld_amx, const void* W8, int ldw, const float* sw,
                      int M, int N, int K, int out_dtype, int mode, const float* bias, int act, void* out, int ldo, void* o_mx,
                      int ld_omx, const float* res, int ldr, void* stream);

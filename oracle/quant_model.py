@@ -16,7 +16,8 @@ that DESIGN.md quotes and that tests/test_numerics_budget.py checks on CPU:
   activation per TOKEN to OCP e4m3fn (scale = amax * fp32(1/448), value * (1/scale) rounded to nearest even, clamp +-448), exactly
   the arithmetic of ``quant_rows_kernel`` / ``norm_quant_kernel``; norm outputs are quantised from their fp32 value (the fused
   kernel never rounds them to 16 bit), attention / GELU / SwiGLU outputs from their 16-bit value.  With ``fp8_mx`` (the product's
-  default) the tower's GELU output reaches fc2 as e4m3 + OCP-MX block scales written by fc1's epilogue (``vitg_gemm_fp8_mx``): one
+  default) the tower's GELU output and the decoder's SwiGLU output reach fc2 / down as e4m3 + OCP-MX block scales written by the producing
+  GEMM's epilogue (``vitg_gemm_fp8_mx``): one
   power-of-two scale per 32 consecutive values, e = ceil(log2(amax / 448)), quantised from the fp32 value (``q8_mx_rows``).
 
 Comparing each against the fp32 oracle gives (a) the rounding noise the product SHOULD show if its kernels are
@@ -51,6 +52,11 @@ class Q:
         return q8_rows(t) if self.mode == "fp8" else t
 
     def a_gelu(self, t):   # the tower's GELU output (fp32 in) as fc2's operand
+        if self.mode == "fp8":
+            return q8_mx_rows(t) if self.fp8_mx else q8_rows(self.mm(t))
+        return self.mm(t)
+
+    def a_swiglu(self, t):  # the decoder's silu(gate) * up (fp32 in) as down's operand
         if self.mode == "fp8":
             return q8_mx_rows(t) if self.fp8_mx else q8_rows(self.mm(t))
         return self.mm(t)
@@ -160,8 +166,8 @@ def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tens
             h = qz.a_norm(O.rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
             g = qz.every(F.linear(h, qz.w(sd[p + "mlp.gate_proj.weight"])))
             u = qz.every(F.linear(h, qz.w(sd[p + "mlp.up_proj.weight"])))
-            f = qz.mm(qz.every(F.silu(g)) * u)
-            x = qz.every(x + qz.every(F.linear(qz.a_act(f), qz.w(sd[p + "mlp.down_proj.weight"]))))
+            f = qz.a_swiglu(qz.every(F.silu(g)) * u)
+            x = qz.every(x + qz.every(F.linear(f, qz.w(sd[p + "mlp.down_proj.weight"]))))
         hfin = qz.every(O.rms_norm(x, sd["model.norm.weight"], cfg.rms_norm_eps))
         tt = tts[b][mask[b]]
         pooled = qz.every(hfin[0][tt == 3].reshape(im.shape[0], -1, D).mean(1))

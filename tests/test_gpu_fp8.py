@@ -259,3 +259,35 @@ def test_gemm_fp8_mx_producer_and_consumer(M, N1, K1, N2, act):
     ref = got.double() @ w2f.t() + b2.cpu().double() + res.cpu().double()
     d = (out.cpu().double() - ref).abs().max().item()
     assert d <= 1e-4 * ref.abs().max().item() + 1e-4, d
+
+
+@pytest.mark.parametrize("M,F_,K1", [(300, 1152, 256), (1000, 18944, 128), (77, 192, 384)])
+def test_gemm_fp8_mx_swiglu_producer(M, F_, K1):
+    """gate/up + SwiGLU emitting e4m3 + MX block scales: decodes to the 16-bit SwiGLU output of the plain fp8 GEMM within e4m3's half ulp
+    of each block's scaled range; padding columns are zero bytes"""
+    from videoitg_amd import ops
+    g = torch.Generator().manual_seed(M + F_)
+    a = torch.randn((M, K1), generator=g).half().cuda()
+    w = (torch.randn((2 * F_, K1), generator=g) * K1 ** -0.5).half().cuda()        # rows already interleaved gate / up per 32 as the engine packs them
+    a8, sa = ops.quant_rows_fp8(a, K1)
+    w8, sw = ops.quant_rows_fp8(w, K1)
+    Fp = ops.pad128(F_)
+    y16 = torch.zeros((M, Fp), dtype=torch.float16, device="cuda")
+    ops.gemm_fp8(a8, sa, w8, sw, y16, mode=ops.GEMM_SWIGLU, out_dtype=torch.float16)
+    q = torch.full((M, Fp), 0x55, dtype=torch.uint8, device="cuda")
+    sc = torch.full((Fp // 128, M, 4), 0xEE, dtype=torch.uint8, device="cuda")
+    ops.gemm_fp8_mx(a8, w8, sw, q, out_dtype=torch.float16, sa=sa, o_mx=sc, swiglu=True)
+    torch.cuda.synchronize()
+    assert (q[:, F_:] == 0).all()
+    want = y16[:, :F_].float().cpu()
+    got = _mx_dequant(q, sc, F_)
+    blocks = (F_ + 31) // 32
+    wb = torch.nn.functional.pad(want, (0, blocks * 32 - F_)).view(M, blocks, 32)
+    amax = wb.abs().amax(-1)
+    e_got = _mx_scales(sc, M)[:, :blocks]
+    e_want = torch.ceil(torch.log2(torch.clamp(amax, min=1e-30) / 448.0)).to(torch.int32)
+    live = amax > 1e-6
+    assert ((e_got - e_want).abs()[live] <= 1).all()
+    bound = (torch.exp2(e_got.float()) * 16.0 + 2e-3 * amax + 1e-6).repeat_interleave(32, dim=1)[:, :F_]
+    err = (got - want).abs()
+    assert (err <= bound).all(), (err / bound).max()

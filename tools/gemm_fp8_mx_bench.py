@@ -31,3 +31,22 @@ t["fc1 -> MX e4m3"] = timeit(lambda: ops.gemm_fp8_mx(x8, w18, sw1, f8, out_dtype
 t["fc2 (MX)"] = timeit(lambda: ops.gemm_fp8_mx(f8, w28, sw2, res, out_dtype=dt, a_mx=fsc, bias=b2, res=res))
 for k, v in t.items(): print(f"{k:18s} {v:7.3f} ms", flush=True)
 print(f"per-token chain {t['fc1 -> fp16'] + t['quantiser'] + t['fc2 (per-token)']:.3f} ms   MX chain {t['fc1 -> MX e4m3'] + t['fc2 (MX)']:.3f} ms")
+
+# ---- the decoder MLP (M = 12860 tokens): gate/up + SwiGLU -> down
+del x, w1, w2, x8, w18, w28, f16, f8, sf, fsc, res
+torch.cuda.empty_cache()
+M, D, Fl = 12860, 3584, 18944
+x = torch.randn((M, D), device="cuda").to(dt)
+wg = (torch.randn((2 * Fl, D), device="cuda") * D ** -0.5).to(dt); wd = (torch.randn((D, Fl), device="cuda") * Fl ** -0.5).to(dt)
+x8, sx = ops.quant_rows_fp8(x, D); wg8, swg = ops.quant_rows_fp8(wg, D); wd8, swd = ops.quant_rows_fp8(wd, Fl)
+f16 = torch.empty((M, Fl), dtype=dt, device="cuda"); f8 = torch.empty((M, Fl), dtype=torch.uint8, device="cuda")
+sf = torch.empty(M, dtype=torch.float32, device="cuda"); fsc = torch.empty((Fl // 128, M, 4), dtype=torch.uint8, device="cuda")
+res = torch.zeros((M, D), dtype=torch.float32, device="cuda")
+t = {}
+t["gate/up -> fp16"] = timeit(lambda: ops.gemm_fp8(x8, sx, wg8, swg, f16, mode=2, out_dtype=dt))
+t["quantiser"] = timeit(lambda: ops.quant_rows_fp8(f16, Fl, f8, sf))
+t["down (per-token)"] = timeit(lambda: ops.gemm_fp8(f8, sf, wd8, swd, res, mode=1, out_dtype=dt, res=res))
+t["gate/up -> MX e4m3"] = timeit(lambda: ops.gemm_fp8_mx(x8, wg8, swg, f8, out_dtype=dt, sa=sx, o_mx=fsc, swiglu=True))
+t["down (MX)"] = timeit(lambda: ops.gemm_fp8_mx(f8, wd8, swd, res, out_dtype=dt, a_mx=fsc, res=res))
+for k, v in t.items(): print(f"{k:20s} {v:7.3f} ms", flush=True)
+print(f"per-token chain {t['gate/up -> fp16'] + t['quantiser'] + t['down (per-token)']:.3f} ms   MX chain {t['gate/up -> MX e4m3'] + t['down (MX)']:.3f} ms")

@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
 // as 16 bits and a stand-alone quantiser pass would read back (fc1 -> fc2: 1.8 ms per tower layer).
 template <typename T, int MODE, int BM, int BN, bool MXA = false, bool MXO = false>
 __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
-    static_assert(!MXO || MODE == MODE_STORE16, "MX output exists for the plain 16-bit-output mode only");
+    static_assert(!MXO || MODE != MODE_F32, "MX output exists for the 16-bit-output modes (plain and SwiGLU)");
     const GemmArgs& g = ga.g;
     constexpr int WM = 2, WN = 4;
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
@@ -246,39 +246,47 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
         static_assert(8 * SB <= F8_STAGES * STAGE, "fp32 staging must fit in the ring");
         epilogue_staged<T, MODE_F32, MT, NT>(g, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
     } else if constexpr (MXO) {
-        // ---- MX output: bias + activation in fp32, then per (token row, 32-column block = one MFMA tile nt): amax over the lane's 16 values
-        // and its lane ^ 32 partner's 16, E8M0 exponent e = ceil(log2(amax / 448)) (no saturation), q = e4m3(v * 2^-e); bytes staged
-        // through wave-private LDS into 16-B row stores, one scale byte per block.  Columns >= N are written as zeros (they are the K
-        // padding of the next GEMM).
+        // ---- MX output: bias + activation (or SwiGLU) in fp32, then per (token row, 32-column output block = one MFMA tile): amax over the
+        // lane's 16 values and its lane ^ 32 partner's 16, E8M0 exponent e = ceil(log2(amax / 448)) (no saturation), q = e4m3(v * 2^-e);
+        // bytes staged through wave-private LDS into 16-B row stores, one scale byte per block.  Columns >= N_out are written as zeros
+        // (they are the K padding of the next GEMM).
         static_assert(NT == 2, "MX epilogue is written for the 128 x 64 wave tile");
-        constexpr int RB = NT * 32;                         // staged bytes per row
+        constexpr int NTO = MODE == MODE_SWIGLU ? 1 : NT;   // 32-column output blocks per wave
+        constexpr int RB = NTO * 32;                        // staged bytes per row
         char* stg = smem + wave * (MT * 32 * RB);
-        const int m_base = m0 + wr * (MT * 32), n_base = n0 + wc * (NT * 32);
+        const int m_base = m0 + wr * (MT * 32);
+        const int n_base = MODE == MODE_SWIGLU ? (n0 + wc * (NT * 32)) / 2 : n0 + wc * (NT * 32);     // first OUTPUT column of this wave
+        const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
         unsigned char* const ob = (unsigned char*)g.out;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             unsigned sc2 = 0;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int nt = 0; nt < NTO; ++nt) {
                 float v[16];
                 float amax = 0.f;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int n = n_base + nt * 32 + q4 * 8 + fh * 4;
                     f32x4 t;
+                    if constexpr (MODE == MODE_SWIGLU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = acc[nt][mt][q4 * 4 + e];
-                    if (g.bias && n < g.N) t += *(const f32x4*)(g.bias + n);
-                    if (g.act == VITG_ACT_GELU_TANH) {
+                        for (int e = 0; e < 4; ++e) t[e] = silu_f(acc[0][mt][q4 * 4 + e]) * acc[NT - 1][mt][q4 * 4 + e];
+                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = gelu_tanh_f(t[e]);
-                    } else if (g.act == VITG_ACT_GELU_ERF) {
+                        for (int e = 0; e < 4; ++e) t[e] = acc[nt][mt][q4 * 4 + e];
+                        if (g.bias && n < g.N) t += *(const f32x4*)(g.bias + n);
+                        if (g.act == VITG_ACT_GELU_TANH) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = gelu_erf_f(t[e]);
+                            for (int e = 0; e < 4; ++e) t[e] = gelu_tanh_f(t[e]);
+                        } else if (g.act == VITG_ACT_GELU_ERF) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[e] = gelu_erf_f(t[e]);
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x = n < g.N ? t[e] : 0.f;
+                        const float x = n < n_lim ? t[e] : 0.f;
                         v[q4 * 4 + e] = x;
                         amax = fmaxf(amax, fabsf(x));
                     }
@@ -296,10 +304,13 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
                         pack4_fp8(v[q4 * 4] * inv, v[q4 * 4 + 1] * inv, v[q4 * 4 + 2] * inv, v[q4 * 4 + 3] * inv);
             }
             const int m = m_base + mt * 32 + frow;
-            if (fh == 0 && m < g.M && n_base < g.ldo)            // n_base is a multiple of 64: this wave's two blocks are half a K-tile dword
-                *(unsigned short*)(ga.o_mx + ((size_t)(n_base / 128) * ga.ld_omx + m) * 4 + (n_base / 32) % 4) = (unsigned short)sc2;
+            if (fh == 0 && m < g.M && n_base < g.ldo) {          // this wave's NTO blocks are a quarter / half of a K-tile dword of the consumer
+                unsigned char* sp = ga.o_mx + ((size_t)(n_base / 128) * ga.ld_omx + m) * 4 + (n_base / 32) % 4;
+                if constexpr (NTO == 2) *(unsigned short*)sp = (unsigned short)sc2;
+                else *sp = (unsigned char)sc2;
+            }
         }
-        // the same wave reads back what it wrote (LDS ops of one wave complete in order): 16-B chunks, 4 per row
+        // the same wave reads back what it wrote (LDS ops of one wave complete in order): 16-B chunks
 #pragma unroll
         for (int i = 0; i < MT * 32 * (RB / 16) / 64; ++i) {
             const int idx = i * 64 + lane;
@@ -337,7 +348,7 @@ static int launch_fp8_t(const Gemm8Args& ga, int mode, hipStream_t s) {
     // MX forms: the two the tower's MLP needs - a block-scaled activation operand into the fp32-residual GEMM (fc2) and the plain
     // 16-bit-output GEMM emitting block-scaled e4m3 instead (fc1); vitg_gemm_fp8_mx refuses the other combinations
     if (ga.a_mx) return launch_fp8<T, MODE_F32, 256, 256, true, false>(ga, s);
-    if (ga.o_mx) return launch_fp8<T, MODE_STORE16, 256, 256, false, true>(ga, s);
+    if (ga.o_mx) return mode == MODE_SWIGLU ? launch_fp8<T, MODE_SWIGLU, 256, 256, false, true>(ga, s) : launch_fp8<T, MODE_STORE16, 256, 256, false, true>(ga, s);
     if (mode == MODE_SWIGLU) return launch_fp8<T, MODE_SWIGLU, 256, 256>(ga, s);
     if (mode == MODE_F32) return launch_fp8<T, MODE_F32, 256, 256>(ga, s);
     return launch_fp8<T, MODE_STORE16, 256, 256>(ga, s);
@@ -531,8 +542,9 @@ extern "C" int vitg_gemm_fp8_mx(const void* A8, int lda, const float* sa, const 
         if (ld_amx < M) return VITG_ERR_ALIGN;
         if (N % 8 != 0 || ldo % 8 != 0 || (res && ldr % 4 != 0)) return VITG_ERR_ALIGN;
     } else {                                            // e4m3 + block scales out
-        if (mode != VITG_GEMM_STORE16 || !sa) return VITG_ERR_ARG;
-        if (N % 8 != 0 || ldo % 128 != 0 || ldo < N || ld_omx < M) return VITG_ERR_ALIGN;
+        if ((mode != VITG_GEMM_STORE16 && mode != VITG_GEMM_SWIGLU) || !sa) return VITG_ERR_ARG;
+        if (mode == VITG_GEMM_SWIGLU && N % 64 != 0) return VITG_ERR_SHAPE;
+        if (N % 8 != 0 || ldo % 128 != 0 || ldo < (mode == VITG_GEMM_SWIGLU ? N / 2 : N) || ld_omx < M) return VITG_ERR_ALIGN;
     }
     Gemm8Args ga = {};
     GemmArgs& g = ga.g;

@@ -513,6 +513,15 @@ class SelectorEngine:
                 K.gemm_norm_consumer(pend[0], lw.gu_w, f, mode=K.GEMM_SWIGLU, stats=pend[1])
             else:
                 h = self._norm(x, lw.post_ln, None, "llm_h", D, cfg.rms_norm_eps)
+                if self.fp8_mx and isinstance(lw.gu_w, Fp8Weight) and isinstance(lw.down_w, Fp8Weight):
+                    # silu(gate) * up leaves gate/up's epilogue as e4m3 + MX block scales and is down's operand as it stands
+                    kp = lw.down_w.w8.shape[1]
+                    f8 = self._buf("llm_f8", (N, kp), torch.uint8)
+                    fsc = self._buf("llm_fsc", (kp // 128, N, 4), torch.uint8)
+                    K.gemm_fp8_mx(h[0], lw.gu_w.w8, lw.gu_w.sw, f8, out_dtype=self.dtype, sa=h[1], o_mx=fsc, swiglu=True)
+                    K.gemm_fp8_mx(f8, lw.down_w.w8, lw.down_w.sw, x, out_dtype=self.dtype, a_mx=fsc, res=x)
+                    pend = None
+                    continue
                 self._gemm(h, lw.gu_w, f, mode=K.GEMM_SWIGLU)
             nxt = w.llm[li + 1].in_ln if (fuse and li + 1 < len(w.llm)) else None
             pend = self._producer(self._operand(f, "llm_f", Fp), lw.down_w, x, bias=None, res=x, gamma=nxt, name="llm",

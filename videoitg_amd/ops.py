@@ -206,8 +206,8 @@ def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Ten
 def gemm_fp8_mx(a8: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, out: torch.Tensor, *, out_dtype: torch.dtype,
                 sa: Optional[torch.Tensor] = None, a_mx: Optional[torch.Tensor] = None, o_mx: Optional[torch.Tensor] = None,
                 n: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
-                m: Optional[int] = None) -> torch.Tensor:
-    """MX forms of gemm_fp8 (vitg_gemm_fp8_mx).  Block scales live in a uint8 [K/128, rows >= M, 4] tensor (one dword per row and
+                m: Optional[int] = None, swiglu: bool = False) -> torch.Tensor:
+    """MX forms of gemm_fp8 (vitg_gemm_fp8_mx).  swiglu (producer only): w8 rows are gate / up interleaved as for GEMM_SWIGLU, N/2 outputs.  Block scales live in a uint8 [K/128, rows >= M, 4] tensor (one dword per row and
     128-deep K-tile).  Producer: o_mx given, out uint8 [M, ldo] (ldo % 128 == 0) receives e4m3 bytes, sa = per-token scales of a8.
     Consumer: a_mx given (block scales of a8), out fp32 [M, N] (+ bias + res)."""
     _req(a8, torch.uint8)
@@ -222,8 +222,9 @@ def gemm_fp8_mx(a8: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, out: torch
         _req(out, torch.uint8)
         _req(o_mx, torch.uint8)
         _req(sa, torch.float32)
-        mode = GEMM_STORE16
+        mode = GEMM_SWIGLU if swiglu else GEMM_STORE16
     else:
+        assert not swiglu
         _req(out, torch.float32)
         _req(a_mx, torch.uint8)
         mode = GEMM_F32

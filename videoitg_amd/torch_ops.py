@@ -122,10 +122,10 @@ _def("gemm_fp8(Tensor a8, Tensor sa, Tensor w8, Tensor sw, Tensor(a!) out, int m
      lambda *a, **k: None)
 
 _def("gemm_fp8_mx(Tensor a8, Tensor w8, Tensor sw, Tensor(a!) out, int out_dtype, Tensor? sa=None, Tensor? a_mx=None, Tensor(b!)? o_mx=None, "
-     "int? n=None, Tensor? bias=None, int act=0, Tensor? res=None, int? m=None) -> ()",
-     lambda a8, w8, sw, out, out_dtype, sa=None, a_mx=None, o_mx=None, n=None, bias=None, act=0, res=None, m=None:
-         (_raw.gemm_fp8_mx(a8, w8, sw, out, out_dtype=_DT[out_dtype], sa=sa, a_mx=a_mx, o_mx=o_mx, n=n, bias=bias, act=act, res=res, m=m),
-          None)[1],
+     "int? n=None, Tensor? bias=None, int act=0, Tensor? res=None, int? m=None, bool swiglu=False) -> ()",
+     lambda a8, w8, sw, out, out_dtype, sa=None, a_mx=None, o_mx=None, n=None, bias=None, act=0, res=None, m=None, swiglu=False:
+         (_raw.gemm_fp8_mx(a8, w8, sw, out, out_dtype=_DT[out_dtype], sa=sa, a_mx=a_mx, o_mx=o_mx, n=n, bias=bias, act=act, res=res, m=m,
+                           swiglu=swiglu), None)[1],
      lambda *a, **k: None)
 
 # ---- call-compatible namespace for the engine (same signatures as videoitg_amd.ops) ------------------------------------
@@ -239,8 +239,8 @@ class _Namespace:
         return out
 
     @staticmethod
-    def gemm_fp8_mx(a8, w8, sw, out, *, out_dtype, sa=None, a_mx=None, o_mx=None, n=None, bias=None, act=0, res=None, m=None):
-        _ops.gemm_fp8_mx(a8, w8, sw, out, _CODE[out_dtype], sa, a_mx, o_mx, n, bias, act, res, m)
+    def gemm_fp8_mx(a8, w8, sw, out, *, out_dtype, sa=None, a_mx=None, o_mx=None, n=None, bias=None, act=0, res=None, m=None, swiglu=False):
+        _ops.gemm_fp8_mx(a8, w8, sw, out, _CODE[out_dtype], sa, a_mx, o_mx, n, bias, act, res, m, swiglu)
         return out
 
     @staticmethod
