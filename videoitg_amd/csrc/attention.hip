@@ -12,6 +12,7 @@
 //
 // Block = 4 waves x 32 queries = 128 queries; KV tile = 64 keys, double-buffered in LDS.
 #include "attn_common.h"
+#include <math.h>
 #include "../../include/videoitg_hip.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -495,7 +496,18 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     // through registers for hd 128 (DMA measured 3-6 % slower there).  attn_waves / attn_dma (1 = DMA, 2 = registers) pin them.
     const int nw_env = tuning().attn_waves;
     int nw = nw_env ? nw_env : 8;
-    if (!nw_env && (long)ceil_div(S, 256) * heads * batch < 384) nw = 4;       // too few 256-query blocks to fill the chip
+    if (!nw_env) {
+        // 256-query blocks run one per CU, 128-query blocks two per CU: with r = blocks / slots rounds of work the chip is r / ceil(r)
+        // busy.  The block size with the fuller last round wins (measured on the per-rank shapes of the context-parallel LLM,
+        // tools/attn_cp_shapes.py: 1660 queries x 28 heads -> 196 big blocks on 256 CUs = 0.77 beat 364 small ones on 512 slots = 0.71,
+        // 344 vs 371 us; the previous rule "fewer than 384 big blocks -> small blocks" picked the slower one there; 6460 queries: 0.95 vs
+        // 0.93, 1120 vs 1203 us); a tie goes to the small blocks (3260 queries: 644 vs 684 us), long launches to the big ones.
+        static int cus = 0;
+        if (!cus) { int d = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d); if (cus <= 0) cus = 256; }
+        const double r8 = (double)ceil_div(S, 256) * heads * batch / cus, r4 = (double)ceil_div(S, 128) * heads * batch / (2.0 * cus);
+        const double e8 = r8 / ceil(r8), e4 = r4 / ceil(r4);
+        if (r8 < 4.0 && e4 >= e8) nw = 4;
+    }
 #if VITG_PROFILING_BUILD
     if (a.ablate && tuning().attn_sp != 1) {   // profiling instantiations (fp16 only)
         if (dtype != DT_F16) return VITG_ERR_ARG;

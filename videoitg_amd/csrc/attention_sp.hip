@@ -349,7 +349,7 @@ static int launch_sp(AttnArgs a, int batch, int heads, hipStream_t s) {
 
 // called by vitg_attention (attention.hip)
 int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, hipStream_t s) {
-#define SP(T, D) (nw == 4 ? launch_sp<T, D, 4>(a, batch, heads, s) : launch_sp<T, D, 8>(a, batch, heads, s))
+#define SP(T, D) (nw == 3 ? launch_sp<T, D, 3>(a, batch, heads, s) : nw == 4 ? launch_sp<T, D, 4>(a, batch, heads, s) : launch_sp<T, D, 8>(a, batch, heads, s))
     if (dtype == DT_BF16) return head_dim == 72 ? SP(bf16_t, 72) : SP(bf16_t, 128);
     return head_dim == 72 ? SP(f16_t, 72) : SP(f16_t, 128);
 #undef SP
