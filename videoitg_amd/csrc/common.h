@@ -72,9 +72,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- activations -------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2u)
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    // v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division (~10 VALU): this runs on 64 values per lane in the fc1 epilogue
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390081777927f * u));
+    // exponent argument -2 log2(e) sqrt(2/pi) (x + 0.044715 x^3) with the constants folded: x * (B + A x^2) = mul, fma, mul (it was
+    // five dependent multiplies); v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division (~10 VALU).  This runs on 128-192 values per
+    // lane in the fc1 epilogue, where it costs 14 % of that GEMM (tools/gemm_cfg_sweep.py).
+    const float a = x * __builtin_fmaf(x * x, -0.10294324302f, -2.30220819814f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
