@@ -120,6 +120,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
         constexpr int CH = NT * 8;                        // 16-B chunks (4 floats) per row
         constexpr int RB = NT * 128;                      // row bytes
         constexpr int SWZ = (CH & -CH) - 1;               // XOR mask: largest power of two dividing CH, minus 1 (NT = 3: 24 chunks -> 7).
+        // a 16-B write is served 16 lanes (rows) at a time against 16 slots per cycle: RB = 256 puts every row on the same slots (swizzle
+        // by row & 15); RB = 384 alternates by row parity, so the swizzle takes the next three row bits (rows r and r + 8 collided before)
+        auto swz = [](int row) { return RB % 256 == 0 ? (row & SWZ) : ((row >> 1) & SWZ); };
                                                           // (Padding the row instead, as the 16-bit path does, costs registers here:
                                                           // the 256x384 fp32 kernel went from 19 to 256 spills.)
 #pragma unroll
@@ -141,14 +144,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
                     }
                     const int c = nt * 8 + q4 * 2 + fh;
-                    *(f32x4*)(stage + frow * RB + ((c ^ (frow & SWZ)) << 4)) = v;
+                    *(f32x4*)(stage + frow * RB + ((c ^ swz(frow)) << 4)) = v;
                 }
             // same wave reads back what it wrote: LDS ops of one wave complete in order, no barrier needed
 #pragma unroll
             for (int i = 0; i < 32 * CH / 64; ++i) {
                 const int idx = i * 64 + lane;
                 const int row = idx / CH, c = idx % CH;
-                f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ (row & SWZ)) << 4));
+                f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4));
                 const int m = m_base + (mt - MT0) * 32 + row, n = n_base + c * 4;
                 if (m < g.M && n < g.N) {
                     if (g.res) {
@@ -167,6 +170,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
         constexpr bool POW2 = (CH & (CH - 1)) == 0;
         constexpr int RB = NTO * 64 + (POW2 ? 0 : 16);
         constexpr int SWZ = POW2 ? CH - 1 : 0;
+        // rows are RB = 64 / 128 B apart, so 4 / 2 consecutive rows fill the 256 B the LDS serves per cycle: the XOR has to take the row
+        // bits ABOVE those.  (With the low bits, as round 1 had it, the 8-B staging writes of rows r, r + 8, r + 16, r + 24 met in the
+        // same banks: 4-way conflicts on 48 writes per wave and tile; now 2-way, the minimum for 8-B writes at this row pitch.)
+        constexpr int SH = CH == 4 ? 2 : CH == 8 ? 1 : 0;
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt)
 #pragma unroll
@@ -206,7 +213,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
                     const int row = (mt - MT0) * 32 + frow, c = nt * 4 + q4;
-                    *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ (row & SWZ)) << 4) + fh * 8) = o;
+                    *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4) + fh * 8) = o;
                 }
         const int n_out = MODE == MODE_SWIGLU ? n_base / 2 : n_base;
         const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
@@ -214,7 +221,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
         for (int i = 0; i < MTN * 32 * CH / 64; ++i) {
             const int idx = i * 64 + lane;
             const int row = idx / CH, c = idx % CH;
-            const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ (row & SWZ)) << 4));
+            const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4));
             const int m = m_base + row, n = n_out + c * 8;
             if (m < g.M) {
                 // wave-uniform tile origin (64-bit, scalar) + 32-bit byte offset: saddr stores, no 64-bit VALU per row.  The non-temporal
