@@ -386,7 +386,8 @@ class SelectorEngine:
         del a0
         qkv = self._buf("vit_qkv", (M, 3 * Dv), vdt)
         o = self._buf("vit_o", (M, Dvp), vdt, zero=True)
-        f = self._buf("vit_f", (M, Fvp), vdt)
+        mx_mlp = self.fp8_mx and all(isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight) for lw in w.vit)
+        f = None if mx_mlp else self._buf("vit_f", (M, Fvp), vdt)      # (the MX path keeps the hidden activation in its own e4m3 buffer)
         scale = hd ** -0.5
         st = (P * 3 * Dv, 3 * Dv, hd)
         for li, lw in enumerate(full_layers):
@@ -484,7 +485,8 @@ class SelectorEngine:
         op = pad64(nq * hd)
         qkv = self._buf("llm_qkv", (N, qkv_n), self.dtype)
         o = self._buf("llm_o", (N, op), self.dtype, zero=True)
-        f = self._buf("llm_f", (N, Fp), self.dtype)
+        mx_mlp = self.fp8_mx and all(isinstance(lw.gu_w, Fp8Weight) and isinstance(lw.down_w, Fp8Weight) for lw in w.llm)
+        f = None if mx_mlp else self._buf("llm_f", (N, Fp), self.dtype)
         cos, sin = self.rope_tables(total)
         cos, sin = cos[pos0:pos0 + N], sin[pos0:pos0 + N]
         scale = hd ** -0.5
