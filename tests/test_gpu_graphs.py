@@ -6,13 +6,30 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def tiny_engine(dtype=torch.float16):
+def tiny_engine(dtype=torch.float16, fp8=False):
     from videoitg_amd import synth
     from videoitg_amd.config import tiny_config
     from videoitg_amd.engine import PackedWeights, SelectorEngine
     cfg = tiny_config()
     sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
-    return cfg, SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, dtype, "cuda:0"))
+    return cfg, SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, dtype, "cuda:0", fp8=fp8))
+
+
+def test_graph_replay_on_the_fp8_weight_path():
+    """configs[3] x configs[4]: the captured forward on fp8 weights (per-token quantisers, MX block-scaled MLP hand-over) replays bit for bit
+    what the eager fp8 forward computes, for every prompt length of the bucket"""
+    from videoitg_amd import synth
+    from videoitg_amd.engine import GraphCache
+    cfg, eng = tiny_engine(fp8=True)
+    assert eng.fp8_mx
+    cache = GraphCache(eng, bucket=32)
+    pix = synth.synth_pixel_values(8, cfg.vision.image_size, seed=5).half().cuda()
+    for L in (7, 32, 19):
+        ids = torch.cat([torch.tensor([-200]), synth.synth_prompt_ids(L, cfg.vocab_size, seed=L)])
+        want = eng.forward(ids.unsqueeze(0), None, [pix])[0].view(-1).clone()
+        got = cache(ids, pix)
+        assert torch.isfinite(got).all() and torch.equal(got, want), (L, (got - want).abs().max().item())
+    assert cache.captures == 1
 
 
 def test_one_capture_serves_every_prompt_length_of_its_bucket():
