@@ -10,6 +10,7 @@ frame indices, ascending.  `--video synthetic` replaces the decoder (decord/PyAV
 random frames so the whole entry point can run offline.
 """
 import argparse
+import os
 
 import numpy as np
 import torch
@@ -34,6 +35,23 @@ def read_video(path, num_frm=512, target_fps=2):
     return frames, idx, round(total / fps)
 
 
+def frame_at(video_path, frame_idx):
+    """one decoded frame (uint8 HWC) by its ORIGINAL frame index - what infer.py:88-89 does with decord's vr[frame_idx]"""
+    if video_path == "synthetic":
+        return np.random.default_rng(1234 + int(frame_idx)).integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    from decord import VideoReader, cpu                 # not in this image; same ImportError the reference raises
+    return VideoReader(video_path, ctx=cpu(0), num_threads=4)[frame_idx].asnumpy()
+
+
+def save_selected_frames(video_path, selected_indices, save_dir="./vis"):
+    """infer.py:81-94: the selected frames as JPEGs named frame_<rank>_idx<original index>.jpg"""
+    from PIL import Image
+    os.makedirs(save_dir, exist_ok=True)
+    for i, frame_idx in enumerate(selected_indices):
+        Image.fromarray(frame_at(video_path, frame_idx)).save(os.path.join(save_dir, f"frame_{i:03d}_idx{frame_idx}.jpg"), "JPEG")
+    print(f"saved {len(selected_indices)} frames to {save_dir}")
+
+
 def topk_selection(model, tokenizer, image_processor, prompt, video_path, num_topk, dtype, num_frm=512):
     video, frame_idx, _ = read_video(video_path, num_frm=num_frm, target_fps=2)                   # infer.py:54
     video_tensor = image_processor.preprocess(video, return_tensors="pt")["pixel_values"].to(dtype).to(DEVICE)
@@ -56,6 +74,7 @@ def main():
                                         "Knight; D. Oppenheimer; E. Dune \n Please respond with only the letter of the correct answer.")
     ap.add_argument("--topk", type=int, default=32)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--save-dir", default="./vis", help="where the selected frames are written as JPEGs (infer.py:81-94); '' = do not save")
     ap.add_argument("--num-frames", type=int, default=0, help="frames to sample (reference: 512; default 32 for synthetic:tiny, whose "
                                                               "72-token visual budget pools 512 frames down to nothing)")
     a = ap.parse_args()
@@ -65,6 +84,8 @@ def main():
     model.eval().to(DEVICE)
     selected, _ = topk_selection(model, tok, proc, a.prompt, a.video, min(a.topk, num_frm), dtype, num_frm)
     print(selected)
+    if a.save_dir:
+        save_selected_frames(a.video, selected, save_dir=a.save_dir)
 
 
 if __name__ == "__main__":

@@ -278,8 +278,12 @@ def qwen2_stack(x: torch.Tensor, sd: SD, *, num_layers: int, num_heads: int, num
 # ----------------------------------------------------------------------------------------------
 def score_head(hidden: torch.Tensor, token_types: torch.Tensor, frames_per_video: Sequence[int], sd: SD
                ) -> List[torch.Tensor]:
+    """One [T,1] tensor per SAMPLE b, with T = images[b].shape[0] (grounding_qwen2.py:149-156 indexes `images` by the batch row, not by
+    the <image> occurrence): a sample with several <image> tokens pools ALL its visual rows in images[b].shape[0] equal groups, and a
+    sample without any gives the mean over an empty group = NaN (tests/golden/helpers.json "forward_errors")."""
     out = []
-    for b, T in enumerate(frames_per_video):
+    for b in range(hidden.shape[0]):
+        T = frames_per_video[b]
         h = hidden[b][token_types[b] == 3].reshape(T, -1, hidden.shape[-1]).mean(1)
         out.append(F.linear(h, sd["out_proj.weight"], sd["out_proj.bias"]))
     return out

@@ -141,6 +141,20 @@ CASES = {
     # image side not a multiple of the patch (62 = 4*14 + 6, like SigLIP-so400m's 384 = 27*14 + 6): the stride-14 VALID
     # convolution ignores the last 6 rows / columns
     "ragged_image": dict(cfg=dict(vision_token_num=72, vision=dict(image_size=62)), T=[7], ids=[[-200, 5, 6, 7, 8]]),
+    # ONE sample with TWO <image> tokens (eagle_archv1.py:296-337): it consumes two entries of `images`, text sits between the
+    # visual blocks, and the head (grounding_qwen2.py:153) reshapes ALL its visual rows by images[b].shape[0] = the FIRST clip's
+    # frame count - so with two clips of 6 frames each logit pools two consecutive frames' tokens
+    "two_images": dict(cfg=dict(vision_token_num=72), T=[6, 6], ids=[[11, -200, 5, 6, -200, 7, 8]], samples=1),
+    # the same with clips of different length: each is pooled with ITS OWN grid (4 frames -> 4x4, 8 frames -> 3x3: 64 + 72 rows), the
+    # head's groups of 136 / 4 = 34 rows straddle frames and clips
+    "two_images_ragged": dict(cfg=dict(vision_token_num=72), T=[4, 8], ids=[[-200, 5, 6, -200, 7]], samples=1),
+}
+# degenerate inputs (recorded in helpers.json["forward_errors"]: exception type, or shape / all-NaN flag of the logits): a sample
+# without <image> still consumes an entry of `images` (eagle_archv1.py:282-294) and then has no visual rows - the head's mean over
+# an empty [T, 0, D] view gives NaN logits; visual rows that do not divide by images[b].shape[0] fail the head's reshape
+ERROR_CASES = {
+    "imageless": dict(cfg=dict(vision_token_num=72), T=[4], ids=[[5, 6, 7, 8]]),
+    "two_images_bad_split": dict(cfg=dict(vision_token_num=72), T=[5, 8], ids=[[-200, 5, 6, -200, 7]]),    # 5*9 + 8*9 = 117 rows, 117 % 5 != 0
 }
 
 
@@ -183,9 +197,31 @@ def run_case(g, ce, name, spec, seed=0):
     print(name, "N=", emb.shape[1], "logits0[:4]=", out.logits[0].view(-1)[:4].tolist())
 
 
-def helper_known_answers():
+def forward_errors(g, ce):
+    out = {}
+    for name, spec in ERROR_CASES.items():
+        cfg = tiny_config(**spec["cfg"])
+        torch.manual_seed(0)
+        m = build_reference_model(g, ce, cfg)
+        load_synth(m, cfg, 0)
+        images = [synth.synth_pixel_values(T, cfg.vision.image_size, seed=1234 + i) for i, T in enumerate(spec["T"])]
+        ids = torch.tensor(spec["ids"], dtype=torch.long)
+        try:
+            with torch.inference_mode():
+                o = m(ids, attention_mask=torch.ones_like(ids).bool(), images=images)
+            out[name] = {"T": spec["T"], "ids": spec["ids"], "cfg": spec["cfg"], "error": None,
+                         "logits_shapes": [list(l.shape) for l in o.logits], "logits_all_nan": bool(all(l.isnan().all() for l in o.logits))}
+        except Exception as e:
+            out[name] = {"T": spec["T"], "ids": spec["ids"], "cfg": spec["cfg"], "error": type(e).__name__}
+        print("forward error case", name, "->", out[name]["error"])
+    return out
+
+
+def helper_known_answers(g=None, ce=None):
     mm = importlib.import_module("eagle.mm_utils")
     ka = {"get_frame_indices": [], "tokenizer_image_token": [], "get_model_name_from_path": [], "get_seq_frames": []}
+    if g is not None:
+        ka["forward_errors"] = forward_errors(g, ce)
     for args in [(3000, 30.0, 2, 512), (18000, 29.97, 2, 512), (7200, 24.0, 2, 64), (500, 25.0, 2, 512),
                  (123456, 59.94, 1, 512), (10, 30.0, 2, 512), (1024, 1.0, 2, 512), (999, 23.976, 2, 16),
                  (2500, 25.0, 2, 512), (1537, 30.0, 2, 512)]:
@@ -236,7 +272,7 @@ def main():
         if name == "helpers":
             continue
         run_case(g, ce, name, CASES[name])
-    helper_known_answers()
+    helper_known_answers(g, ce)
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image"]
+CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image", "two_images", "two_images_ragged"]
 SCORE_TOL = 1e-3
 
 
@@ -46,7 +46,7 @@ def test_forward_matches_reference_golden(golden_dir, name, dtype):
     z, got, T = run_case(golden_dir, name, dtype)
     tol = GOLDEN_TOL[dtype].get(name, GOLDEN_TOL_DEFAULT[dtype])
     worst = 0.0
-    for b in range(len(T)):
+    for b in range(len(got)):                     # one logits tensor per SAMPLE (a sample may hold several <image> tokens)
         ref = torch.from_numpy(z[f"logits{b}"])
         assert got[b].shape == ref.shape == (T[b], 1)
         assert torch.isfinite(got[b]).all()
@@ -63,7 +63,7 @@ def test_topk_index_sets_match_reference(golden_dir, name):
     from videoitg_amd import ops
     z, got, T = run_case(golden_dir, name, torch.float16)
     checked = 0
-    for b in range(len(T)):
+    for b in range(len(got)):                     # one logits tensor per SAMPLE (a sample may hold several <image> tokens)
         ref = torch.sigmoid(torch.from_numpy(z[f"logits{b}"]).view(-1))
         sref, oref = torch.sort(ref, descending=True, stable=True)
         _, order = ops.rank(got[b].view(-1).cuda())
@@ -103,7 +103,7 @@ def test_attention_loop_structures_agree(golden_dir, name):
             z, got, T = run_case(golden_dir, name, torch.float16, variant=0)
         finally:
             ops.set_option("attn_sp", 0)
-        for bi in range(len(T)):
+        for bi in range(len(got)):
             ref = torch.from_numpy(z[f"logits{bi}"])
             assert (torch.sigmoid(got[bi]) - torch.sigmoid(ref)).abs().max().item() <= tol, (sp, name)
         outs.append(got)
@@ -397,3 +397,48 @@ def test_graph_captured_forward_replays_bit_identically(golden_dir):
         gf(torch.tensor([[11, -200, 5, 6, 7, 8]]), pix0)                 # <image> moved
     with pytest.raises(ValueError):
         gf(ids0, pix0[:6])                                               # fewer frames
+
+
+def test_degenerate_samples_as_the_reference(golden_dir):
+    """A sample without <image> -> NaN logits of shape [images[b].shape[0], 1]; visual rows that do not divide by images[b].shape[0]
+    -> RuntimeError: what the reference itself does (tests/golden/helpers.json "forward_errors", recorded by running it)."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    ka = json.load(open(os.path.join(golden_dir, "helpers.json")))["forward_errors"]
+    for name, rec in ka.items():
+        cfg = tiny_config(**rec["cfg"])
+        sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+        eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+        images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i).cuda() for i, t in enumerate(rec["T"])]
+        ids = torch.tensor(rec["ids"])
+        if rec["error"]:
+            with pytest.raises(RuntimeError):
+                eng.forward(ids, None, images)
+        else:
+            lg = eng.forward(ids, None, images)
+            assert [list(l.shape) for l in lg] == rec["logits_shapes"]
+            assert all(bool(l.isnan().all()) for l in lg) == rec["logits_all_nan"]
+
+
+def test_mixed_batch_of_single_and_double_image_samples_equals_the_oracle(golden_dir):
+    """B = 2: sample 0 holds two <image> tokens (clips 0 and 1), sample 1 one (clip 2); the head of sample b reshapes by images[b].shape[0]
+    (the reference's indexing, grounding_qwen2.py:153).  Compared with the oracle, which is pinned to the reference on the two-image
+    fixtures."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    from oracle import videoitg_oracle as O
+    cfg = tiny_config(vision_token_num=72)
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    T = [6, 6, 8]
+    images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=4321 + i) for i, t in enumerate(T)]
+    ids = torch.tensor([[11, -200, 5, 6, -200, 7, 8], [-200, 30, 31, 32, 0, 0, 0]])
+    mask = torch.tensor([[1] * 7, [1, 1, 1, 1, 0, 0, 0]]).bool()
+    want = O.forward(cfg, sd, vsd, ids, mask, images)
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    got = eng.forward(ids, mask, [im.cuda() for im in images])
+    assert len(got) == len(want) == 2
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        assert (torch.sigmoid(g.float().cpu()) - torch.sigmoid(w)).abs().max().item() <= SCORE_TOL

@@ -21,19 +21,25 @@ def ops():
     return o
 
 
-@pytest.fixture(params=["auto", "tile128", "cfg2_256x128x32", "cfg6_phased", "cfg9_256x384", "cfg10_384x256"])
+@pytest.fixture(params=["auto", "tile128", "cfg2_256x128x32", "cfg6_phased", "cfg9_256x384", "cfg10_384x256",
+                        "cfg6_mi16", "cfg9_256x384_mi16", "cfg10_384x256_mi16", "cfg6_mi32", "cfg9_256x384_mi32", "cfg10_384x256_mi32"])
 def gemm_cfg(request, ops):
     """Every SHIPPED GEMM kernel configuration is forced in turn (vitg_set_option), so the 256-tile kernels are covered at test
     sizes too (auto mode would pick the 128 tile for them); tile128 doubles as the cross-check set.  The research
     configurations of round 1 live in the profiling library and are not part of the product test matrix."""
     name = request.param
-    tile, cfg = {"auto": (0, 0), "tile128": (128, 0), "cfg2_256x128x32": (256, 2), "cfg6_phased": (256, 6), "cfg9_256x384": (256, 9),
-                 "cfg10_384x256": (256, 10)}[name]
+    # (the three wide tile shapes exist on both MFMA shapes: gemm_mi 16 = v_mfma_f32_16x16x32, gemm_mi16.hip; 32 = v_mfma_f32_32x32x16,
+    # gemm256.hip; 0 = the default)
+    tile, cfg, mi = {"auto": (0, 0, 0), "tile128": (128, 0, 0), "cfg2_256x128x32": (256, 2, 0), "cfg6_phased": (256, 6, 0), "cfg9_256x384": (256, 9, 0),
+                     "cfg10_384x256": (256, 10, 0), "cfg6_mi16": (256, 6, 16), "cfg9_256x384_mi16": (256, 9, 16), "cfg10_384x256_mi16": (256, 10, 16),
+                     "cfg6_mi32": (256, 6, 32), "cfg9_256x384_mi32": (256, 9, 32), "cfg10_384x256_mi32": (256, 10, 32)}[name]
     ops.set_option("gemm_tile", tile)
     ops.set_option("gemm_cfg", cfg)
+    ops.set_option("gemm_mi", mi)
     yield name
     ops.set_option("gemm_tile", 0)
     ops.set_option("gemm_cfg", 0)
+    ops.set_option("gemm_mi", 0)
 
 
 @pytest.fixture(params=[(0, 0, 0, 0, 0), (4, 0, 2, 2, 2), (8, 0, 2, 2, 2), (4, 1, 2, 2, 2), (4, 0, 1, 2, 2), (8, 0, 1, 2, 2), (4, 0, 0, 1, 2), (8, 0, 0, 1, 2),
@@ -298,9 +304,10 @@ def test_mfma_probe_runs_and_zero_operands_are_not_slower(ops):
     assert 500.0 < r <= z * 1.05 and z < 2700.0, (z, r)
 
 
+@pytest.mark.parametrize("mi", [16, 32])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [6, 9, 10])
-def test_gemm_software_tile_loop_bit_identical(ops, dtype, cfg):
+def test_gemm_software_tile_loop_bit_identical(ops, dtype, cfg, mi):
     """one block per CU walking the tile list (default) vs one hardware block per tile (gemm_flags bit24) - same bits, all three epilogues"""
     M, N, K = 40000, 1152, 640                                                  # 157 x 5 (x 3 for the 384-wide tile) >= 2 tiles per CU
     a, w, b = rnd((M, K), 51, dtype=dtype).to(dtype).cuda(), rnd((N, K), 52, K ** -0.5, dtype=dtype).to(dtype).cuda(), rnd((N,), 53, 0.1, torch.float32).cuda()
@@ -310,6 +317,7 @@ def test_gemm_software_tile_loop_bit_identical(ops, dtype, cfg):
     for flags in (0, 1 << 24):
         ops.set_option("gemm_cfg", cfg)
         ops.set_option("gemm_flags", flags)
+        ops.set_option("gemm_mi", mi)
         try:
             o16 = ops.gemm(a, w, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=ops.ACT_GELU_TANH)
             o32 = x.clone()
@@ -319,6 +327,7 @@ def test_gemm_software_tile_loop_bit_identical(ops, dtype, cfg):
         finally:
             ops.set_option("gemm_cfg", 0)
             ops.set_option("gemm_flags", 0)
+            ops.set_option("gemm_mi", 0)
     for got, ref in zip(res[1 << 24], res[0]):
         assert torch.isfinite(got.float()).all() and torch.equal(got, ref)
 

@@ -11,7 +11,7 @@ from oracle import videoitg_oracle as O
 from videoitg_amd import synth
 from videoitg_amd.config import ITGConfig
 
-CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image"]
+CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image", "two_images", "two_images_ragged"]
 TOL = 2e-5
 
 
@@ -50,10 +50,30 @@ def test_oracle_matches_reference(golden_dir, name):
     assert abs(im["layers"][0].double().abs().sum().item() - ls[1][1]) < 2e-6 * ls[1][1]
     assert abs(im["final"].double().abs().sum().item() - ls[-1][1]) < 2e-6 * ls[-1][1]
     # A12: logits
-    for b in range(len(T)):
+    assert len(logits) == ids.shape[0]                     # one logits tensor per SAMPLE (a sample may hold several <image> tokens)
+    for b in range(ids.shape[0]):
         ref = torch.from_numpy(z[f"logits{b}"])
         assert logits[b].shape == ref.shape == (T[b], 1)
         assert (logits[b] - ref).abs().max() < TOL
+
+
+def test_oracle_degenerate_samples_as_the_reference(golden_dir):
+    """helpers.json "forward_errors": what the reference does with a sample without <image> (NaN logits of shape [T,1]) and with
+    visual rows that do not divide by images[b].shape[0] (RuntimeError from the head's reshape)."""
+    from videoitg_amd.config import tiny_config
+    ka = json.load(open(os.path.join(golden_dir, "helpers.json")))["forward_errors"]
+    for name, rec in ka.items():
+        cfg = tiny_config(**rec["cfg"])
+        sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+        images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i) for i, t in enumerate(rec["T"])]
+        ids = torch.tensor(rec["ids"])
+        if rec["error"]:
+            with pytest.raises(RuntimeError):
+                O.forward(cfg, sd, vsd, ids, None, images)
+        else:
+            lg = O.forward(cfg, sd, vsd, ids, None, images)
+            assert [list(l.shape) for l in lg] == rec["logits_shapes"]
+            assert all(l.isnan().all() for l in lg) == rec["logits_all_nan"]
 
 
 def test_padded_batch_equals_single(golden_dir):

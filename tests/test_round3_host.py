@@ -1,0 +1,58 @@
+"""Host-side pieces added in round 3 (no GPU)."""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _infer():
+    spec = importlib.util.spec_from_file_location("vitg_infer", os.path.join(ROOT, "infer.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_save_selected_frames_names_and_count(tmp_path):
+    """infer.py:81-94 of the reference: frame_<rank>_idx<original index>.jpg, one JPEG per selected frame"""
+    from PIL import Image
+    m = _infer()
+    sel = [3, 40, 41, 977]
+    m.save_selected_frames("synthetic", sel, save_dir=str(tmp_path / "vis"))
+    names = sorted(os.listdir(tmp_path / "vis"))
+    assert names == [f"frame_{i:03d}_idx{f}.jpg" for i, f in enumerate(sel)]
+    im = Image.open(tmp_path / "vis" / names[0])
+    assert im.format == "JPEG" and im.size == (160, 120)
+
+
+def test_fp8_selector_is_normalised():
+    from videoitg_amd.engine import normalise_fp8
+    import numpy as np
+    assert normalise_fp8(True) is True and normalise_fp8(1) is True and normalise_fp8(np.bool_(True)) is True
+    assert normalise_fp8(False) is False and normalise_fp8(0) is False and normalise_fp8(None) is False
+    assert normalise_fp8("vit") == "vit" and normalise_fp8("llm") == "llm"
+    for bad in ("both", "tower", 1.5, [1]):
+        with pytest.raises(ValueError):
+            normalise_fp8(bad)
+
+
+def test_graph_cache_serves_only_what_a_capture_can(monkeypatch):
+    """a prompt whose 32-token bucket passes tokenizer_model_max_length, or a prompt with no / two <image> tokens, must go to
+    the eager forward instead of raising out of the graph cache"""
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import GraphCache
+
+    class Eng:                                   # layout decisions need the config only
+        cfg = tiny_config(vision_token_num=72, tokenizer_model_max_length=100)
+    gc = GraphCache.__new__(GraphCache)
+    gc.eng, gc.bucket = Eng(), 32
+    pix = torch.zeros(8, 3, 56, 56)              # 8 frames, 4x4 grid pooled to 3x3: 72 visual tokens
+    assert not gc.serves(torch.tensor([-200, 5, 6, 7]), pix)                   # 72 visual + one 32-token bucket = 104 > 100 -> eager forward
+    Eng.cfg = tiny_config(vision_token_num=72, tokenizer_model_max_length=104)
+    assert gc.serves(torch.tensor([-200, 5, 6, 7]), pix)
+    Eng.cfg = tiny_config(vision_token_num=72, tokenizer_model_max_length=None)
+    assert gc.serves(torch.tensor([-200, 5, 6, 7]), pix)
+    assert not gc.serves(torch.tensor([5, 6, 7]), pix)
+    assert not gc.serves(torch.tensor([-200, 5, -200, 7]), pix)

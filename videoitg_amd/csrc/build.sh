@@ -6,7 +6,7 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS="device gemm gemm256 gemm_fp8 attention attention_sp attention_ab elementwise preprocess probe"
+SRCS="device gemm gemm256 gemm_mi16 gemm_fp8 attention attention_sp attention_ab elementwise preprocess probe"
 OUT="$HERE/../libvideoitg_hip.so"
 OBJ="$HERE/build"
 DEFS=""

@@ -565,6 +565,24 @@ __global__ __launch_bounds__(G2_THREADS, (BN >= 256 ? 2 : 4)) void gemm256_kerne
         }
     }
     stamp(29);
+    if constexpr (PROF) {
+        // gemm_flags bit26 (A/B): keep the blocks of an XCD in the same ROUND of the tile list.  The 32 blocks of an XCD work on a
+        // compact group_m x (32 / group_m) super-tile and share its operand panels through the 4 MiB L2 only while they are within a
+        // few K-tiles of each other; free-running they drift apart and the same panel is fetched again and again (fc1: 8.6x its
+        // operand bytes through L2 misses, profiles/r02_pmc_traffic_v9_fp16.md).  Timing only - no data is handed over, so relaxed
+        // atomics without fences; the spin is bounded, so a block that is not co-resident can never hang the others.
+        if ((g.flags & 0x4000000) && g.xcd_sync) {
+            const int round_ = (vb - (int)blockIdx.x) / (int)gridDim.x;
+            const int full_rounds = nwg_ / (int)gridDim.x;
+            if (round_ + 1 < full_rounds && threadIdx.x == 0) {
+                unsigned* c = g.xcd_sync + (blockIdx.x & 7) * 32;
+                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned target = (unsigned)((gridDim.x >> 3) * (round_ + 1));
+                for (int spin = 0; spin < 4096 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
     if (vb + (int)gridDim.x < nwg_) {                    // another tile follows: every wave is done with the ring / its staging region
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -829,6 +847,14 @@ static int launch256(GemmArgs g, hipStream_t s) {
     // 1 = estimate the tile period, > 1 = tile period in ns): de-phase the tile groups of the fp32-residual shapes
     const int stag = tuning().gemm_stagger;
     g.stagger_ns = (MODE == MODE_F32 && loop && splits == 1 && stag > 0) ? (stag > 1 ? stag : (g.K / 64) * 2400 + 40000) : 0;
+#if VITG_PROFILING_BUILD
+    g.xcd_sync = nullptr;
+    if ((g.flags & 0x4000000) && loop && splits == 1 && (cus & 7) == 0) {
+        static unsigned* sync_buf = nullptr;
+        if (!sync_buf) (void)hipMalloc((void**)&sync_buf, 8 * 32 * sizeof(unsigned));
+        if (sync_buf) { (void)hipMemsetAsync(sync_buf, 0, 8 * 32 * sizeof(unsigned), s); g.xcd_sync = sync_buf; }
+    }
+#endif
     hipLaunchKernelGGL((gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM, NRM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
@@ -886,6 +912,8 @@ static int choose_cfg(const GemmArgs& g, int mode) {
     return cfg;
 }
 
+static bool gemm_mi16_selected() { return tuning().gemm_mi == 16; }
+
 template <typename T, int MODE, bool NRM = false>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
     int cfg = tuning().gemm_cfg;
@@ -897,6 +925,10 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
         return launch256<T, MODE, 256, 2, 2, 64, false, 1, G2_BM, true>(g, s);
     }
     if (MODE == MODE_F32 && g.split_k > 1) cfg = 6;           // split-K partials: 256x256 tiles (the plan of vitg_gemm_splitk_plan assumes them)
+    // MFMA shape (round 3): the three shipped tile shapes exist on v_mfma_f32_16x16x32 as well (gemm_mi16.hip), which the package power
+    // cap lets run 14 % faster than 32x32x16 on real operands (profiles/r03_mfma_shape.md)
+    if ((cfg == 6 || cfg == 9 || cfg == 10) && gemm_mi16_selected())
+        return launch_gemm_mi16(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, cfg, s);
 #if VITG_PROFILING_BUILD
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
 #endif

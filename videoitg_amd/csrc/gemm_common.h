@@ -35,6 +35,7 @@ struct GemmArgs {
     int nrm_P;                // producer: partials per row = N / (columns per wave block), set by the host entry
     const float* nrm_stats;   // consumer: [M][2] (mean, rstd)
     const float* nrm_colsum;  // consumer: s[n] = sum_k gamma[k] W[n,k] (LayerNorm) or null (RMSNorm: no mean term)
+    unsigned* xcd_sync;       // profiling build, gemm_flags bit26: 8 per-XCD arrival counters (128 B apart), zeroed before the launch
     int split_k;              // MODE_F32 only: gridDim.y = split_k blocks share one output tile, block y accumulates its K range and
     long split_stride;        // writes the raw fp32 partial tile to out + y * split_stride floats (vitg_gemm_splitk reduces them)
 };
@@ -54,6 +55,17 @@ __device__ __forceinline__ void block_to_tile(int bid, int tiles_m, int tiles_n,
     const int in_g = bid - grp * per_group;
     tm = first_m + in_g % gsz;
     tn = in_g / gsz;
+}
+
+// 16-B output store with a cache policy (profiling build A/B, gemm_flags bits 22/23): wave-uniform 64-bit base + 32-bit lane byte offset.
+//   0 plain (the line stays in the XCD's L2) | 1 sc1 (write-through, the L2 drops the line) | 2 nt | 3 sc0 sc1
+// An output tile is never read again by the launch that writes it, so every line it leaves in the L2 displaces operand panels the
+// other blocks of the XCD are about to fetch (MI355X_MICROARCH.md "stores of each flavour").
+__device__ __forceinline__ void store16_policy(char* base, unsigned off, u32x4 v, int pol) {
+    if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else if (pol == 3) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+    else *(u32x4*)(base + off) = v;
 }
 
 // Epilogue for one 32x32 accumulator pair position: lane holds C[m][n .. n+3] (4 consecutive output features of one
@@ -160,7 +172,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                     }
                     // wave-uniform tile origin (64-bit, scalar) + 32-bit in-tile offset: saddr store, no 64-bit VALU per row
                     char* const ob = (char*)((float*)g.out + (size_t)m_base * g.ldo + n_base);
-                    *(f32x4*)(ob + (unsigned)(((mt - MT0) * 32 + row) * g.ldo + c * 4) * 4u) = v;
+                    const unsigned boff_ = (unsigned)(((mt - MT0) * 32 + row) * g.ldo + c * 4) * 4u;
+                    if (VITG_PROFILING_BUILD && (g.flags & 0xC00000)) {
+                        u32x4 vv; __builtin_memcpy(&vv, &v, 16);
+                        store16_policy(ob, boff_, vv, (g.flags >> 22) & 3);
+                    } else *(f32x4*)(ob + boff_) = v;
                 }
             }
         }
@@ -231,6 +247,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                 if (VITG_PROFILING_BUILD && (g.flags & 2)) continue;
                 if (n + 8 <= n_lim) {
                     if (VITG_PROFILING_BUILD && (g.flags & 1)) __builtin_nontemporal_store(v, (u32x4*)(ob + boff));
+                    else if (VITG_PROFILING_BUILD && (g.flags & 0xC00000)) store16_policy(ob, boff, v, (g.flags >> 22) & 3);
                     else *(u32x4*)(ob + boff) = v;
                 } else if (n + 4 <= n_lim) *(u32x2*)(ob + boff) = u32x2{v[0], v[1]};
             }
@@ -241,6 +258,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s);   // gemm256.hip
 bool gemm256_applicable(const GemmArgs& g, int mode);
 int gemm256_norm_cols(const GemmArgs& g);                                       // gemm256.hip
+int launch_gemm_mi16(const GemmArgs& g, int dtype, int mode, int cfg, hipStream_t s);   // gemm_mi16.hip: the same tiles on v_mfma_f32_16x16x32
 int launch_gemm_w4(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_w4.hip
 bool gemm_w4_applicable(const GemmArgs& g, int mode);
 int launch_gemm_wf(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_wf.hip

@@ -52,6 +52,26 @@ class Fp8Weight:
         return Fp8Weight(self.w8[rows], self.sw[rows])
 
 
+def _fuse_norm_enabled() -> bool:
+    from . import _lib as _l
+    return _l.PROFILING and os.environ.get("VITG_FUSE_NORM", "0") not in ("", "0")
+
+
+def normalise_fp8(v) -> object:
+    """fp8 weight-path selector -> False | True | "vit" | "llm".  Truthy non-bool values (1, numpy.bool_, an env-parsed int) mean True,
+    falsy ones False; any other string or type is an error - a caller that believes it is on the fp8 tier must not silently get 16-bit
+    weights."""
+    if isinstance(v, str):
+        if v in ("vit", "llm"):
+            return v
+        raise ValueError(f"fp8 must be a bool, 'vit' or 'llm', not {v!r}")
+    if v is None:
+        return False
+    if isinstance(v, (bool, int)) or type(v).__name__ in ("bool_", "bool"):
+        return bool(v)
+    raise ValueError(f"fp8 must be a bool, 'vit' or 'llm', not {v!r}")
+
+
 @dataclass
 class VitLayerW:
     # fused-norm consumers (16-bit path): s[n] = sum_k gamma[k] W[n,k] and c = W beta + bias of the GEMM behind each LayerNorm
@@ -98,6 +118,7 @@ class PackedWeights:
 
     # ---- packing ---------------------------------------------------------------------------------
     def __post_init__(self):
+        self.fp8 = normalise_fp8(self.fp8)
         if self.vit_dtype is None:
             self.vit_dtype = self.dtype
         self._packing = self.dtype                  # type the _w16 / _wl helpers currently emit (switched while the tower is packed)
@@ -114,7 +135,7 @@ class PackedWeights:
         (quantised from the SAME 16-bit-rounded, zero-padded matrix the 16-bit path would multiply with)"""
         w16 = self._w16(w, rows)
         part = "vit" if self._packing_part == "vit" else "llm"
-        if not (self.fp8 is True or self.fp8 == part):
+        if not (self.fp8 is True or self.fp8 == part):          # (normalised in __post_init__: False | True | "vit" | "llm")
             return w16
         w8, sw = K.quant_rows_fp8(w16, w16.shape[1], torch.empty((w16.shape[0], K.pad128(w16.shape[1])), dtype=torch.uint8, device=self.device),
                                   torch.empty(w16.shape[0], dtype=torch.float32, device=self.device))
@@ -149,9 +170,11 @@ class PackedWeights:
             fc2_w=self._wl(vsd[p + "mlp.fc2.weight"]), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
         ))
         self._packing, self._packing_part = self.dtype, "llm"
-        lw = self.vit[-1]
-        if not isinstance(lw.qkv_w, Fp8Weight):
-            # load-time constants of the fused LayerNorm consumers, from the 16-bit-rounded weights the MFMA will see
+        if _fuse_norm_enabled() and not isinstance(self.vit[-1].qkv_w, Fp8Weight):
+            # load-time constants of the fused LayerNorm consumers (profiling library + VITG_FUSE_NORM=1 only: the fused kernels measured
+            # 4 % slower than the stand-alone norm, profiles/r02_fused_norm.md, and are not in the product library), from the
+            # 16-bit-rounded weights the MFMA will see
+            lw = self.vit[-1]
             Dv = v.hidden_size
             for wname, bname, gam, bet, cs, cc in (("qkv_w", "qkv_b", lw.ln1_w, lw.ln1_b, "qkv_cs", "qkv_c"),
                                                   ("fc1_w", "fc1_b", lw.ln2_w, lw.ln2_b, "fc1_cs", "fc1_c")):
@@ -191,7 +214,7 @@ class PackedWeights:
         ))
 
     @staticmethod
-    def from_state_dicts(cfg: ITGConfig, sd: SD, vsd: SD, dtype: torch.dtype, device, fp8: bool = False,
+    def from_state_dicts(cfg: ITGConfig, sd: SD, vsd: SD, dtype: torch.dtype, device, fp8: "bool | str" = False,
                          vit_dtype: Optional[torch.dtype] = None) -> "PackedWeights":
         pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device(device), fp8=fp8, vit_dtype=vit_dtype)
         pw.pack_vision_embeddings(vsd)
@@ -229,8 +252,8 @@ class SelectorEngine:
         self.skip_dead_rows = True        # last tower layer only on the tokens the pool reads (see vit_forward)
         # LayerNorm / RMSNorm folded into the GEMMs around them (vitg_gemm_norm_*).  Measured 4 % SLOWER on the step than the stand-alone
         # norm kernels (profiles/r02_fused_norm.md), so the kernels live in the profiling library and this switch only exists there.
-        from . import _lib as _l
-        self.fuse_norm = _l.PROFILING and os.environ.get("VITG_FUSE_NORM", "0") not in ("", "0")
+        # (never together with fp8 layer weights - the fused consumers only exist for 16-bit operands)
+        self.fuse_norm = _fuse_norm_enabled() and weights.fp8 is False
         # fp8 tower: fc1 (+ GELU) hands its output to fc2 as e4m3 + MX block scales straight from its epilogue (vitg_gemm_fp8_mx) instead
         # of 16 bits + a stand-alone per-token quantiser pass; VITG_FP8_MX=0 keeps the per-token form (A/B, tests)
         self.fp8_mx = os.environ.get("VITG_FP8_MX", "1") not in ("", "0")
@@ -535,71 +558,110 @@ class SelectorEngine:
     # ---- whole path for one sample whose frames are already encoded ---------------------------------
     def score_video(self, feats: torch.Tensor, T: int, G: int, ids: torch.Tensor, cmap: Optional[torch.Tensor] = None,
                     pc: int = 0, ids_dev: Optional[torch.Tensor] = None, kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """feats fp32 [T*P, Dv] (this video's rows), ids HOST int64 [L] (unpadded, one IMAGE_TOKEN_INDEX) ->
+        """feats fp32 [T*P, Dv] (this video's rows), ids HOST int64 [L] (unpadded, exactly one IMAGE_TOKEN_INDEX) ->
         logits fp32 [T].  ids_dev: the same ids already on the device (graph capture: no host-to-device copy may be
         recorded; only the text VALUES are read from it, the layout comes from the host copy).  kv_len: see llm_forward - with it,
-        `ids` is the BUCKET-PADDED prompt (pad ids after the real text) and the device scalar holds the real token count."""
+        `ids` is the BUCKET-PADDED prompt (pad ids after the real text) and the device scalar holds the real token count.
+        The one-<image> form of score_sample (what infer.py, the harness plugin, graph capture and the context-parallel path use)."""
+        if int((ids.cpu() == IMAGE_TOKEN_INDEX).sum()) != 1:
+            raise ValueError("score_video takes exactly one <image> token; samples with none or several go through score_sample")
+        return self.score_sample([(feats, T, cmap, pc)], G, ids, T, ids_dev=ids_dev, kv_len=kv_len)
+
+    def score_sample(self, blocks, G: int, ids: torch.Tensor, t_head: int, ids_dev: Optional[torch.Tensor] = None,
+                     kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One row of the batch (eagle_archv1.py:280-337 + grounding_qwen2.py:146-156).  `blocks` = one (feats fp32, T_i, cmap, pc)
+        per <image> token of `ids`, in order; every block is pooled with ITS OWN grid (mlp_proj.py:48 works per list entry) and
+        spliced between the text segments.  t_head = images[b].shape[0], the frame count the reference's head reshapes this row's
+        visual tokens by - for a multi-<image> row that is NOT the row's own clip list (the reference indexes `images` by the batch
+        row), so all nvis visual rows are pooled in t_head equal groups; nvis % t_head != 0 fails like the reference's reshape
+        (RuntimeError) and a row without <image> gives NaN logits like the reference's mean over an empty group
+        (tests/golden/helpers.json "forward_errors")."""
         cfg = self.cfg
         ids = ids.cpu()
         pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
-        if len(pos) != 1:
-            raise ValueError(f"exactly one <image> token per sample is supported on the selector path, got {len(pos)}")
-        hw = cfg.pooled_grid(T, G)
-        nv = T * hw * hw
-        pre, post = ids[:pos[0]], ids[pos[0] + 1:]
-        n = pre.numel() + nv + post.numel()
-        if cfg.tokenizer_model_max_length is not None and n > cfg.tokenizer_model_max_length:
-            keep = cfg.tokenizer_model_max_length                   # eagle_archv1.py:341-345 truncates the tail
-            if keep < pre.numel() + nv:
+        if len(pos) != len(blocks):
+            raise ValueError(f"{len(pos)} <image> tokens but {len(blocks)} visual blocks for this sample")
+        logits = torch.empty(t_head, dtype=torch.float32, device=self.device)
+        if not pos:
+            return logits.fill_(float("nan"))                       # no visual rows: the decoder output is never read by the head
+        hws = [cfg.pooled_grid(T, G) for _, T, _, _ in blocks]
+        nvs = [T * hw * hw for (_, T, _, _), hw in zip(blocks, hws)]
+        bounds = [-1] + pos + [ids.numel()]
+        segs = [(bounds[i] + 1, bounds[i + 1]) for i in range(len(bounds) - 1)]      # text between / around the <image> tokens (ids index ranges)
+        n = sum(e - s for s, e in segs) + sum(nvs)
+        limit = cfg.tokenizer_model_max_length
+        if limit is not None and n > limit:                             # eagle_archv1.py:341-345 truncates the tail
+            if limit < n - (segs[-1][1] - segs[-1][0]):
                 raise ValueError("tokenizer_model_max_length truncates visual tokens: the reference's per-frame reshape "
                                  "(grounding_qwen2.py:153) fails in this case too")
-            post = post[:keep - pre.numel() - nv]
-            n = keep
+            segs[-1] = (segs[-1][0], segs[-1][1] - (n - limit))
+            n = limit
+        nvis = sum(nvs)
+        if nvis % t_head:
+            raise RuntimeError(f"shape '[{t_head}, -1, {cfg.hidden_size}]' is invalid for input of size {nvis * cfg.hidden_size} "
+                               "(grounding_qwen2.py:153: the row's visual tokens do not divide by images[b].shape[0])")
         x = self._buf("llm_x", (n, cfg.hidden_size), torch.float32)
-        if pre.numel():
-            src = ids_dev[:pos[0]] if ids_dev is not None else pre.contiguous().to(self.device)
-            K.embed_gather(src, self.w.embed, x[:pre.numel()])
-        self.project_into(feats, T, G, hw, x[pre.numel():pre.numel() + nv], cmap, pc)
-        if post.numel():
-            src = ids_dev[pos[0] + 1:pos[0] + 1 + post.numel()] if ids_dev is not None else post.contiguous().to(self.device)
-            K.embed_gather(src, self.w.embed, x[pre.numel() + nv:])
+        row, vis_rows = 0, []
+        for i, (s0, e0) in enumerate(segs):
+            if e0 > s0:
+                src = ids_dev[s0:e0] if ids_dev is not None else ids[s0:e0].contiguous().to(self.device)
+                K.embed_gather(src, self.w.embed, x[row:row + e0 - s0])
+                row += e0 - s0
+            if i < len(blocks):
+                feats, T, cmap, pc = blocks[i]
+                self.project_into(feats, T, G, hws[i], x[row:row + nvs[i]], cmap, pc)
+                vis_rows.append((row, nvs[i]))
+                row += nvs[i]
         hfin = self.llm_forward(x, kv_len=kv_len)
-        logits = torch.empty(T, dtype=torch.float32, device=self.device)
-        K.pool_score(hfin[pre.numel():], T, hw * hw, cfg.hidden_size, self.w.head_w, self.w.head_b, logits)
+        if len(vis_rows) == 1:
+            hv = hfin[vis_rows[0][0]:]                                  # contiguous: the head reads the rows in place
+        else:
+            # hidden_states[b][token_types == 3]: the visual rows compacted in sequence order (text sits between the blocks)
+            idx = torch.cat([torch.arange(r0, r0 + nv, dtype=torch.int32) for r0, nv in vis_rows]).to(self.device)
+            hv = self._buf("llm_hv", (nvis, cfg.hidden_size), torch.float32)
+            K.gather_rows(hfin, idx, n, 1, hv, cfg.hidden_size)
+        K.pool_score(hv, t_head, nvis // t_head, cfg.hidden_size, self.w.head_w, self.w.head_b, logits)
         return logits
 
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], images: Sequence[torch.Tensor]
                 ) -> List[torch.Tensor]:
-        """EagleQwenG.forward (grounding_qwen2.py:86-181), inference branch: list of [T_b,1] fp32 logits.
+        """EagleQwenG.forward (grounding_qwen2.py:86-181), inference branch: list of B tensors [images[b].shape[0], 1] (fp32 logits).
         Padded batches are run sample by sample on the unpadded ids (eagle_archv1.py:272 strips padding; the
-        padded rows never influence real ones because keys are masked), which is value-identical."""
+        padded rows never influence real ones because keys are masked), which is value-identical.  A sample consumes one entry
+        of `images` per <image> token - and one entry when it has none (eagle_archv1.py:282-294) - in batch order."""
         images = [im if im.dim() == 4 else im.unsqueeze(0) for im in images]
         if input_ids.dim() == 1:
             input_ids = input_ids.unsqueeze(0)
         B = input_ids.shape[0]
-        if len(images) != B:
-            raise ValueError(f"{len(images)} videos for a batch of {B} prompts")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
-        attention_mask = attention_mask.bool()
-        sizes = {tuple(im.shape[1:]) for im in images}
+        ids_host = input_ids.cpu()
+        mask_host = attention_mask.bool().cpu()
+        samples = [ids_host[b][mask_host[b]] for b in range(B)]          # eagle_archv1.py:272
+        counts = [int((s_ == IMAGE_TOKEN_INDEX).sum()) for s_ in samples]
+        need = sum(max(c, 1) for c in counts)
+        if len(images) < max(need, B):
+            raise ValueError(f"{len(images)} videos for a batch of {B} prompts holding {sum(counts)} <image> tokens")
+        used = images[:need]                                            # (entries past the consumed ones are never read by the reference either)
+        sizes = {tuple(im.shape[1:]) for im in used}
         if len(sizes) != 1:
             raise ValueError("all videos in a batch must share one frame size")
-        pix = torch.cat([im.to(self.device) for im in images], 0) if B > 1 else images[0].to(self.device)
+        pix = torch.cat([im.to(self.device) for im in used], 0) if len(used) > 1 else used[0].to(self.device)
         G0 = pix.shape[-1] // self.cfg.vision.patch_size
-        hws = {self.cfg.pooled_grid(im.shape[0], G0) for im in images}
+        hws = {self.cfg.pooled_grid(im.shape[0], G0) for im in used}
         hw_all = hws.pop() if len(hws) == 1 else None                 # videos of different length pool differently -> dense
         feats, G, cmap, pc = self.vit_forward(pix, hw_all)
         P = pc if cmap is not None else G * G
-        out, row = [], 0
-        ids_host = input_ids.cpu()
-        mask_host = attention_mask.cpu()
+        rows0, r = [], 0
+        for im in used:
+            rows0.append(r)
+            r += im.shape[0]
+        out, img = [], 0
         for b in range(B):
-            T = images[b].shape[0]
-            ids = ids_host[b][mask_host[b]]                          # eagle_archv1.py:272
-            lg = self.score_video(feats[row * P:(row + T) * P], T, G, ids, cmap, pc)
-            out.append(lg.reshape(T, 1))
-            row += T
+            blocks = [(feats[rows0[i] * P:(rows0[i] + used[i].shape[0]) * P], used[i].shape[0], cmap, pc) for i in range(img, img + counts[b])]
+            img += max(counts[b], 1)
+            t_head = images[b].shape[0]                                  # grounding_qwen2.py:153 indexes `images` by the batch row
+            out.append(self.score_sample(blocks, G, samples[b], t_head).reshape(t_head, 1))
         return out
 
 
@@ -683,9 +745,10 @@ class GraphedForward:
 
     def __call__(self, input_ids: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
         """-> logits fp32 [T] (a fresh tensor); the layout must be inside the captured bucket"""
+        input_ids = input_ids.cpu()
         if not self.matches(input_ids, pix):
             raise ValueError("GraphedForward: frame count, resolution, <image> position and prompt-length bucket must equal the captured ones")
-        self._stage(input_ids.cpu(), pix)
+        self._stage(input_ids, pix)
         self.graph.replay()
         return self.out.clone()
 
@@ -699,8 +762,21 @@ class GraphCache:
         self._graphs: Dict[tuple, GraphedForward] = {}
         self.captures = 0
 
+    def serves(self, input_ids: torch.Tensor, pix: torch.Tensor) -> bool:
+        """can a captured forward score this document?  Exactly one <image> token and a bucket-padded prompt inside
+        tokenizer_model_max_length; everything else belongs to the eager forward (which truncates like the reference)"""
+        try:
+            n_pre, n_post_b, shape = GraphedForward.layout_key(self.eng, input_ids.cpu(), pix, self.bucket)
+        except ValueError:
+            return False
+        cfg = self.eng.cfg
+        T, G = shape[0], shape[-1] // cfg.vision.patch_size
+        lim = cfg.tokenizer_model_max_length
+        return lim is None or n_pre + T * cfg.pooled_grid(T, G) ** 2 + n_post_b <= lim
+
     def __call__(self, input_ids: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
-        key = GraphedForward.layout_key(self.eng, input_ids.cpu(), pix, self.bucket)
+        input_ids = input_ids.cpu()                                        # one host copy, shared by the key, the match and the staging
+        key = GraphedForward.layout_key(self.eng, input_ids, pix, self.bucket)
         g = self._graphs.pop(key, None)
         if g is None:
             if len(self._graphs) >= self.max_entries:

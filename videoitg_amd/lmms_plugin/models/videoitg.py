@@ -142,8 +142,12 @@ class VideoITG(_Base):
             resp = self.model(ids, attention_mask=ids.ne(pad_id), images=[pix])
             scores, order = ops.rank(resp.logits[0].view(-1).float())
         order = order.cpu().tolist()
-        scores = scores.cpu()[order].tolist()
-        return [int(sampled[i]) for i in order], [round(v, 2) for v in scores], 1
+        # the reference's model is .half(): its logit leaves out_proj as fp16 and the sigmoid is evaluated on that fp16 value and rounded to
+        # fp16 again before .tolist() (videoitg.py:301-307) - the 2-dp figures in results.jsonl are roundings of THOSE values.  The ORDER
+        # stays the stable fp32 one (ties of the fp16 scores are broken by the fp32 score, then by frame position).
+        lg16 = resp.logits[0].view(-1).float().cpu().half()
+        s16 = torch.sigmoid(lg16.float()).half().float()[order].tolist()
+        return [int(sampled[i]) for i in order], [round(v, 2) for v in s16], 1
 
     def generate_until(self, requests) -> List[dict]:
         os.makedirs(self.output_dir, exist_ok=True)

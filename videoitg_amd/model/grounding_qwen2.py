@@ -196,8 +196,13 @@ class EagleQwenG(nn.Module):
                     from ..engine import GraphCache
                     self._graphs = GraphCache(eng)
                 im = images[0] if images[0].dim() == 4 else images[0].unsqueeze(0)
-                lg = self._graphs(input_ids.reshape(-1), im.to(self._device, self._dtype))
-                return SelectorOutput(logits=[lg.reshape(-1, 1)])
+                ids_host = input_ids.reshape(-1).cpu()                # ONE device-to-host copy per call; the cache works on the host copy
+                # a document the capture cannot serve - no / several <image> tokens, or a prompt whose 32-token BUCKET passes
+                # tokenizer_model_max_length although the prompt itself may fit - is scored by the eager forward, which splices and
+                # truncates like the reference (eagle_archv1.py:341-345), instead of aborting the run
+                if self._graphs.serves(ids_host, im):
+                    lg = self._graphs(ids_host, im.to(self._device, self._dtype))
+                    return SelectorOutput(logits=[lg.reshape(-1, 1)])
             logits = eng.forward(input_ids, attention_mask, images)
             if grounding_labels is None:
                 return SelectorOutput(logits=logits)
