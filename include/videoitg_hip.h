@@ -76,6 +76,24 @@ int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int 
               const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
               void* stream);
 
+/* 16-bit residual stream (round 3).  The reference runs model.half() (/root/reference/eagle/model/builder.py:59, infer.py:21): its
+ * residual adds happen on fp16 tensors.  vitg_gemm keeps the stream in fp32 (mode VITG_GEMM_F32); these three entry points run the
+ * SigLIP tower's stream in the MFMA input type instead - half the bytes of every LayerNorm read, out-proj / fc2 read-modify-write -
+ * with fp32 accumulation inside the epilogue and ONE rounding per residual update:
+ *   vitg_gemm_res16:      out16[m,n] = round16( sum_k A[m,k] W[n,k] + bias[n] + res16[m,n] + res32[m % res_mod, n] )
+ *                         res16 (16-bit, ld ldr16, may alias out) or res32 (fp32 table, e.g. the position embedding with res_mod = tokens
+ *                         per frame) or neither.  Same call sites as vitg_gemm: SigLIP patch-embed (+ position table), out_proj, fc2.
+ *   vitg_layernorm16:     LayerNorm of 16-bit rows -> 16-bit rows (same type), fp32 statistics; D, ldx, ldo multiples of 8.
+ *   vitg_bilinear_pool16: vitg_bilinear_pool on 16-bit features.
+ * The decoder's stream stays fp32 (12 860 rows: its norm traffic is 0.4 % of a step, and the 28-layer bidirectional stack is the
+ * precision-sensitive part, profiles/r02_parity.md). */
+int vitg_gemm_res16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, void* out,
+                    int ldo, const void* res16, int ldr16, const float* res32, int ldr32, int res_mod, void* stream);
+int vitg_layernorm16(const void* x, int ldx, const float* w, const float* b, void* out, int ldo, int dtype, long M, int D, float eps,
+                     void* stream);
+int vitg_bilinear_pool16(const void* x, int ldx, void* out, int ldo, int T, int G, int HW, int D, int dtype, const int* cmap, int Pc,
+                         void* stream);
+
 /* Deterministic split-K form of vitg_gemm(mode = VITG_GEMM_F32, act = none) for shapes with FEW output tiles and a long K - the
  * o / down projections of one rank of the context-parallel LLM (M = 12 860 / 8 rows: 98 tiles of 256 x 256 on 256 CUs).
  * vitg_gemm_splitk_plan tells how many splits pay off on this device (1 = use vitg_gemm) and how much fp32 workspace they need;

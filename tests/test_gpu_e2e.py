@@ -442,3 +442,26 @@ def test_mixed_batch_of_single_and_double_image_samples_equals_the_oracle(golden
     for g, w in zip(got, want):
         assert g.shape == w.shape
         assert (torch.sigmoid(g.float().cpu()) - torch.sigmoid(w)).abs().max().item() <= SCORE_TOL
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_residual16_tower_stream_matches_reference_golden(golden_dir, name):
+    """the tower's residual stream in fp16 (the reference's own arithmetic: model.half()) instead of fp32: same goldens, same bound"""
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    z = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    cfg = ITGConfig.from_dict(json.loads(str(z["cfg"])))
+    T = z["T"].tolist()
+    images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i).cuda() for i, t in enumerate(T)]
+    sd, vsd = synth.synth_llm_state_dict(cfg, int(z["seed"])), synth.synth_vision_state_dict(cfg, int(z["seed"]))
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    eng.residual16 = True
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    got = [g.float().cpu() for g in eng.forward(ids, mask, images)]
+    assert "vit_x16" in eng._ws and "vit_x" not in eng._ws                  # the 16-bit stream really ran
+    tol = GOLDEN_TOL[torch.float16].get(name, SCORE_TOL)
+    for b in range(len(got)):
+        ref = torch.from_numpy(z[f"logits{b}"])
+        assert got[b].shape == ref.shape
+        assert (torch.sigmoid(got[b]) - torch.sigmoid(ref)).abs().max().item() <= tol

@@ -379,3 +379,56 @@ def test_gemm_splitk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K
     sp, nb = ops.gemm_splitk_plan(1660, 3584, 18944)
     assert sp == 2 and nb == 2 * 1660 * 3584 * 4
     assert ops.gemm_splitk_plan(12860, 3584, 18944)[0] == 1 and ops.gemm_splitk_plan(1660, 3584, 1152)[0] == 1
+
+
+# ---- round 3: the tower's 16-bit residual stream (vitg_gemm_res16 / vitg_layernorm16 / vitg_bilinear_pool16) -----------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,P", [(729 * 2, 1152, 640, 729), (100, 144, 192, 16), (513, 256, 256, 0), (1000, 1152, 4352, 0), (3000, 1152, 1152, 0)])
+def test_gemm_res16(ops, gemm_cfg, dtype, M, N, K, P):
+    """out16 = round16(a w^T + bias + residual): fp32 table form (patch embedding + positions, res_mod) and the in-place 16-bit stream
+    form; exactly ONE 16-bit rounding of the fp32 sum"""
+    a, w, b = rnd((M, K), 4, dtype=dtype), rnd((N, K), 5, K ** -0.5, dtype=dtype), rnd((N,), 6, 0.1, torch.float32)
+    if P:
+        res = rnd((P, N), 7, 1.0, torch.float32)
+        want = a @ w.t() + b + res.repeat(M // P + 1, 1)[:M]
+        out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+        ops.gemm_res16(a.to(dtype).cuda(), w.to(dtype).cuda(), out, bias=b.cuda(), res32=res.cuda(), res_mod=P)
+    else:
+        x = rnd((M, N), 8, 2.0, dtype=dtype)
+        want = a @ w.t() + b + x
+        out = x.to(dtype).cuda()
+        ops.gemm_res16(a.to(dtype).cuda(), w.to(dtype).cuda(), out, bias=b.cuda(), res16=out)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= EPS16[dtype] * want.abs().max().item() + 2e-4 * math.sqrt(K)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,D", [(1000, 1152), (37, 144), (70000, 1152), (64, 256), (5, 4096)])
+def test_layernorm16(ops, dtype, M, D):
+    from videoitg_amd.ops import pad64
+    x = (rnd((M, D), 40, 3.0, torch.float32) + 0.5).to(dtype)
+    w, b = rnd((D,), 41, 0.1, torch.float32) + 1.0, rnd((D,), 42, 0.1, torch.float32)
+    out = torch.full((M, pad64(D)), float("nan"), dtype=dtype, device="cuda")
+    ops.layernorm16(x.cuda(), w.cuda(), b.cuda(), out, D, 1e-6)
+    got = out.float().cpu()
+    assert (got[:, D:] == 0).all()
+    assert (got[:, :D] - F.layer_norm(x.float(), (D,), w, b, 1e-6)).abs().max().item() <= EPS16[dtype] * 8 * 6
+    # same statistics as the fp32-input kernel on the same (16-bit-exact) row: outputs agree to one rounding
+    ref = torch.empty((M, pad64(D)), dtype=dtype, device="cuda")
+    ops.layernorm(x.float().cuda(), w.cuda(), b.cuda(), ref, D, 1e-6)
+    assert (got[:, :D] - ref.float().cpu()[:, :D]).abs().max().item() <= EPS16[dtype] * 8
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,G,HW,D", [(4, 27, 5, 1152), (3, 4, 3, 144), (2, 4, 4, 144), (1, 32, 5, 64)])
+def test_bilinear_pool16(ops, dtype, T, G, HW, D):
+    from videoitg_amd.ops import pad64
+    x = rnd((T * G * G, D), 70, 1.0, dtype=dtype)
+    want = F.interpolate(x.view(T, G, G, D).permute(0, 3, 1, 2), size=(HW, HW), mode="bilinear", align_corners=False)
+    want = want.permute(0, 2, 3, 1).reshape(T * HW * HW, D) if HW < G else x
+    out = torch.full((T * HW * HW, pad64(D)), float("nan"), dtype=dtype, device="cuda")
+    ops.bilinear_pool16(x.to(dtype).cuda(), out, T, G, HW, D)
+    got = out.float().cpu()
+    assert (got[:, D:] == 0).all()
+    assert (got[:, :D] - want).abs().max().item() <= EPS16[dtype] * want.abs().max().item() + 1e-6

@@ -29,6 +29,7 @@ SIGNATURES = {
     "vitg_set_option": [C.c_char_p, _i],
     "vitg_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "vitg_gemm": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
+    "vitg_gemm_res16": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _p],
     "vitg_gemm_splitk_plan": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_long)],
     "vitg_gemm_splitk": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p],
     "vitg_quant_rows_fp8": [_p, _l, _i, _p, _l, _p, _l, _i, _p],
@@ -37,11 +38,13 @@ SIGNATURES = {
     "vitg_gemm_fp8_mx": [_p, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "vitg_mfma_probe": [_p, _i, _i, _i, _p, C.POINTER(C.c_double), _p],
     "vitg_layernorm": [_p, _i, _p, _p, _p, _i, _i, _l, _i, _f, _p],
+    "vitg_layernorm16": [_p, _i, _p, _p, _p, _i, _i, _l, _i, _f, _p],
     "vitg_rmsnorm": [_p, _i, _p, _p, _i, _i, _l, _i, _f, _p],
     "vitg_rope": [_p, _i, _p, _p, _l, _i, _i, _i, _p],
     "vitg_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "vitg_attention_dyn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "vitg_bilinear_pool": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "vitg_bilinear_pool16": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "vitg_gather_rows": [_p, _l, _p, _i, _i, _i, _p, _l, _i, _p],
     "vitg_embed_gather": [_p, _i, _p, _i, _p, _i, _i, _p],
     "vitg_pool_score": [_p, _i, _i, _i, _i, _p, _p, _p, _p],

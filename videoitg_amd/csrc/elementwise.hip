@@ -116,6 +116,72 @@ __global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* _
     }
 }
 
+// LayerNorm over 16-bit rows (the tower's 16-bit residual stream, round 3: the reference's own arithmetic - model.half(),
+// /root/reference/eagle/model/builder.py:59) -> 16-bit rows of the same type: 2 B read + 2 B written per element instead of 4 + 2.  One wave per row, 8 elements (16 B) per lane and chunk, row in registers, fp32 statistics, next row prefetched.
+template <typename T, int NV, bool PF>
+__global__ void ln16_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bia,
+                            T* __restrict__ out, int ldo, long M, int D, float eps) {
+    typedef typename T16<T>::vec8 vec8;
+    const int lane = threadIdx.x & 63;
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    vec8 v[NV], nx[PF ? NV : 1];
+    auto load_row = [&](auto& dst, long r) {
+        const T* xr = x + r * ldx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < D) dst[i] = *(const vec8*)(xr + c);
+            else dst[i] = vec8{};
+        }
+    };
+    load_row(v, row);
+    for (; row < M; row += nwaves) {
+        const long next = row + nwaves;
+        if constexpr (PF) { if (next < M) load_row(nx, next); }
+        float f[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[i][e] = T16<T>::to_f32(v[i][e]); s += f[i][e]; }
+        s = wave_sum(s);
+        const float mean = s / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < D) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        const float rstd = rsqrtf(q / D + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c >= ldo) continue;
+            vec8 o = vec8{};
+            if (c < D) {
+                const f32x4 w0 = *(const f32x4*)(w + c), w1 = *(const f32x4*)(w + c + 4);
+                const f32x4 b0 = *(const f32x4*)(bia + c), b1 = *(const f32x4*)(bia + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = T16<T>::from_f32((f[i][e] - mean) * rstd * w0[e] + b0[e]);
+                    o[e + 4] = T16<T>::from_f32((f[i][e + 4] - mean) * rstd * w1[e] + b1[e]);
+                }
+            }
+            *(vec8*)(out + row * ldo + c) = o;
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = nx[i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // RoPE (rotate_half layout) in place on the q and k heads of a packed qkv row:
 //   x[i] <- x[i] cos_i - x[i+hd/2] sin_i ;  x[i+hd/2] <- x[i+hd/2] cos_i + x[i] sin_i
@@ -152,8 +218,13 @@ __global__ void rope_kernel(T* __restrict__ qkv, int ld, const float* __restrict
 // fp32 tower features [T, G*G, D] -> 16-bit [T*HW*HW, ldo] (pad columns zeroed).
 // src = (dst + 0.5) * G/HW - 0.5 clamped at 0; i0 = floor(src), i1 = min(i0+1, G-1), w1 = src - i0.
 // ------------------------------------------------------------------------------------------------
-template <typename TO>
-__global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out, int ldo, int T, int G, int HW,
+template <typename TI> __device__ __forceinline__ f32x4 ld4_as_f32(const TI* p);
+template <> __device__ __forceinline__ f32x4 ld4_as_f32<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 ld4_as_f32<f16_t>(const f16_t* p) { const f16x4 v = *(const f16x4*)p; return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+template <> __device__ __forceinline__ f32x4 ld4_as_f32<bf16_t>(const bf16_t* p) { const bf16x4 v = *(const bf16x4*)p; return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+
+template <typename TO, typename TI = float>
+__global__ void pool_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ out, int ldo, int T, int G, int HW,
                             int D, const int* __restrict__ cmap, int Pc) {
     const long orow = blockIdx.x;                 // t*HW*HW + oy*HW + ox
     const int t = (int)(orow / (HW * HW)), o = (int)(orow % (HW * HW));
@@ -168,7 +239,7 @@ __global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict
     const int y1 = min(y0 + 1, G - 1), x1 = min(x0 + 1, G - 1);
     const float wy1 = sy - y0, wx1 = sx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
     // dense input: G*G rows per frame; compact input (cmap != null): only the Pc rows the pool reads, at cmap[y*G+x]
-    const float* base = x + (long)t * (cmap ? Pc : G * G) * ldx;
+    const TI* base = x + (long)t * (cmap ? Pc : G * G) * ldx;
     const int i00 = y0 * G + x0, i01 = y0 * G + x1, i10 = y1 * G + x0, i11 = y1 * G + x1;
     int r00 = i00, r01 = i01, r10 = i10, r11 = i11;
     if (cmap) {
@@ -180,16 +251,16 @@ __global__ void pool_kernel(const float* __restrict__ x, int ldx, TO* __restrict
             return;
         }
     }
-    const float* p00 = base + (long)r00 * ldx;
-    const float* p01 = base + (long)r01 * ldx;
-    const float* p10 = base + (long)r10 * ldx;
-    const float* p11 = base + (long)r11 * ldx;
+    const TI* p00 = base + (long)r00 * ldx;
+    const TI* p01 = base + (long)r01 * ldx;
+    const TI* p10 = base + (long)r10 * ldx;
+    const TI* p11 = base + (long)r11 * ldx;
     for (int c = threadIdx.x * 4; c < ldo; c += blockDim.x * 4) {
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (c < D) {
             // same association as ATen's upsample_bilinear2d: w_y0*(w_x0*a + w_x1*b) + w_y1*(w_x0*c + w_x1*d)
-            r = wy0 * (wx0 * *(const f32x4*)(p00 + c) + wx1 * *(const f32x4*)(p01 + c)) +
-                wy1 * (wx0 * *(const f32x4*)(p10 + c) + wx1 * *(const f32x4*)(p11 + c));
+            r = wy0 * (wx0 * ld4_as_f32<TI>(p00 + c) + wx1 * ld4_as_f32<TI>(p01 + c)) +
+                wy1 * (wx0 * ld4_as_f32<TI>(p10 + c) + wx1 * ld4_as_f32<TI>(p11 + c));
         }
         typename T16<TO>::vec4 ov;
 #pragma unroll
@@ -355,6 +426,25 @@ extern "C" int vitg_rmsnorm(const float* x, int ldx, const float* w, void* out, 
     return norm_dispatch<true>(x, ldx, w, nullptr, out, ldo, out_dtype, M, D, eps, (hipStream_t)stream);
 }
 
+extern "C" int vitg_layernorm16(const void* x, int ldx, const float* w, const float* b, void* out, int ldo, int dtype, long M, int D,
+                                float eps, void* stream) {
+    if (M <= 0) return 0;
+    if (D % 8 || ldo % 8 || ldx % 8) return VITG_ERR_ALIGN;
+    if (ldo < D) return VITG_ERR_SHAPE;
+    const int need = ceil_div(ldo, 512);
+    const long want = (M + 3) / 4;
+    const long cap = 16384;
+    dim3 blk(256), grid((unsigned)(want < cap ? want : cap));
+    hipStream_t s = (hipStream_t)stream;
+#define LK(T, NV) do { if (want > cap) hipLaunchKernelGGL((ln16_kernel<T, NV, true>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); \
+                        else hipLaunchKernelGGL((ln16_kernel<T, NV, false>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); } while (0)
+#define LKS(T) do { if (need <= 1) LK(T, 1); else if (need <= 3) LK(T, 3); else if (need <= 8) LK(T, 8); else return VITG_ERR_SHAPE; } while (0)
+    if (dtype == DT_F16) LKS(f16_t); else if (dtype == DT_BF16) LKS(bf16_t); else return VITG_ERR_DTYPE;
+#undef LKS
+#undef LK
+    return CHECK_LAUNCH();
+}
+
 extern "C" int vitg_rope(void* qkv, int ld, const float* cos_t, const float* sin_t, long N, int heads, int head_dim,
                          int dtype, void* stream) {
     if (N <= 0 || heads <= 0) return 0;
@@ -396,6 +486,21 @@ extern "C" int vitg_bilinear_pool(const float* x, int ldx, void* out, int ldo, i
         else if (dtype == DT_F16) hipLaunchKernelGGL((pool_kernel<f16_t>), grid, blk, 0, s, x, ldx, (f16_t*)out, ldo, T, G, HW, D, cmap, Pc);
         else return VITG_ERR_DTYPE;
     }
+    return CHECK_LAUNCH();
+}
+
+extern "C" int vitg_bilinear_pool16(const void* x, int ldx, void* out, int ldo, int T, int G, int HW, int D, int dtype,
+                                    const int* cmap, int Pc, void* stream) {
+    if (T <= 0) return 0;
+    if (D % 4 || ldo % 4 || ldx % 4 || ldo < D) return VITG_ERR_ALIGN;
+    if (HW <= 0 || HW > G) return VITG_ERR_SHAPE;
+    if (HW == G && cmap) return VITG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    // (HW == G runs the same kernel: every output token then reads its own source token with weight 1 and the pad columns are zeroed)
+    dim3 blk(256), grid((unsigned)((long)T * HW * HW));
+    if (dtype == DT_BF16) hipLaunchKernelGGL((pool_kernel<bf16_t, bf16_t>), grid, blk, 0, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, T, G, HW, D, cmap, Pc);
+    else if (dtype == DT_F16) hipLaunchKernelGGL((pool_kernel<f16_t, f16_t>), grid, blk, 0, s, (const f16_t*)x, ldx, (f16_t*)out, ldo, T, G, HW, D, cmap, Pc);
+    else return VITG_ERR_DTYPE;
     return CHECK_LAUNCH();
 }
 

@@ -158,6 +158,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm128_kernel(GemmArgs g) {
                         }
                         *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
                     } else {
+                        if (g.res) {                     // vitg_gemm_res16 forms: fp32 table (patch embedding + positions) ...
+                            const int rm = g.res_mod > 0 ? m % g.res_mod : m;
+                            v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+                        }
+                        if (g.res16) {                   // ... or the 16-bit residual row (a lane reads the quad it overwrites: in place is safe)
+                            const typename T16<T>::vec4 r = *(const typename T16<T>::vec4*)((const T*)g.res16 + (size_t)m * g.ldr16 + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += T16<T>::to_f32(r[e]);
+                        }
                         typename T16<T>::vec4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
@@ -207,7 +216,8 @@ struct NormFusion {               // fused normalisation around a GEMM (see Gemm
 
 static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void* Wf, int M, int N, int K, int dtype,
                       int mode, const float* bias, int act, void* out, int ldo,
-                      const float* res, int ldr, int res_mod, void* stream, const NormFusion* nf = nullptr) {
+                      const float* res, int ldr, int res_mod, void* stream, const NormFusion* nf = nullptr,
+                      const void* res16 = nullptr, int ldr16 = 0) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || K % BK != 0) return VITG_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8)) return VITG_ERR_ALIGN;
@@ -221,6 +231,7 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.res = res; g.ldr = ldr; g.res_mod = res_mod;
     g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4; g.Wf = Wf;
     g.split_k = 1; g.split_stride = 0;
+    g.res16 = res16; g.ldr16 = ldr16;
 #if VITG_PROFILING_BUILD
     g.stamps = g_stamp_buf; g.stamp_blocks = g_stamp_blocks;
 #endif
@@ -256,6 +267,12 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
         rc = launch_gemm_pe(g, dtype, mode, s);
     else
 #endif
+    // 16-bit output + residual (vitg_gemm_res16): the 256-wide tiles of gemm_mi16.hip, or - where auto mode would take the 256x128
+    // tile or the shape is small / unaligned - the 128-tile kernel; gemm256.hip's own epilogues do not carry these forms
+    if (mode == VITG_GEMM_STORE16 && (res || res16) &&
+        !(force != 128 && gemm256_applicable(g, mode) && (ldr16 % 4 == 0) && gemm256_pick_cfg(g, mode) != 2 && N >= 256))
+        rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
+    else
     if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);
     else rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
@@ -265,6 +282,15 @@ extern "C" int vitg_gemm(const void* A, int lda, const void* W, int ldw, int M, 
                          int mode, const float* bias, int act, void* out, int ldo,
                          const float* res, int ldr, int res_mod, void* stream) {
     return gemm_entry(A, lda, W, ldw, nullptr, M, N, K, dtype, mode, bias, act, out, ldo, res, ldr, res_mod, stream);
+}
+
+extern "C" int vitg_gemm_res16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias,
+                               void* out, int ldo, const void* res16, int ldr16, const float* res32, int ldr32, int res_mod,
+                               void* stream) {
+    if (res16 && (ldr16 % 4)) return VITG_ERR_ALIGN;
+    if (res32 && (ldr32 % 4)) return VITG_ERR_ALIGN;
+    return gemm_entry(A, lda, W, ldw, nullptr, M, N, K, dtype, VITG_GEMM_STORE16, bias, VITG_ACT_NONE, out, ldo, res32, ldr32, res_mod, stream,
+                      nullptr, res16, ldr16);
 }
 
 #if VITG_PROFILING_BUILD

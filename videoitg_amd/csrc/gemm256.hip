@@ -895,6 +895,12 @@ static int choose_cfg(const GemmArgs& g, int mode) {
     double best = cost(256, 256, 1.00, 1);
     int cfg = 6;
     if (g.N < 256) return 2;
+    {   // gemm_pref (A/B): force a tile shape per epilogue mode when the shape admits it
+        const int pref = tuning().gemm_pref, d = mode == MODE_STORE16 ? pref / 100 % 10 : mode == MODE_F32 ? pref / 10 % 10 : pref % 10;
+        if (d == 1) return 6;
+        if (d == 2 && mode != MODE_SWIGLU && g.N >= 384) return 9;
+        if (d == 3 && g.M >= 384) return 10;
+    }
     const double c2 = cost(256, 128, 0.65, 1);
     if (c2 < 0.97 * best) { best = c2; cfg = 2; }
     if (wide_ok && mode != MODE_SWIGLU && g.N >= 384) {
@@ -913,6 +919,7 @@ static int choose_cfg(const GemmArgs& g, int mode) {
 }
 
 static bool gemm_mi16_selected() { return tuning().gemm_mi == 16; }
+int gemm256_pick_cfg(const GemmArgs& g, int mode);
 
 template <typename T, int MODE, bool NRM = false>
 static int launch256_m(const GemmArgs& g, hipStream_t s) {
@@ -927,7 +934,9 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
     if (MODE == MODE_F32 && g.split_k > 1) cfg = 6;           // split-K partials: 256x256 tiles (the plan of vitg_gemm_splitk_plan assumes them)
     // MFMA shape (round 3): the three shipped tile shapes exist on v_mfma_f32_16x16x32 as well (gemm_mi16.hip), which the package power
     // cap lets run 14 % faster than 32x32x16 on real operands (profiles/r03_mfma_shape.md)
-    if ((cfg == 6 || cfg == 9 || cfg == 10) && gemm_mi16_selected())
+    // (the residual forms of the 16-bit-output mode - vitg_gemm_res16 - exist in gemm_mi16.hip and the 128-tile kernel only; gemm_entry
+    // never sends them here with the 256x128 tile)
+    if ((cfg == 6 || cfg == 9 || cfg == 10) && (gemm_mi16_selected() || (MODE == MODE_STORE16 && (g.res || g.res16))))
         return launch_gemm_mi16(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, cfg, s);
 #if VITG_PROFILING_BUILD
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
@@ -978,6 +987,11 @@ static int launch256_t(const GemmArgs& g, int mode, hipStream_t s) {
     if (mode == MODE_SWIGLU) return launch256_m<T, MODE_SWIGLU>(g, s);
     if (mode == MODE_F32) return launch256_m<T, MODE_F32>(g, s);
     return launch256_m<T, MODE_STORE16>(g, s);
+}
+
+int gemm256_pick_cfg(const GemmArgs& g, int mode) {
+    const int cfg = tuning().gemm_cfg;
+    return cfg ? cfg : choose_cfg(g, mode);
 }
 
 // columns covered by one partial of the fused-norm producer for this shape (= BN / WN of the tile shape auto mode picks), 0 when the

@@ -17,6 +17,8 @@ struct GemmArgs {
     int act;                  // VITG_ACT_*
     void* out; int ldo;       // mode STORE16/SWIGLU: T16*, mode F32: float*
     const float* res; int ldr; int res_mod;   // mode F32: out = acc + bias + res[(m % res_mod), n] (res may be null)
+    const void* res16; int ldr16;             // mode STORE16 (vitg_gemm_res16): out = round16(acc + bias + res16[m, n]) - the 16-bit residual stream of the
+                                              // tower; `res` (fp32, res_mod) is accepted there too (patch embedding + position table)
     int tiles_m, tiles_n;
     int group_m;              // gemm256: M-tiles per group of the XCD-aware tile order
     int stagger_ns;           // persistent kernel: tile period estimate for de-phasing the XCDs (0 = off)
@@ -87,6 +89,15 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, f
         }
         *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
     } else {
+        if (g.res) {                                     // vitg_gemm_res16 forms (a lane reads the quad it is about to overwrite: in place is safe)
+            const int rm = g.res_mod > 0 ? m % g.res_mod : m;
+            v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+        }
+        if (g.res16) {
+            const typename T16<T>::vec4 r = *(const typename T16<T>::vec4*)((const T*)g.res16 + (size_t)m * g.ldr16 + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += T16<T>::to_f32(r[e]);
+        }
         typename T16<T>::vec4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
@@ -257,6 +268,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 
 int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s);   // gemm256.hip
 bool gemm256_applicable(const GemmArgs& g, int mode);
+int gemm256_pick_cfg(const GemmArgs& g, int mode);                                // the tile shape auto mode takes for this shape (2 / 6 / 9 / 10)
 int gemm256_norm_cols(const GemmArgs& g);                                       // gemm256.hip
 int launch_gemm_mi16(const GemmArgs& g, int dtype, int mode, int cfg, hipStream_t s);   // gemm_mi16.hip: the same tiles on v_mfma_f32_16x16x32
 int launch_gemm_w4(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_w4.hip

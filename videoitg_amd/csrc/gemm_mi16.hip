@@ -100,13 +100,15 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     const int r16 = lane & 15, fq = lane >> 4;
     // Accumulators: zero, or - fp32 residual update without activation - the residual tile itself (the read half of the
     // read-modify-write then overlaps the main loop; these loads are older than every DMA in the vmcnt queue)
-    const bool acc_from_res = MODE == MODE_F32 && g.res != nullptr && g.act == VITG_ACT_NONE;
+    // (MODE_STORE16 with a residual = vitg_gemm_res16: the 16-bit residual stream of the tower, or the fp32 position table)
+    const bool acc_from_res = (MODE == MODE_F32 || MODE == MODE_STORE16) && (g.res != nullptr || (MODE == MODE_STORE16 && g.res16 != nullptr)) &&
+                              g.act == VITG_ACT_NONE;
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (MODE == MODE_F32) {
+    if constexpr (MODE == MODE_F32 || MODE == MODE_STORE16) {
         if (acc_from_res) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -115,7 +117,16 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = n0 + wc * (NT * 16) + nt * 16 + fq * 4;
-                    if (m < g.M && n < g.N) acc[nt][mt] = *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+                    if (m < g.M && n < g.N) {
+                        if (g.res) acc[nt][mt] = *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+                        if constexpr (MODE == MODE_STORE16) {
+                            if (g.res16) {
+                                const typename T16<T>::vec4 r = *(const typename T16<T>::vec4*)((const T*)g.res16 + (size_t)m * g.ldr16 + n);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[nt][mt][e] += T16<T>::to_f32(r[e]);
+                            }
+                        }
+                    }
                 }
             }
         }

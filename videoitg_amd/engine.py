@@ -250,6 +250,9 @@ class SelectorEngine:
         self.device = weights.device
         self.attn_variant = attn_variant
         self.skip_dead_rows = True        # last tower layer only on the tokens the pool reads (see vit_forward)
+        # 16-bit residual stream in the TOWER (round 3; vitg_gemm_res16 / vitg_layernorm16): the reference's own arithmetic (model.half()),
+        # half the bytes of every LayerNorm read and out-proj / fc2 read-modify-write.  The decoder's stream stays fp32.
+        self.residual16 = os.environ.get("VITG_RES16", "0") not in ("", "0")
         # LayerNorm / RMSNorm folded into the GEMMs around them (vitg_gemm_norm_*).  Measured 4 % SLOWER on the step than the stand-alone
         # norm kernels (profiles/r02_fused_norm.md), so the kernels live in the profiling library and this switch only exists there.
         # (never together with fp8 layer weights - the fused consumers only exist for 16-bit operands)
@@ -399,13 +402,33 @@ class SelectorEngine:
         Dv, Dvp, Fvp = v.hidden_size, pad64(v.hidden_size), pad64(v.intermediate_size)
         H, hd = v.num_attention_heads, v.head_dim
         a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.vdtype)
-        x = self._buf("vit_x", (M, Dv), torch.float32)
         eps, vdt = v.layer_norm_eps, self.vdtype
+        r16 = self.residual16 and not self._part_fp8("vit_") and not self.fuse_norm and Dv % 8 == 0
+        x = self._buf("vit_x16" if r16 else "vit_x", (M, Dv), vdt if r16 else torch.float32)
         src = self.pool_sources(G, hw) if (hw is not None and self.skip_dead_rows and len(w.vit) > 0) else None
         full_layers = w.vit if src is None else w.vit[:-1]
+
+        def norm(xs, gw, gb, name):
+            """LayerNorm of stream rows as the A operand of the next GEMM"""
+            if not r16:
+                return self._norm(xs, gw, gb, name, Dv, eps, vdt)
+            h_ = self._buf(name, (xs.shape[0], Dvp), vdt, zero=True)
+            return K.layernorm16(xs, gw, gb, h_, Dv, eps)
+
+        def update(a, wt, bias, xs):
+            """xs += a @ wt.T + bias  (16-bit stream: one rounding per update, fp32 accumulation inside the epilogue)"""
+            if r16:
+                K.gemm_res16(a, wt, xs, bias=bias, res16=xs)
+            else:
+                self._gemm(a, wt, xs, mode=K.GEMM_F32, bias=bias, res=xs)
+
         # `pend` = (xh, stats) when the GEMM that produced x also emitted the operand / statistics of the next LayerNorm (fuse_norm)
-        pend = self._producer(a0, w.patch_w, x, bias=w.patch_b, res=w.pos_table(G), res_mod=P, gamma=w.vit[0].ln1_w if w.vit else None,
-                              name="vit", eps=eps, rms=False, dt=vdt)
+        if r16:
+            K.gemm_res16(a0, w.patch_w, x, bias=w.patch_b, res32=w.pos_table(G), res_mod=P)
+            pend = None
+        else:
+            pend = self._producer(a0, w.patch_w, x, bias=w.patch_b, res=w.pos_table(G), res_mod=P, gamma=w.vit[0].ln1_w if w.vit else None,
+                                  name="vit", eps=eps, rms=False, dt=vdt)
         del a0
         qkv = self._buf("vit_qkv", (M, 3 * Dv), vdt)
         o = self._buf("vit_o", (M, Dvp), vdt, zero=True)
@@ -417,11 +440,17 @@ class SelectorEngine:
             if pend is not None:
                 K.gemm_norm_consumer(pend[0], lw.qkv_w, qkv, mode=K.GEMM_STORE16, stats=pend[1], colsum=lw.qkv_cs, bias=lw.qkv_c)
             else:
-                h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, eps, vdt)
+                h = norm(x, lw.ln1_w, lw.ln1_b, "vit_h")
                 self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
             K.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
                         q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
                         variant=self.attn_variant)
+            if r16:
+                update(o, lw.out_w, lw.out_b, x)
+                h = norm(x, lw.ln2_w, lw.ln2_b, "vit_h")
+                self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
+                update(f, lw.fc2_w, lw.fc2_b, x)
+                continue
             pend = self._producer(self._operand(o, "vit_o", Dv), lw.out_w, x, bias=lw.out_b, res=x, gamma=lw.ln2_w, name="vit", eps=eps,
                                   rms=False, dt=vdt)
             if pend is not None:
@@ -448,26 +477,32 @@ class SelectorEngine:
             K.gemm_norm_consumer(pend[0], lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, stats=pend[1], colsum=lw.qkv_cs[Dv:],
                                  bias=lw.qkv_c[Dv:])
         else:
-            h = self._norm(x, lw.ln1_w, lw.ln1_b, "vit_h", Dv, eps, vdt)
+            h = norm(x, lw.ln1_w, lw.ln1_b, "vit_h")
             self._gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, bias=lw.qkv_b[Dv:])
-        xq = self._buf("vit_xq", (Mc, Dv), torch.float32)
+        xq = self._buf("vit_xq16" if r16 else "vit_xq", (Mc, Dv), vdt if r16 else torch.float32)
         K.gather_rows(x, idx, P, T, xq, Dv)
         # LayerNorm is per row: normalising the gathered residual rows equals gathering the normalised rows
-        hq = self._norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq", Dv, eps, vdt)
+        hq = norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq")
         qc = self._buf("vit_qc", (Mc, Dv), vdt)
         self._gemm(hq, lw.qkv_w[:Dv], qc, mode=K.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
         oc = self._buf("vit_oc", (Mc, Dvp), vdt, zero=True)
         K.attention(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
                     q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
                     variant=self.attn_variant)
-        self._gemm(self._operand(oc, "vit_oc", Dv), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
-        hq = self._norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", Dv, eps, vdt)
+        if r16:
+            update(oc, lw.out_w, lw.out_b, xq)
+        else:
+            self._gemm(self._operand(oc, "vit_oc", Dv), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
+        hq = norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq")
         if self.fp8_mx and isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight):
             self._mlp_fp8_mx(hq, lw.fc1_w, lw.fc1_b, lw.fc2_w, lw.fc2_b, xq, "vit_c")
             return xq, G, cmap, Pc
         fc = self._buf("vit_fc", (Mc, Fvp), vdt)
         self._gemm(hq, lw.fc1_w, fc, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
-        self._gemm(self._operand(fc, "vit_fc", Fvp), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
+        if r16:
+            update(fc, lw.fc2_w, lw.fc2_b, xq)
+        else:
+            self._gemm(self._operand(fc, "vit_fc", Fvp), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
         return xq, G, cmap, Pc
 
     # ---- A9: pool + projector, written straight into rows of the LLM residual stream ------------------
@@ -477,7 +512,7 @@ class SelectorEngine:
         Dv, Dvp, Dp = cfg.vision.hidden_size, pad64(cfg.vision.hidden_size), pad64(cfg.hidden_size)
         nv = T * hw * hw
         pooled = self._buf("pooled", (nv, Dvp), self.dtype)
-        K.bilinear_pool(feats, pooled, T, G, hw, Dv, cmap, pc)
+        (K.bilinear_pool if feats.dtype == torch.float32 else K.bilinear_pool16)(feats, pooled, T, G, hw, Dv, cmap, pc)   # (16-bit tower stream)
         g = self._buf("proj_g", (nv, Dp), self.dtype)
         K.gemm(pooled, w.proj0_w, g, mode=K.GEMM_STORE16, bias=w.proj0_b, act=K.ACT_GELU_ERF)
         K.gemm(g, w.proj2_w, dst_rows, mode=K.GEMM_F32, bias=w.proj2_b)

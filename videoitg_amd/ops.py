@@ -90,6 +90,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, n: O
     return out
 
 
+def gemm_res16(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+               res16: Optional[torch.Tensor] = None, res32: Optional[torch.Tensor] = None, res_mod: int = 0) -> torch.Tensor:
+    """out16 = round16(a @ w.T + bias + res16 + res32[m % res_mod]) - the tower's 16-bit residual stream (vitg_gemm_res16)"""
+    _req(a); _req(w); _req(out, a.dtype)
+    M, Kd = a.shape
+    N = w.shape[0]
+    if res16 is not None:
+        _req(res16, a.dtype)
+    if res32 is not None:
+        _req(res32, torch.float32)
+    _lib.call("vitg_gemm_res16", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, N, Kd, dt_code(a.dtype), _ptr(bias), _ptr(out), out.stride(0),
+              _ptr(res16), res16.stride(0) if res16 is not None else 0, _ptr(res32), res32.stride(0) if res32 is not None else 0, res_mod, _stream())
+    return out
+
+
 def gemm_norm_plan(M: int, N: int, K: int) -> int:
     """output columns per partial of the fused-norm producer for this shape; 0 = not covered (use the stand-alone norm)"""
     c = C.c_int(0)
@@ -307,6 +322,14 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tens
     return out
 
 
+def layernorm16(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, d: int, eps: float) -> torch.Tensor:
+    """LayerNorm of 16-bit rows into 16-bit rows of the same type (vitg_layernorm16)"""
+    _req(x); _req(out, x.dtype)
+    _lib.call("vitg_layernorm16", _ptr(x), x.stride(0), _ptr(_req(w, torch.float32)), _ptr(_req(b, torch.float32)), _ptr(out), out.stride(0),
+              dt_code(x.dtype), x.shape[0], d, float(eps), _stream())
+    return out
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, d: int, eps: float) -> torch.Tensor:
     _req(x, torch.float32)
     _lib.call("vitg_rmsnorm", _ptr(x), x.stride(0), _ptr(_req(w, torch.float32)), _ptr(out), out.stride(0),
@@ -349,6 +372,14 @@ def bilinear_pool(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d
         _req(cmap, torch.int32)
     _lib.call("vitg_bilinear_pool", _ptr(x), x.stride(0), _ptr(out), out.stride(0), T, G, HW, d, dt_code(out.dtype), _ptr(cmap), pc,
               _stream())
+    return out
+
+
+def bilinear_pool16(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d: int, cmap: Optional[torch.Tensor] = None,
+                    pc: int = 0) -> torch.Tensor:
+    """bilinear_pool on 16-bit features (vitg_bilinear_pool16)"""
+    _req(x); _req(out, x.dtype)
+    _lib.call("vitg_bilinear_pool16", _ptr(x), x.stride(0), _ptr(out), out.stride(0), T, G, HW, d, dt_code(x.dtype), _ptr(cmap), pc, _stream())
     return out
 
 

@@ -8,9 +8,16 @@ dispatcher, functionalisation and ``torch.compile`` see which buffers an op writ
 output shapes so the ops trace without running.  There is deliberately NO CPU registration: calling an op on host tensors
 raises ``NotImplementedError`` from the dispatcher (the product has no CPU path).
 
+Aliasing: the engine passes ``res`` aliasing ``out`` (x = a @ w.T + x) to gemm / gemm_fp8 / gemm_fp8_mx / gemm_res16; only ``out`` carries
+the mutation annotation, so under functionalisation (``torch.compile``, ``torch.func.functionalize``) an aliased ``res`` could be read
+from a stale clone.  These ops are therefore **eager-only contracts with Meta kernels for shape tracing**: the product never compiles
+or functionalises them (it captures HIP graphs of the eager launches instead), and ``tests/test_torch_ops.py`` pins the eager
+aliasing behaviour.
+
 ``SelectorEngine`` launches through this module (``videoitg_amd.engine.K``); ``videoitg_amd.ops`` stays the raw binding.
 Names are the build's choice: patchify, gemm, layernorm, rmsnorm, rope_, attention, bilinear_pool,
-gather_rows, embed_gather, pool_score, rank, preprocess_u8, bce_loss, quant_rows_fp8, norm_quant_fp8, gemm_fp8, gemm_fp8_mx.
+gather_rows, embed_gather, pool_score, rank, preprocess_u8, bce_loss, quant_rows_fp8, norm_quant_fp8, gemm_fp8, gemm_fp8_mx,
+gemm_res16 / layernorm16 / bilinear_pool16 (the tower's 16-bit residual stream).
 """
 from __future__ import annotations
 
@@ -46,6 +53,11 @@ _def("gemm(Tensor a, Tensor w, Tensor(a!) out, int mode, int? n=None, Tensor? bi
          (_raw.gemm(a, w, out, mode=mode, n=n, bias=bias, act=act, res=res, res_mod=res_mod, m=m), None)[1],
      lambda a, w, out, mode, n=None, bias=None, act=0, res=None, res_mod=0, m=None: None)
 
+_def("gemm_res16(Tensor a, Tensor w, Tensor(a!) out, Tensor? bias=None, Tensor? res16=None, Tensor? res32=None, int res_mod=0) -> ()",
+     lambda a, w, out, bias=None, res16=None, res32=None, res_mod=0:
+         (_raw.gemm_res16(a, w, out, bias=bias, res16=res16, res32=res32, res_mod=res_mod), None)[1],
+     lambda *a, **k: None)
+
 _def("gemm_splitk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int splits, Tensor? bias=None, Tensor? res=None) -> ()",
      lambda a, w, out, workspace, splits, bias=None, res=None: (_raw.gemm_splitk(a, w, out, workspace, splits, bias=bias, res=res), None)[1],
      lambda *a, **k: None)
@@ -69,6 +81,8 @@ if _raw._lib.PROFILING:
 # ---- norms / rope ----------------------------------------------------------------------------------------------------------
 _def("layernorm(Tensor x, Tensor w, Tensor b, Tensor(a!) out, int d, float eps) -> ()",
      lambda x, w, b, out, d, eps: (_raw.layernorm(x, w, b, out, d, eps), None)[1], lambda x, w, b, out, d, eps: None)
+_def("layernorm16(Tensor x, Tensor w, Tensor b, Tensor(a!) out, int d, float eps) -> ()",
+     lambda x, w, b, out, d, eps: (_raw.layernorm16(x, w, b, out, d, eps), None)[1], lambda x, w, b, out, d, eps: None)
 _def("rmsnorm(Tensor x, Tensor w, Tensor(a!) out, int d, float eps) -> ()",
      lambda x, w, out, d, eps: (_raw.rmsnorm(x, w, out, d, eps), None)[1], lambda x, w, out, d, eps: None)
 _def("rope_(Tensor(a!) qkv, Tensor cos, Tensor sin, int heads, int head_dim) -> ()",
@@ -89,6 +103,9 @@ _def("attention(Tensor q, Tensor k, Tensor v, Tensor(a!) o, int batch, int heads
 # ---- pooling / gathers / head ------------------------------------------------------------------------------------------------
 _def("bilinear_pool(Tensor x, Tensor(a!) out, int T, int G, int HW, int d, Tensor? cmap=None, int pc=0) -> ()",
      lambda x, out, T, G, HW, d, cmap=None, pc=0: (_raw.bilinear_pool(x, out, T, G, HW, d, cmap, pc), None)[1],
+     lambda *a, **k: None)
+_def("bilinear_pool16(Tensor x, Tensor(a!) out, int T, int G, int HW, int d, Tensor? cmap=None, int pc=0) -> ()",
+     lambda x, out, T, G, HW, d, cmap=None, pc=0: (_raw.bilinear_pool16(x, out, T, G, HW, d, cmap, pc), None)[1],
      lambda *a, **k: None)
 _def("gather_rows(Tensor src, Tensor idx, int rows_per_batch, int batch, Tensor(a!) out, int width) -> ()",
      lambda src, idx, rows_per_batch, batch, out, width: (_raw.gather_rows(src, idx, rows_per_batch, batch, out, width), None)[1],
@@ -199,6 +216,21 @@ class _Namespace:
         return out
 
     @staticmethod
+    def bilinear_pool16(x, out, T, G, HW, d, cmap=None, pc=0):
+        _ops.bilinear_pool16(x, out, T, G, HW, d, cmap, pc)
+        return out
+
+    @staticmethod
+    def gemm_res16(a, w, out, *, bias=None, res16=None, res32=None, res_mod=0):
+        _ops.gemm_res16(a, w, out, bias, res16, res32, res_mod)
+        return out
+
+    @staticmethod
+    def layernorm16(x, w, b, out, d, eps):
+        _ops.layernorm16(x, w, b, out, d, eps)
+        return out
+
+    @staticmethod
     def gather_rows(src, idx, rows_per_batch, batch, out, width):
         _ops.gather_rows(src, idx, rows_per_batch, batch, out, width)
         return out
@@ -250,4 +282,5 @@ class _Namespace:
 
 K = _Namespace()
 OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
-                       "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx"]
+                       "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx",
+                       "gemm_res16", "layernorm16", "bilinear_pool16"]
