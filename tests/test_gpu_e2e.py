@@ -465,3 +465,61 @@ def test_residual16_tower_stream_matches_reference_golden(golden_dir, name):
         ref = torch.from_numpy(z[f"logits{b}"])
         assert got[b].shape == ref.shape
         assert (torch.sigmoid(got[b]) - torch.sigmoid(ref)).abs().max().item() <= tol
+
+
+def _rccl_worker(rank, world, frames, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    from videoitg_amd.parallel import ContextParallel
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        cfg = tiny_config(vision_token_num=72)
+        sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+        eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, dev))
+        pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).to(dev)
+        ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
+        cp = ContextParallel(rank, world)
+        fr = cp.local_frames(frames)
+        a = cp.forward(eng, ids, pix[fr.start:fr.stop].clone(), total_frames=frames)
+        b = cp.forward(eng, ids, pix[fr.start:fr.stop].clone(), total_frames=frames)     # asynchronous exchanges: must be repeatable
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        if rank == 0:
+            q.put(a.float().cpu())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the one-GPU boxes run the "
+                                                           "same plan over gloo, test_context_parallel_multi_rank_on_one_gpu)")
+@pytest.mark.parametrize("world,frames", [(2, 9), (2, 8)])
+def test_context_parallel_over_rccl(world, frames):
+    """One rank per GPU over RCCL: K|V written in place into the gather buffer, the all-gather launched asynchronously under the Q
+    projection, ragged shards (9 frames / 2 ranks, prompt tokens on the first and last rank).  Runs the moment a multi-GPU box exists;
+    logits must equal the single-rank forward (same arithmetic per token)."""
+    import torch.multiprocessing as mp
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, frames, 29600 + frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, p.exitcode
+    cfg = tiny_config(vision_token_num=72)
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
+    want = eng.forward(torch.tensor([[11, 12, -200, 5, 6, 7]]), None, [pix])[0].view(-1).float().cpu()
+    assert (got - want).abs().max().item() <= 1e-5

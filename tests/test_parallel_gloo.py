@@ -109,3 +109,40 @@ def test_context_parallel_matches_single_process(tmp_path, world, ids, T):
     want = O.forward(cfg, sd, vsd, ids_t.unsqueeze(0), None, [pix])[0].view(-1)
     assert got.shape == want.shape
     assert (got - want).abs().max().item() < 2e-4
+
+
+def _split_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = make_plan(world, 7, 3, 2, 4)                       # ragged: 7 frames / world ranks, text on the first and last rank
+    g = RowGatherer(plan, rank)
+    c = 6
+    res = []
+    for it in range(2):                                        # second pass: cached buffers, in-place collective again
+        rows = g.local_rows(c, torch.float32, "cpu")
+        assert rows.shape == (plan.n_local[rank], c)
+        base = plan.offset[rank]
+        rows.copy_((torch.arange(plan.n_local[rank] * c, dtype=torch.float32).view(-1, c) + 1000 * (base + it)))
+        allr = g.finish(g.start())
+        res.append(allr.clone())
+        # and the copying form gives the same rows
+        assert torch.equal(g(rows.clone()), allr)
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_gatherer_split_api_in_place(tmp_path, world):
+    """local_rows() / start() / finish(): the producer writes straight into its slot of the receive buffer and the collective runs in
+    place (what the context-parallel layers do so that the exchange overlaps the Q projection)"""
+    out = str(tmp_path / "rows.pt")
+    mp.spawn(_split_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = torch.load(out)
+    plan = make_plan(world, 7, 3, 2, 4)
+    for it, allr in enumerate(res):
+        assert allr.shape == (plan.total, 6)
+        for r in range(world):
+            want = torch.arange(plan.n_local[r] * 6, dtype=torch.float32).view(-1, 6) + 1000 * (plan.offset[r] + it)
+            assert torch.equal(allr[plan.offset[r]:plan.offset[r] + plan.n_local[r]], want)

@@ -25,9 +25,21 @@ pix = (torch.rand((len(fr), 3, R, R), device=dev) * 2 - 1).half()
 kvw = 2 * cfg.num_key_value_heads * cfg.head_dim
 kv_all = torch.randn((plan.total, kvw), device=dev).half()
 
-def gather(local):
-    kv_all[plan.offset[rank]:plan.offset[rank] + local.shape[0]].copy_(local)
-    return kv_all
+class NoCommGatherer:
+    """the split API of parallel.RowGatherer without a collective: this rank's K|V rows are written in place into the full buffer
+    (random rows stand for the other ranks'), start() / finish() cost nothing - what is measured is one rank's COMPUTE, including
+    the K|V-first / Q split of the QKV projection that the overlap needs"""
+    def local_rows(self, c, dtype, device):
+        return kv_all[plan.offset[rank]:plan.offset[rank] + plan.n_local[rank]]
+    def start(self):
+        return None
+    def finish(self, work, producer_stream=None):
+        if producer_stream is not None:
+            torch.cuda.current_stream().wait_stream(producer_stream)
+        return kv_all
+
+
+gather = NoCommGatherer()
 
 def step():
     feats, _, cmap, pc = eng.vit_forward(pix, hw)

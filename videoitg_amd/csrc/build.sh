@@ -17,9 +17,12 @@ if [ "${1:-}" = "--profiling" ]; then
   OBJ="$HERE/build_prof"
   DEFS="-DVITG_PROFILING_BUILD=1"
 fi
+# VITG_CLEAN=1: compile every source from scratch (the default reuses objects newer than their sources and shared headers)
+if [ "${VITG_CLEAN:-0}" != "0" ]; then rm -rf "$OBJ" "$OUT"; fi
 mkdir -p "$OBJ"
 pids=()
 objs=()
+compiled=""; reused=""
 for f in $SRCS; do
   src="$HERE/$f.hip"; obj="$OBJ/$f.o"
   [ -f "$src" ] || continue
@@ -27,8 +30,12 @@ for f in $SRCS; do
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/gemm_common.h" -nt "$obj" ] || [ "$HERE/attn_common.h" -nt "$obj" ] || [ "$HERE/../../include/videoitg_hip.h" -nt "$obj" ]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC $DEFS -c "$src" -o "$obj" "$@" &
     pids+=($!)
+    compiled="$compiled $f"
+  else
+    reused="$reused $f"
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
+echo "compiled:${compiled:- (none)}  reused:${reused:- (none)}"
 echo "built $OUT"

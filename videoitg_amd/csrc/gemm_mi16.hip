@@ -27,11 +27,15 @@
 namespace vitg {
 
 constexpr int G16_THREADS = 512;
+constexpr int MODE_RES16 = 3;      // internal: MODE_STORE16 with a residual preloaded into the accumulators (vitg_gemm_res16).  Its own instantiation:
+                                   // compiled into the plain 16-bit-output kernels the preload cost the wide tiles 15-20 spilled registers
 
 template <typename T, int MODE, int BM, int BN>
 __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     typedef typename T16<T>::vec8 vec8;
     GemmArgs g = g_;
+    constexpr bool RES16 = MODE == MODE_RES16;
+    constexpr int EMODE = RES16 ? MODE_STORE16 : MODE;   // epilogue form
     if constexpr (MODE == MODE_F32) {
         if (g.split_k > 1) {                              // split-K: block y takes its own K range into its own partial buffer (gemm256.hip)
             const int sp = blockIdx.y;
@@ -100,15 +104,14 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     const int r16 = lane & 15, fq = lane >> 4;
     // Accumulators: zero, or - fp32 residual update without activation - the residual tile itself (the read half of the
     // read-modify-write then overlaps the main loop; these loads are older than every DMA in the vmcnt queue)
-    // (MODE_STORE16 with a residual = vitg_gemm_res16: the 16-bit residual stream of the tower, or the fp32 position table)
-    const bool acc_from_res = (MODE == MODE_F32 || MODE == MODE_STORE16) && (g.res != nullptr || (MODE == MODE_STORE16 && g.res16 != nullptr)) &&
-                              g.act == VITG_ACT_NONE;
+    // (MODE_RES16 = vitg_gemm_res16: the 16-bit residual stream of the tower, or the fp32 position table, into a 16-bit output)
+    const bool acc_from_res = (MODE == MODE_F32 && g.res != nullptr && g.act == VITG_ACT_NONE) || RES16;
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (MODE == MODE_F32 || MODE == MODE_STORE16) {
+    if constexpr (MODE == MODE_F32 || RES16) {
         if (acc_from_res) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                     const int n = n0 + wc * (NT * 16) + nt * 16 + fq * 4;
                     if (m < g.M && n < g.N) {
                         if (g.res) acc[nt][mt] = *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
-                        if constexpr (MODE == MODE_STORE16) {
+                        if constexpr (RES16) {
                             if (g.res16) {
                                 const typename T16<T>::vec4 r = *(const typename T16<T>::vec4*)((const T*)g.res16 + (size_t)m * g.ldr16 + n);
 #pragma unroll
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     // ---- epilogue: 32 rows (two accumulator row-tiles) at a time through a wave-private LDS window -> full-row 16-B stores -------
     __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring before it is reused
     const int mw = m0 + wr * (MT * 16), nw = n0 + wc * (NT * 16);
-    if constexpr (MODE == MODE_F32) {
+    if constexpr (EMODE == MODE_F32) {
         constexpr int CH = NT * 4;                        // 16-B chunks (4 floats) per row: 16 or 24
         constexpr int RB = NT * 64;
         constexpr int SWZ = (CH & -CH) - 1;               // 15 or 7
@@ -246,23 +249,15 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
             }
         }
     } else {
-        constexpr int NTO = MODE == MODE_SWIGLU ? NT / 2 : NT;        // output 16-column tiles per wave
+        constexpr int NTO = EMODE == MODE_SWIGLU ? NT / 2 : NT;        // output 16-column tiles per wave
         constexpr int CH = NTO * 2;                                   // 16-B chunks (8 halfs) per row: 4, 8 or 12
         constexpr bool POW2 = (CH & (CH - 1)) == 0;
         constexpr int RB = NTO * 32 + (POW2 ? 0 : 16);                // padded rows when the chunk count is not a power of two
         constexpr int SWZ = POW2 ? CH - 1 : 0;
         constexpr int SH = CH == 4 ? 2 : CH == 8 ? 1 : 0;             // XOR takes the row bits above those that already spread over 256 B
         char* const stage = smem + wave * (32 * RB);
-        const int n_out = MODE == MODE_SWIGLU ? nw / 2 : nw;
-        const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
-        f32x4 bv[NT];
-        if constexpr (MODE != MODE_SWIGLU) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = nw + nt * 16 + fq * 4;
-                bv[nt] = (g.bias && n < g.N) ? *(const f32x4*)(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
+        const int n_out = EMODE == MODE_SWIGLU ? nw / 2 : nw;
+        const int n_lim = EMODE == MODE_SWIGLU ? g.N / 2 : g.N;
 #pragma unroll
         for (int mp = 0; mp < MT / 2; ++mp) {
 #pragma unroll
@@ -270,12 +265,14 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
 #pragma unroll
                 for (int nt = 0; nt < NTO; ++nt) {
                     f32x4 v;
-                    if constexpr (MODE == MODE_SWIGLU) {
+                    if constexpr (EMODE == MODE_SWIGLU) {
                         // weight rows are interleaved [32 gate | 32 up] (engine.pack_llm_layer): tiles 0-1 gate, 2-3 up of the wave's 64 features
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[nt][mp * 2 + h][e]) * acc[nt + NT / 2][mp * 2 + h][e];
                     } else {
-                        v = acc[nt][mp * 2 + h] + bv[nt];
+                        v = acc[nt][mp * 2 + h];
+                        const int nb = nw + nt * 16 + fq * 4;      // (bias re-read per row pair from L1 instead of NT quads held over the epilogue)
+                        if (g.bias && nb < g.N) v += *(const f32x4*)(g.bias + nb);
                         if (g.act == VITG_ACT_GELU_TANH) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
@@ -351,6 +348,7 @@ static int launch16_m(const GemmArgs& g, int cfg, hipStream_t s) {
 
 template <typename T>
 static int launch16_t(const GemmArgs& g, int mode, int cfg, hipStream_t s) {
+    if (mode == MODE_STORE16 && (g.res || g.res16)) return launch16_m<T, MODE_RES16>(g, cfg, s);
     if (mode == MODE_SWIGLU) return launch16_m<T, MODE_SWIGLU>(g, cfg, s);
     if (mode == MODE_F32) return launch16_m<T, MODE_F32>(g, cfg, s);
     return launch16_m<T, MODE_STORE16>(g, cfg, s);

@@ -265,6 +265,7 @@ class SelectorEngine:
         self._ws: Dict[str, torch.Tensor] = {}
         self._poolsrc: Dict[tuple, object] = {}
         self._splitk: Dict[tuple, tuple] = {}        # (M, N, K) -> (splits, workspace bytes) from vitg_gemm_splitk_plan
+        self._side: Optional[torch.cuda.Stream] = None   # context-parallel layers: K|V projection + exchange run here, under the Q projection
 
     # workspace: ONE buffer per name, grown to the largest row count seen and handed out as a [:rows] view, so a run over
     # documents with varying prompt lengths / frame counts holds max-size buffers instead of one set per distinct shape.
@@ -552,18 +553,38 @@ class SelectorEngine:
         pend = None                                       # layer 0 normalises the assembled embeddings with the stand-alone kernel
         fuse = kv_gather is None                          # (the context-parallel ranks take the split-K path for o / down instead)
         for li, lw in enumerate(w.llm):
-            if pend is not None:
-                K.gemm_norm_consumer(pend[0], lw.qkv_w, qkv, mode=K.GEMM_STORE16, stats=pend[1], bias=lw.qkv_b)
-            else:
+            if kv_gather is not None and hasattr(kv_gather, "local_rows"):
+                # context-parallel rank: K|V FIRST, written straight into this rank's slot of the gather buffer, RoPE on the
+                # K heads, exchange launched - all on a side stream - while the main stream runs the Q projection and its RoPE; the
+                # attention then waits for the exchange only.  (K|V: 28 - 56 output tiles, Q: 98 at M = 1660 - the two GEMMs share the CUs.)
                 h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps)
-                self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
-            K.rope_(qkv, cos, sin, nq + nkv, hd)
+                kcol = nq * hd
+                kv_local = kv_gather.local_rows(kvw, self.dtype, self.device)
+                main = torch.cuda.current_stream(self.device)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(main)                              # h is ready; the previous layer's attention is done with the buffer
+                with torch.cuda.stream(self._side):
+                    self._gemm(h, lw.qkv_w[kcol:], kv_local, mode=K.GEMM_STORE16, bias=lw.qkv_b[kcol:])
+                    K.rope_(kv_local, cos, sin, nkv, hd)
+                    work = kv_gather.start()
+                self._gemm(h, lw.qkv_w[:kcol], qkv[:, :kcol], mode=K.GEMM_STORE16, bias=lw.qkv_b[:kcol])
+                K.rope_(qkv, cos, sin, nq, hd)
+                kv = kv_gather.finish(work, self._side)                   # [total, 2*nkv*hd]: K heads then V heads per row
+            else:
+                if pend is not None:
+                    K.gemm_norm_consumer(pend[0], lw.qkv_w, qkv, mode=K.GEMM_STORE16, stats=pend[1], bias=lw.qkv_b)
+                else:
+                    h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps)
+                    self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
+                K.rope_(qkv, cos, sin, nq + nkv, hd)
+                if kv_gather is not None:                                 # (a plain callable: gathers the local K|V rows, blocking)
+                    kv = kv_gather(qkv[:, nq * hd:])
             if kv_gather is None:
                 K.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
                             head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
                             o_strides=(0, op, hd), scale=scale, variant=self.attn_variant, kv_len=kv_len)
             else:
-                kv = kv_gather(qkv[:, nq * hd:])                 # [total, 2*nkv*hd]: K heads then V heads per row
                 K.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
                             head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, kvw, hd), v_strides=(0, kvw, hd),
                             o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)

@@ -61,38 +61,78 @@ def make_plan(world: int, T: int, tokens_per_frame: int, n_pre: int, n_post: int
 
 
 class RowGatherer:
-    """all-gather of a ragged row-sharded matrix: rank r contributes rows [offset_r, offset_r + n_r)."""
+    """all-gather of a ragged row-sharded matrix: rank r contributes rows [offset_r, offset_r + n_r).
+
+    Two ways to use it.  ``gather(local)`` copies `local` into the send slot and gathers (what the CPU tests and round 2 used).  The
+    engine's context-parallel layers use the split form so that the exchange runs UNDER compute (SURVEY.md 8e "overlap it with the
+    Q-projection"): ``rows = local_rows(c, dtype, device)`` is this rank's slot INSIDE the receive buffer - the K|V projection writes its
+    output there (no staging copy; the collective is the in-place form send == recv[rank]) - then ``w = start()`` launches the
+    all-gather (RCCL: asynchronous, ordered after the work already queued on the current stream) and ``finish(w)`` makes the current
+    stream wait for it and returns all rows (ragged shards: ONE gather-rows launch compacts the padded receive buffer)."""
 
     def __init__(self, plan: ShardPlan, rank: int, group=None):
         self.plan, self.rank, self.group = plan, rank, group
         self.n_max = max(plan.n_local)
         self.even = len(set(plan.n_local)) == 1
-        self._send = self._recv = self._out = self._idx = None
+        self._recv = self._out = self._idx = None
+        self._async = None
 
-    def __call__(self, local: torch.Tensor) -> torch.Tensor:
+    def _ensure(self, c: int, dtype, device) -> None:
         p = self.plan
-        n, c = local.shape
-        assert n == p.n_local[self.rank]
-        if self._send is None or self._send.shape[1] != c or self._send.dtype != local.dtype:
-            self._send = torch.zeros((self.n_max, c), dtype=local.dtype, device=local.device)
-            self._recv = torch.empty((p.world * self.n_max, c), dtype=local.dtype, device=local.device)
-            self._out = self._recv if self.even else torch.empty((p.total, c), dtype=local.dtype, device=local.device)
-        self._send[:n].copy_(local)
-        dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+        if self._recv is None or self._recv.shape[1] != c or self._recv.dtype != dtype or self._recv.device != torch.device(device):
+            self._recv = torch.zeros((p.world * self.n_max, c), dtype=dtype, device=device)
+            self._out = self._recv if self.even else torch.empty((p.total, c), dtype=dtype, device=device)
+            self._idx = None
+
+    def local_rows(self, c: int, dtype, device) -> torch.Tensor:
+        """[n_local, c] view of this rank's slot in the receive buffer: write the local rows here, then start()"""
+        self._ensure(c, dtype, device)
+        return self._recv[self.rank * self.n_max:self.rank * self.n_max + self.plan.n_local[self.rank]]
+
+    def _slot(self) -> torch.Tensor:
+        return self._recv[self.rank * self.n_max:(self.rank + 1) * self.n_max]
+
+    def start(self):
+        """launch the exchange; returns a handle for finish().  RCCL ("nccl") runs it asynchronously on its own stream, ordered behind
+        the current stream; other backends (gloo in the CPU / one-GPU tests) exchange in finish()."""
+        if self._async is None:
+            self._async = dist.get_backend(self.group) == "nccl"
+        if self._async:
+            return dist.all_gather_into_tensor(self._recv, self._slot(), group=self.group, async_op=True)
+        return None
+
+    def finish(self, work, producer_stream=None) -> torch.Tensor:
+        if work is not None:
+            work.wait()                                     # the CURRENT stream waits for the collective; the host does not block
+        else:
+            if producer_stream is not None and self._recv.is_cuda:
+                torch.cuda.current_stream(self._recv.device).wait_stream(producer_stream)
+            dist.all_gather_into_tensor(self._recv, self._slot(), group=self.group)
+        return self._compact()
+
+    def _compact(self) -> torch.Tensor:
+        p = self.plan
         if self.even:
             return self._recv
-        if local.is_cuda:
+        c = self._recv.shape[1]
+        if self._recv.is_cuda:
             # ragged shards (the prompt tokens sit on the first / last rank): ONE gather-rows launch compacts the padded
             # receive buffer instead of `world` slice copies
             from .torch_ops import K as ops
             if self._idx is None:
                 idx = torch.cat([torch.arange(p.n_local[r], dtype=torch.int32) + r * self.n_max for r in range(p.world)])
-                self._idx = idx.to(local.device)
+                self._idx = idx.to(self._recv.device)
             ops.gather_rows(self._recv, self._idx, 0, 1, self._out, c)
             return self._out
         for r in range(p.world):
             self._out[p.offset[r]:p.offset[r] + p.n_local[r]].copy_(self._recv[r * self.n_max:r * self.n_max + p.n_local[r]])
         return self._out
+
+    def __call__(self, local: torch.Tensor) -> torch.Tensor:
+        n, c = local.shape
+        assert n == self.plan.n_local[self.rank]
+        self.local_rows(c, local.dtype, local.device).copy_(local)
+        return self.finish(self.start())
 
 
 def gather_logits(local: torch.Tensor, plan: ShardPlan, rank: int, group=None) -> torch.Tensor:
