@@ -345,6 +345,7 @@ def main():
     timer = GemmTimer()
     ops.gemm = timer.wrap(ops.gemm)
     ops.gemm_splitk = timer.wrap(ops.gemm_splitk)       # (the o / down projections of a context-parallel rank; includes their reduce kernel)
+    ops.gemm_res16 = timer.wrap(ops.gemm_res16)         # (patch embedding, out-proj and fc2 of the tower on its 16-bit residual stream)
     timer8 = GemmTimer()                                # --fp8: the layer GEMMs run here; patch-embed / projector stay on ops.gemm
     if args.fp8:
         ops.gemm_fp8 = timer8.wrap(ops.gemm_fp8)
@@ -451,7 +452,8 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"frame-sharded tower + context-parallel LLM x{world}",
                        "algorithmic_tflop_per_video": round(fl["total"] / 1e12, 1)},
             "end_to_end_tflops": round(fl["total"] / (dt / args.steps) / 1e12, 1),
-            "roofline": {"kernel": "gemm256_kernel (all GEMM launches of the step)", "bound": "mfma", "achieved": round(achieved, 1),
+            "roofline": {"kernel": "gemm16_kernel = the 256x256 / 256x384 / 384x256 tiles on v_mfma_f32_16x16x32 (all GEMM launches of the step)",
+                         "bound": "mfma", "achieved": round(achieved, 1),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "traffic": traffic, "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": round(per_launch_flops / 1e12, 4), "achieved_algorithmic": round(achieved_alg, 1),
@@ -580,6 +582,32 @@ def main():
                                           "algorithmic_tflop_per_video": round(fl0["total"] / 1e12, 1),
                                           "parity": parity_block(T, 384, args.prompt_len, args.seed, b0["logits"], b0["order"])}
             del pix0
+            # the tower's residual stream.  The default runs it in fp16 (the reference's own arithmetic, model.half():
+            # one rounding per residual update, fp32 accumulation inside the epilogue); this is the fp32-stream alternative of rounds 1-2
+            # on the same engine, with its parity block - `residual16` restates the default's numbers beside it.
+            out["secondary"]["residual16"] = {"is_default": bool(eng.residual16), "value": out["value"], "unit": "frames/s",
+                                              "ms_per_step": out["ms_per_step"], "parity": out["parity"],
+                                              "what": "SigLIP tower residual stream in fp16 (vitg_gemm_res16 / vitg_layernorm16); decoder stream fp32"}
+            r16_was = eng.residual16
+            eng.residual16 = not r16_was
+            oo = {}
+
+            def step_r():
+                oo["logits"] = eng.forward(ids, None, [pix])[0].view(-1)
+                _, order_ = ops.rank(oo["logits"])
+                oo["order"] = order_.cpu().tolist()
+            step_r()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            step_r()
+            step_r()
+            torch.cuda.synchronize()
+            d3 = (time.perf_counter() - t3) / 2
+            out["secondary"]["residual_fp32" if r16_was else "residual16_alt"] = {
+                "value": round(T / d3, 2), "unit": "frames/s", "ms_per_step": round(d3 * 1e3, 2),
+                "parity": parity_block(T, R, args.prompt_len, args.seed, oo["logits"], oo["order"]),
+                "what": "the other residual-stream width of the tower on the same engine and weights"}
+            eng.residual16 = r16_was
             # the other 16-bit type on the same workload: bf16 is what BASELINE.json's configuration names, fp16 what the reference
             # itself runs (model.half()); both go through the same kernels
             eng.release_workspace()

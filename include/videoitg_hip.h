@@ -48,7 +48,8 @@ int vitg_device_info(char* name, int name_len);
  *   gemm_cfg    2 256x128x32 (2 blocks/CU; small-M shapes) | 6 256x256x64 phased | 9 256x384 (fp32-residual shapes) |
  *               10 384x256 (SwiGLU, 16-bit outputs); anything else = 6.  Auto mode picks per shape (gemm256.hip: choose_cfg)
  *   gemm_group  M-tiles per group of the XCD-aware tile order (default 4)
- *   gemm_mi     MFMA shape of the 256x256 / 256x384 / 384x256 tiles: 16 v_mfma_f32_16x16x32 (gemm_mi16.hip) | 32 v_mfma_f32_32x32x16 (gemm256.hip)
+ *   gemm_mi     MFMA shape of the 256x256 / 256x384 / 384x256 tiles: 16 v_mfma_f32_16x16x32 (gemm_mi16.hip, the default) | 32 v_mfma_f32_32x32x16
+ *               (gemm256.hip);  gemm_mi_modes  bit mask of epilogue modes on the 16x16x32 kernels (A/B);  gemm_pref  forced tile shape per mode (A/B)
  *   gemm_flags  bit8 wide tiles off, bits 11-14 cost-model A/B switches, bit24 one hardware block per tile instead of one block per CU walking the tile list (the default for long tile lists)
  *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
  *   attn_ab     1 | 2  half-tile-out-of-phase hd-72 kernel on / off (default on)

@@ -80,8 +80,10 @@ def test_workspace_buffers_are_name_keyed_views():
     assert c.shape == (20, 8) and eng.workspace_bytes() == 20 * 8 * 4 and len(eng.workspace_tensors()) == 1
     d = eng._buf("s", (7,), torch.float32)
     assert d.shape == (7,) and len(eng.workspace_tensors()) == 2
-    assert eng._part_fp8("vit_h") is False
-    W.fp8 = "vit"
-    assert eng._part_fp8("vit_h") and not eng._part_fp8("llm_h")
-    W.fp8 = True
-    assert eng._part_fp8("llm_f")
+    # the fp8 selector: parts, single GEMMs, everything (PackedWeights.fp8_on / fp8_part decide per layer GEMM)
+    from videoitg_amd.engine import FP8_GEMMS, PackedWeights, normalise_fp8
+    assert normalise_fp8("vit") == frozenset(g for g in FP8_GEMMS if g.startswith("vit."))
+    assert normalise_fp8("vit,llm") is True and normalise_fp8(list(FP8_GEMMS)) is True
+    pw = PackedWeights(cfg=None, dtype=torch.float16, device=torch.device("cpu"), fp8="vit.fc1,llm.gu,llm.down")
+    assert pw.fp8_on("vit.fc1") and not pw.fp8_on("vit.fc2") and pw.fp8_part("vit") and pw.fp8_part("llm") and not pw.fp8_on("llm.o")
+    assert not PackedWeights(cfg=None, dtype=torch.float16, device=torch.device("cpu"), fp8="llm").fp8_part("vit")

@@ -32,7 +32,7 @@ def test_fp8_selector_is_normalised():
     import numpy as np
     assert normalise_fp8(True) is True and normalise_fp8(1) is True and normalise_fp8(np.bool_(True)) is True
     assert normalise_fp8(False) is False and normalise_fp8(0) is False and normalise_fp8(None) is False
-    assert normalise_fp8("vit") == "vit" and normalise_fp8("llm") == "llm"
+    assert normalise_fp8("llm") == frozenset({"llm.qkv", "llm.o", "llm.gu", "llm.down"}) and normalise_fp8("vit.fc1") == frozenset({"vit.fc1"})
     for bad in ("both", "tower", 1.5, [1]):
         with pytest.raises(ValueError):
             normalise_fp8(bad)

@@ -22,14 +22,17 @@ def timeit(fn, n=5):
 
 shapes = [("vit_qkv +bias", 524288, 3456, 1152, 0, 0), ("vit_fc1 +bias+gelu", 524288, 4352, 1152, 0, ops.ACT_GELU_TANH), ("vit_out +res", 524288, 1152, 1152, 1, 0),
           ("vit_fc2 +res", 524288, 1152, 4352, 1, 0), ("llm_qkv +bias", 12860, 4608, 3584, 0, 0), ("llm_o +res", 12860, 3584, 3584, 1, 0),
-          ("llm_gu swiglu", 12860, 37888, 3584, 2, 0), ("llm_down +res", 12860, 3584, 18944, 1, 0), ("8192^3", 8192, 8192, 8192, 0, 0)]
+          ("llm_gu swiglu", 12860, 37888, 3584, 2, 0), ("llm_down +res", 12860, 3584, 18944, 1, 0), ("8192^3", 8192, 8192, 8192, 0, 0),
+          ("vit_out +res16", 524288, 1152, 1152, 3, 0), ("vit_fc2 +res16", 524288, 1152, 4352, 3, 0)]      # mode 3 = vitg_gemm_res16 (16x16x32 kernels only)
 for name, M, N, K, mode, act in shapes:
     a = torch.randn((M, K), device="cuda").to(dt)
     w = (torch.randn((N, K), device="cuda") * K ** -0.5).to(dt)
     bias = None if mode == 2 or ("res" in name and "vit" not in name) or name == "8192^3" else torch.randn(N, device="cuda") * 0.02
     res0 = torch.randn((M, N), device="cuda") if mode == 1 else None
     out = torch.zeros((M, N // 2 if mode == 2 else N), dtype=torch.float32 if mode == 1 else dt, device="cuda")
-    fn = lambda: ops.gemm(a, w, out, mode=mode, bias=bias, act=act, res=res0)
+    fn = (lambda: ops.gemm_res16(a, w, out, bias=bias, res16=out)) if mode == 3 else (lambda: ops.gemm(a, w, out, mode=mode, bias=bias, act=act, res=res0))
+    if mode == 3:
+        out.normal_()
     cfgs = [0, 6, 10] + ([9] if mode != 2 else [])
     t = {(c, mi): [] for c in cfgs for mi in (32, 16)}
     diff = 0.0

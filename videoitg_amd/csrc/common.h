@@ -92,7 +92,8 @@ struct Tuning {
                        // +6 % on the out-proj shape alone, nothing measurable in the step (profiles/r02_gemm_timeline.md): default off
     int gemm_group;    // gemm256: M-tiles per tile-order group (0 = default 4)
     int gemm_pref;     // A/B: forced tile shape per epilogue mode as three decimal digits <16-bit out><fp32 residual><SwiGLU>, digit 0 auto | 1 256x256 | 2 256x384 | 3 384x256
-    int gemm_mi;       // MFMA shape of the 256-tile GEMMs: 0 auto | 16 v_mfma_f32_16x16x32 (gemm_mi16.hip) | 32 v_mfma_f32_32x32x16 (gemm256.hip)
+    int gemm_mi;       // MFMA shape of the 256-tile GEMMs: 0 auto (= 16) | 16 v_mfma_f32_16x16x32 (gemm_mi16.hip) | 32 v_mfma_f32_32x32x16 (gemm256.hip)
+    int gemm_mi_modes; // A/B: epilogue modes that take the 16x16x32 kernels when gemm_mi selects them, bit0 16-bit output, bit1 fp32 residual, bit2 SwiGLU (0 = all)
     int attn_waves;    // 0 auto | 4 | 8
     int attn_pipe;     // 0 off (default) | 1 cross-tile pipelined hd-72 variant
     int attn_dma;      // 0 auto (DMA for hd 72, registers for hd 128) | 1 LDS-DMA K/V staging | 2 register staging

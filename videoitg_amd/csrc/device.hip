@@ -22,7 +22,7 @@ extern "C" int vitg_device_info(char* name, int name_len) {
 namespace vitg {
 static int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; }
 Tuning& tuning() {
-    static Tuning t = {env_int("VITG_GEMM_TILE"), env_int("VITG_GEMM_CFG"), env_int("VITG_GEMM_FLAGS"), env_int("VITG_GEMM_STAGGER"), env_int("VITG_GEMM_GROUP"), env_int("VITG_GEMM_PREF"), env_int("VITG_GEMM_MI"),
+    static Tuning t = {env_int("VITG_GEMM_TILE"), env_int("VITG_GEMM_CFG"), env_int("VITG_GEMM_FLAGS"), env_int("VITG_GEMM_STAGGER"), env_int("VITG_GEMM_GROUP"), env_int("VITG_GEMM_PREF"), env_int("VITG_GEMM_MI"), env_int("VITG_GEMM_MI_MODES"),
                        env_int("VITG_ATTN_WAVES"), env_int("VITG_ATTN_PIPE"), env_int("VITG_ATTN_DMA"), env_int("VITG_ATTN_AB"), env_int("VITG_ATTN_SP")};
     return t;
 }
@@ -38,6 +38,7 @@ extern "C" int vitg_set_option(const char* key, int value) {
     else if (!strcmp(key, "gemm_group")) t.gemm_group = value;
     else if (!strcmp(key, "gemm_mi")) t.gemm_mi = value;
     else if (!strcmp(key, "gemm_pref")) t.gemm_pref = value;
+    else if (!strcmp(key, "gemm_mi_modes")) t.gemm_mi_modes = value;
     else if (!strcmp(key, "attn_waves")) t.attn_waves = value;
     else if (!strcmp(key, "attn_pipe")) t.attn_pipe = value;
     else if (!strcmp(key, "attn_dma")) t.attn_dma = value;

@@ -879,6 +879,13 @@ bool gemm256_applicable(const GemmArgs& g, int mode) {
 //   cfg 10 384x256 (wave tile 192x64)          SwiGLU 1.07; 16-bit outputs 1.08 (fc1 / qkv: -3 % in an isolated loop but +1.3 % of the
 //                                              WHOLE step in alternating bench.py runs - the step decides); fp32-residual unusable (spills)
 // cfg 6 is kept unless another configuration is predicted at least 3 % faster.
+// MFMA shape of the three wide tiles: v_mfma_f32_16x16x32 (gemm_mi16.hip) unless gemm_mi = 32 asks for the 32x32x16 kernels of this file
+// (A/B, tests); gemm_mi_modes restricts it per epilogue mode (A/B)
+static bool gemm_mi16_selected(int mode) {
+    if (tuning().gemm_mi == 32) return false;
+    const int mm = tuning().gemm_mi_modes;
+    return mm == 0 || ((mm >> mode) & 1);
+}
 static int choose_cfg(const GemmArgs& g, int mode) {
     static int cus = 0;
     if (!cus) {
@@ -904,7 +911,12 @@ static int choose_cfg(const GemmArgs& g, int mode) {
     const double c2 = cost(256, 128, 0.65, 1);
     if (c2 < 0.97 * best) { best = c2; cfg = 2; }
     if (wide_ok && mode != MODE_SWIGLU && g.N >= 384) {
-        const double e = mode == MODE_F32 ? ((g.K >= 4096 || (tuning().gemm_flags & 8192)) ? 1.07 : 1.00) : ((tuning().gemm_flags & 2048) ? 0.90 : 1.00);   // flags bit11: A/B (16-bit outputs off the wide tile)
+        // residual updates (fp32 stream, or the 16-bit stream of vitg_gemm_res16) behave alike: the wide-N tile pays for K >= 4096 (fc2, down)
+        const bool resid = mode == MODE_F32 || (mode == MODE_STORE16 && (g.res || g.res16));
+        // 16-bit outputs on the 16x16x32 kernels: the 128x96 wave tile leads on the tower's qkv / fc1 (1142 / 1024 against 1096 / 1041 for
+        // 384x256 and 1042 / 994 for 256x256 TF/s, +0.7 % on the step over 384x256: profiles/r03_gemm_mi16.md)
+        const double e = resid ? ((g.K >= 4096 || (tuning().gemm_flags & 8192)) ? 1.07 : 1.00)
+                               : (gemm_mi16_selected(mode) ? 1.10 : ((tuning().gemm_flags & 2048) ? 0.90 : 1.00));   // flags bit11: A/B (16-bit outputs off the wide tile)
         const double c9 = cost(256, 384, e, 1);
         if (c9 < 0.97 * best) { best = c9; cfg = 9; }
     }
@@ -912,13 +924,13 @@ static int choose_cfg(const GemmArgs& g, int mode) {
         // fp32-residual GEMMs on the tall tile since the saddr addressing freed its registers (it used to spill): o-proj at M = 12860
         // +6 %, and at M = 6460 (two context-parallel ranks) o / down fit ONE round of 384x256 tiles: +24 % / +48 % (tools/gemm_small_m.py).
         // flags bit12: A/B (16-bit outputs off the tall tile); bit14: A/B (fp32-residual GEMMs off it)
-        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : mode == MODE_F32 ? 1.05 : ((tuning().gemm_flags & 4096) ? 0.96 : 1.08), 1);
+        const bool resid10 = mode == MODE_F32 || (mode == MODE_STORE16 && (g.res || g.res16));
+        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : resid10 ? 1.05 : (gemm_mi16_selected(mode) ? 1.05 : ((tuning().gemm_flags & 4096) ? 0.96 : 1.08)), 1);
         if (c10 < 0.97 * best) { best = c10; cfg = 10; }
     }
     return cfg;
 }
 
-static bool gemm_mi16_selected() { return tuning().gemm_mi == 16; }
 int gemm256_pick_cfg(const GemmArgs& g, int mode);
 
 template <typename T, int MODE, bool NRM = false>
@@ -936,7 +948,7 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
     // cap lets run 14 % faster than 32x32x16 on real operands (profiles/r03_mfma_shape.md)
     // (the residual forms of the 16-bit-output mode - vitg_gemm_res16 - exist in gemm_mi16.hip and the 128-tile kernel only; gemm_entry
     // never sends them here with the 256x128 tile)
-    if ((cfg == 6 || cfg == 9 || cfg == 10) && (gemm_mi16_selected() || (MODE == MODE_STORE16 && (g.res || g.res16))))
+    if ((cfg == 6 || cfg == 9 || cfg == 10) && (gemm_mi16_selected(MODE) || (MODE == MODE_STORE16 && (g.res || g.res16))))
         return launch_gemm_mi16(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, cfg, s);
 #if VITG_PROFILING_BUILD
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)

@@ -57,19 +57,35 @@ def _fuse_norm_enabled() -> bool:
     return _l.PROFILING and os.environ.get("VITG_FUSE_NORM", "0") not in ("", "0")
 
 
+FP8_GEMMS = ("vit.qkv", "vit.out", "vit.fc1", "vit.fc2", "llm.qkv", "llm.o", "llm.gu", "llm.down")
+
+
 def normalise_fp8(v) -> object:
-    """fp8 weight-path selector -> False | True | "vit" | "llm".  Truthy non-bool values (1, numpy.bool_, an env-parsed int) mean True,
-    falsy ones False; any other string or type is an error - a caller that believes it is on the fp8 tier must not silently get 16-bit
-    weights."""
-    if isinstance(v, str):
-        if v in ("vit", "llm"):
-            return v
-        raise ValueError(f"fp8 must be a bool, 'vit' or 'llm', not {v!r}")
+    """fp8 weight-path selector -> False | True | frozenset of GEMM names (FP8_GEMMS).  True = every layer GEMM, "vit" / "llm" = that
+    part's four, a comma-separated string or an iterable of names = exactly those (the per-GEMM precision policies of
+    profiles/r03_fp8_pareto.md).  Truthy non-bool scalars (1, numpy.bool_, an env-parsed int) mean True, falsy ones False; anything
+    else is an error - a caller that believes it is on the fp8 tier must not silently get 16-bit weights."""
     if v is None:
         return False
     if isinstance(v, (bool, int)) or type(v).__name__ in ("bool_", "bool"):
         return bool(v)
-    raise ValueError(f"fp8 must be a bool, 'vit' or 'llm', not {v!r}")
+    if isinstance(v, str):
+        names = [n.strip() for n in v.split(",") if n.strip()]
+    elif isinstance(v, (set, frozenset, list, tuple)):
+        names = list(v)
+    else:
+        raise ValueError(f"fp8 must be a bool, 'vit', 'llm' or GEMM names out of {FP8_GEMMS}, not {v!r}")
+    out = set()
+    for n in names:
+        if n in ("vit", "llm"):
+            out.update(g for g in FP8_GEMMS if g.startswith(n + "."))
+        elif n in FP8_GEMMS:
+            out.add(n)
+        else:
+            raise ValueError(f"fp8 must be a bool, 'vit', 'llm' or GEMM names out of {FP8_GEMMS}, not {v!r}")
+    if not out:
+        return False
+    return True if len(out) == len(FP8_GEMMS) else frozenset(out)
 
 
 @dataclass
@@ -130,12 +146,19 @@ class PackedWeights:
         cols = pad64(w.shape[1]) if cols is None else cols
         return _pad2(w, rows, cols).to(self._packing).contiguous()
 
-    def _wl(self, w: torch.Tensor, rows: Optional[int] = None):
+    def fp8_on(self, gemm: str) -> bool:
+        """is this layer GEMM (one of FP8_GEMMS) on the fp8 weight path?"""
+        return self.fp8 is True or (isinstance(self.fp8, frozenset) and gemm in self.fp8)
+
+    def fp8_part(self, part: str) -> bool:
+        """is ANY GEMM of this part ("vit" / "llm") on the fp8 weight path?"""
+        return any(self.fp8_on(g) for g in FP8_GEMMS if g.startswith(part + "."))
+
+    def _wl(self, w: torch.Tensor, rows: Optional[int] = None, gemm: str = ""):
         """weight of a tower / decoder layer GEMM: 16-bit, or - on the fp8 weight path - e4m3fn bytes + per-output-channel scales
         (quantised from the SAME 16-bit-rounded, zero-padded matrix the 16-bit path would multiply with)"""
         w16 = self._w16(w, rows)
-        part = "vit" if self._packing_part == "vit" else "llm"
-        if not (self.fp8 is True or self.fp8 == part):          # (normalised in __post_init__: False | True | "vit" | "llm")
+        if not self.fp8_on(gemm):                               # (fp8 normalised in __post_init__: False | True | frozenset of GEMM names)
             return w16
         w8, sw = K.quant_rows_fp8(w16, w16.shape[1], torch.empty((w16.shape[0], K.pad128(w16.shape[1])), dtype=torch.uint8, device=self.device),
                                   torch.empty(w16.shape[0], dtype=torch.float32, device=self.device))
@@ -163,11 +186,11 @@ class PackedWeights:
         self._packing, self._packing_part = self.vit_dtype, "vit"
         self.vit.append(VitLayerW(
             ln1_w=self._f32(vsd[p + "layer_norm1.weight"]), ln1_b=self._f32(vsd[p + "layer_norm1.bias"]),
-            qkv_w=self._wl(qkv_w), qkv_b=self._f32(qkv_b),
-            out_w=self._wl(vsd[p + "self_attn.out_proj.weight"]), out_b=self._f32(vsd[p + "self_attn.out_proj.bias"]),
+            qkv_w=self._wl(qkv_w, gemm="vit.qkv"), qkv_b=self._f32(qkv_b),
+            out_w=self._wl(vsd[p + "self_attn.out_proj.weight"], gemm="vit.out"), out_b=self._f32(vsd[p + "self_attn.out_proj.bias"]),
             ln2_w=self._f32(vsd[p + "layer_norm2.weight"]), ln2_b=self._f32(vsd[p + "layer_norm2.bias"]),
-            fc1_w=self._wl(vsd[p + "mlp.fc1.weight"], rows=fvp), fc1_b=self._f32(vsd[p + "mlp.fc1.bias"], fvp),
-            fc2_w=self._wl(vsd[p + "mlp.fc2.weight"]), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
+            fc1_w=self._wl(vsd[p + "mlp.fc1.weight"], rows=fvp, gemm="vit.fc1"), fc1_b=self._f32(vsd[p + "mlp.fc1.bias"], fvp),
+            fc2_w=self._wl(vsd[p + "mlp.fc2.weight"], gemm="vit.fc2"), fc2_b=self._f32(vsd[p + "mlp.fc2.bias"]),
         ))
         self._packing, self._packing_part = self.dtype, "llm"
         if _fuse_norm_enabled() and not isinstance(self.vit[-1].qkv_w, Fp8Weight):
@@ -206,11 +229,11 @@ class PackedWeights:
         gu = torch.cat([g, u], 1).reshape(2 * fp, -1)           # rows: [32 gate | 32 up] repeated
         self.llm.append(LlmLayerW(
             in_ln=self._f32(sd[p + "input_layernorm.weight"]),
-            qkv_w=self._wl(qkv_w), qkv_b=self._f32(qkv_b),
-            o_w=self._wl(sd[p + "self_attn.o_proj.weight"]),
+            qkv_w=self._wl(qkv_w, gemm="llm.qkv"), qkv_b=self._f32(qkv_b),
+            o_w=self._wl(sd[p + "self_attn.o_proj.weight"], gemm="llm.o"),
             post_ln=self._f32(sd[p + "post_attention_layernorm.weight"]),
-            gu_w=self._wl(gu),
-            down_w=self._wl(sd[p + "mlp.down_proj.weight"]),
+            gu_w=self._wl(gu, gemm="llm.gu"),
+            down_w=self._wl(sd[p + "mlp.down_proj.weight"], gemm="llm.down"),
         ))
 
     @staticmethod
@@ -252,11 +275,13 @@ class SelectorEngine:
         self.skip_dead_rows = True        # last tower layer only on the tokens the pool reads (see vit_forward)
         # 16-bit residual stream in the TOWER (round 3; vitg_gemm_res16 / vitg_layernorm16): the reference's own arithmetic (model.half()),
         # half the bytes of every LayerNorm read and out-proj / fc2 read-modify-write.  The decoder's stream stays fp32.
-        self.residual16 = os.environ.get("VITG_RES16", "0") not in ("", "0")
+        # Default since the gate held on every complete-pass fixture (max |dscore| 3.1e-4 against 1.5e-4 on the fp32 stream, Top-K sets
+        # identical, step -2.8 %: profiles/r03_residual16.md); VITG_RES16=0 / engine.residual16 = False restores the fp32 stream.
+        self.residual16 = os.environ.get("VITG_RES16", "1") not in ("", "0")
         # LayerNorm / RMSNorm folded into the GEMMs around them (vitg_gemm_norm_*).  Measured 4 % SLOWER on the step than the stand-alone
         # norm kernels (profiles/r02_fused_norm.md), so the kernels live in the profiling library and this switch only exists there.
         # (never together with fp8 layer weights - the fused consumers only exist for 16-bit operands)
-        self.fuse_norm = _fuse_norm_enabled() and weights.fp8 is False
+        self.fuse_norm = _fuse_norm_enabled() and getattr(weights, "fp8", False) is False
         # fp8 tower: fc1 (+ GELU) hands its output to fc2 as e4m3 + MX block scales straight from its epilogue (vitg_gemm_fp8_mx) instead
         # of 16 bits + a stand-alone per-token quantiser pass; VITG_FP8_MX=0 keeps the per-token form (A/B, tests)
         self.fp8_mx = os.environ.get("VITG_FP8_MX", "1") not in ("", "0")
@@ -290,10 +315,11 @@ class SelectorEngine:
 
     # ---- GEMM operands: 16-bit tensors, or (e4m3fn bytes, per-token scales) on the fp8 weight path ---------------------------
     def _norm(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], name: str, d: int, eps: float,
-              dt: Optional[torch.dtype] = None):
-        """LayerNorm (b given) / RMSNorm of the fp32 residual rows as the A operand of the next GEMM"""
+              dt: Optional[torch.dtype] = None, cw=None):
+        """LayerNorm (b given) / RMSNorm of the fp32 residual rows as the A operand of the next GEMM, whose weight `cw` decides the
+        operand form: e4m3 + per-token scales for an Fp8Weight, 16 bits otherwise"""
         M = x.shape[0]
-        if self._part_fp8(name):
+        if isinstance(cw, Fp8Weight):
             a8 = self._buf(name + "_q8", (M, K.pad128(d)), torch.uint8)
             sa = self._buf(name + "_qs", (M,), torch.float32)
             K.norm_quant_fp8(x, w, b, a8, sa, d, eps)
@@ -305,14 +331,9 @@ class SelectorEngine:
             K.rmsnorm(x, w, h, d, eps)
         return h
 
-    def _part_fp8(self, name: str) -> bool:
-        """workspace names start with vit_ / llm_: is that part on the fp8 weight path?"""
-        f = self.w.fp8
-        return f is True or (isinstance(f, str) and name.startswith(f + "_"))
-
-    def _operand(self, t: torch.Tensor, name: str, d: int):
-        """a 16-bit activation (attention output, GELU / SwiGLU output) as the A operand of the next GEMM"""
-        if not self._part_fp8(name):
+    def _operand(self, t: torch.Tensor, name: str, d: int, cw=None):
+        """a 16-bit activation (attention output, GELU / SwiGLU output) as the A operand of the next GEMM (weight `cw`)"""
+        if not isinstance(cw, Fp8Weight):
             return t
         a8 = self._buf(name + "_q8", (t.shape[0], K.pad128(d)), torch.uint8)
         sa = self._buf(name + "_qs", (t.shape[0],), torch.float32)
@@ -404,15 +425,16 @@ class SelectorEngine:
         H, hd = v.num_attention_heads, v.head_dim
         a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.vdtype)
         eps, vdt = v.layer_norm_eps, self.vdtype
-        r16 = self.residual16 and not self._part_fp8("vit_") and not self.fuse_norm and Dv % 8 == 0
+        # (fp16 only: a bf16 stream would carry 8 mantissa bits through 26 layers; never together with fp8 tower GEMMs or the fused norm)
+        r16 = self.residual16 and vdt == torch.float16 and not w.fp8_part("vit") and not self.fuse_norm and Dv % 8 == 0
         x = self._buf("vit_x16" if r16 else "vit_x", (M, Dv), vdt if r16 else torch.float32)
         src = self.pool_sources(G, hw) if (hw is not None and self.skip_dead_rows and len(w.vit) > 0) else None
         full_layers = w.vit if src is None else w.vit[:-1]
 
-        def norm(xs, gw, gb, name):
-            """LayerNorm of stream rows as the A operand of the next GEMM"""
+        def norm(xs, gw, gb, name, cw=None):
+            """LayerNorm of stream rows as the A operand of the next GEMM (weight cw)"""
             if not r16:
-                return self._norm(xs, gw, gb, name, Dv, eps, vdt)
+                return self._norm(xs, gw, gb, name, Dv, eps, vdt, cw=cw)
             h_ = self._buf(name, (xs.shape[0], Dvp), vdt, zero=True)
             return K.layernorm16(xs, gw, gb, h_, Dv, eps)
 
@@ -441,31 +463,31 @@ class SelectorEngine:
             if pend is not None:
                 K.gemm_norm_consumer(pend[0], lw.qkv_w, qkv, mode=K.GEMM_STORE16, stats=pend[1], colsum=lw.qkv_cs, bias=lw.qkv_c)
             else:
-                h = norm(x, lw.ln1_w, lw.ln1_b, "vit_h")
+                h = norm(x, lw.ln1_w, lw.ln1_b, "vit_h", lw.qkv_w)
                 self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
             K.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
                         q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
                         variant=self.attn_variant)
             if r16:
                 update(o, lw.out_w, lw.out_b, x)
-                h = norm(x, lw.ln2_w, lw.ln2_b, "vit_h")
+                h = norm(x, lw.ln2_w, lw.ln2_b, "vit_h", lw.fc1_w)
                 self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
                 update(f, lw.fc2_w, lw.fc2_b, x)
                 continue
-            pend = self._producer(self._operand(o, "vit_o", Dv), lw.out_w, x, bias=lw.out_b, res=x, gamma=lw.ln2_w, name="vit", eps=eps,
+            pend = self._producer(self._operand(o, "vit_o", Dv, lw.out_w), lw.out_w, x, bias=lw.out_b, res=x, gamma=lw.ln2_w, name="vit", eps=eps,
                                   rms=False, dt=vdt)
             if pend is not None:
                 K.gemm_norm_consumer(pend[0], lw.fc1_w, f, mode=K.GEMM_STORE16, stats=pend[1], colsum=lw.fc1_cs, bias=lw.fc1_c,
                                      act=K.ACT_GELU_TANH)
             else:
-                h = self._norm(x, lw.ln2_w, lw.ln2_b, "vit_h", Dv, eps, vdt)
+                h = self._norm(x, lw.ln2_w, lw.ln2_b, "vit_h", Dv, eps, vdt, cw=lw.fc1_w)
                 if self.fp8_mx and isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight):
                     self._mlp_fp8_mx(h, lw.fc1_w, lw.fc1_b, lw.fc2_w, lw.fc2_b, x, "vit")
                     pend = None
                     continue
                 self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
             nxt = w.vit[li + 1].ln1_w if li + 1 < len(w.vit) else None          # the norm in front of the NEXT layer's qkv
-            pend = self._producer(self._operand(f, "vit_f", Fvp), lw.fc2_w, x, bias=lw.fc2_b, res=x, gamma=nxt, name="vit", eps=eps,
+            pend = self._producer(self._operand(f, "vit_f", Fvp, lw.fc2_w), lw.fc2_w, x, bias=lw.fc2_b, res=x, gamma=nxt, name="vit", eps=eps,
                                   rms=False, dt=vdt)
         if src is None:
             return x, G, None, 0
@@ -478,12 +500,12 @@ class SelectorEngine:
             K.gemm_norm_consumer(pend[0], lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, stats=pend[1], colsum=lw.qkv_cs[Dv:],
                                  bias=lw.qkv_c[Dv:])
         else:
-            h = norm(x, lw.ln1_w, lw.ln1_b, "vit_h")
+            h = norm(x, lw.ln1_w, lw.ln1_b, "vit_h", lw.qkv_w)
             self._gemm(h, lw.qkv_w[Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, bias=lw.qkv_b[Dv:])
         xq = self._buf("vit_xq16" if r16 else "vit_xq", (Mc, Dv), vdt if r16 else torch.float32)
         K.gather_rows(x, idx, P, T, xq, Dv)
         # LayerNorm is per row: normalising the gathered residual rows equals gathering the normalised rows
-        hq = norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq")
+        hq = norm(xq, lw.ln1_w, lw.ln1_b, "vit_hq", lw.qkv_w)
         qc = self._buf("vit_qc", (Mc, Dv), vdt)
         self._gemm(hq, lw.qkv_w[:Dv], qc, mode=K.GEMM_STORE16, bias=lw.qkv_b[:Dv])                  # Q for the pooled tokens
         oc = self._buf("vit_oc", (Mc, Dvp), vdt, zero=True)
@@ -493,8 +515,8 @@ class SelectorEngine:
         if r16:
             update(oc, lw.out_w, lw.out_b, xq)
         else:
-            self._gemm(self._operand(oc, "vit_oc", Dv), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
-        hq = norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq")
+            self._gemm(self._operand(oc, "vit_oc", Dv, lw.out_w), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
+        hq = norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", lw.fc1_w)
         if self.fp8_mx and isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight):
             self._mlp_fp8_mx(hq, lw.fc1_w, lw.fc1_b, lw.fc2_w, lw.fc2_b, xq, "vit_c")
             return xq, G, cmap, Pc
@@ -503,7 +525,7 @@ class SelectorEngine:
         if r16:
             update(fc, lw.fc2_w, lw.fc2_b, xq)
         else:
-            self._gemm(self._operand(fc, "vit_fc", Fvp), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
+            self._gemm(self._operand(fc, "vit_fc", Fvp, lw.fc2_w), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
         return xq, G, cmap, Pc
 
     # ---- A9: pool + projector, written straight into rows of the LLM residual stream ------------------
@@ -557,7 +579,7 @@ class SelectorEngine:
                 # context-parallel rank: K|V FIRST, written straight into this rank's slot of the gather buffer, RoPE on the
                 # K heads, exchange launched - all on a side stream - while the main stream runs the Q projection and its RoPE; the
                 # attention then waits for the exchange only.  (K|V: 28 - 56 output tiles, Q: 98 at M = 1660 - the two GEMMs share the CUs.)
-                h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps)
+                h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps, cw=lw.qkv_w)
                 kcol = nq * hd
                 kv_local = kv_gather.local_rows(kvw, self.dtype, self.device)
                 main = torch.cuda.current_stream(self.device)
@@ -575,7 +597,7 @@ class SelectorEngine:
                 if pend is not None:
                     K.gemm_norm_consumer(pend[0], lw.qkv_w, qkv, mode=K.GEMM_STORE16, stats=pend[1], bias=lw.qkv_b)
                 else:
-                    h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps)
+                    h = self._norm(x, lw.in_ln, None, "llm_h", D, cfg.rms_norm_eps, cw=lw.qkv_w)
                     self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
                 K.rope_(qkv, cos, sin, nq + nkv, hd)
                 if kv_gather is not None:                                 # (a plain callable: gathers the local K|V rows, blocking)
@@ -588,12 +610,12 @@ class SelectorEngine:
                 K.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
                             head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, kvw, hd), v_strides=(0, kvw, hd),
                             o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
-            pend = self._producer(self._operand(o, "llm_o", nq * hd), lw.o_w, x, bias=None, res=x, gamma=lw.post_ln if fuse else None,
+            pend = self._producer(self._operand(o, "llm_o", nq * hd, lw.o_w), lw.o_w, x, bias=None, res=x, gamma=lw.post_ln if fuse else None,
                                   name="llm", eps=cfg.rms_norm_eps, rms=True, dt=self.dtype)
             if pend is not None:
                 K.gemm_norm_consumer(pend[0], lw.gu_w, f, mode=K.GEMM_SWIGLU, stats=pend[1])
             else:
-                h = self._norm(x, lw.post_ln, None, "llm_h", D, cfg.rms_norm_eps)
+                h = self._norm(x, lw.post_ln, None, "llm_h", D, cfg.rms_norm_eps, cw=lw.gu_w)
                 if self.fp8_mx and isinstance(lw.gu_w, Fp8Weight) and isinstance(lw.down_w, Fp8Weight):
                     # silu(gate) * up leaves gate/up's epilogue as e4m3 + MX block scales and is down's operand as it stands
                     kp = lw.down_w.w8.shape[1]
@@ -605,7 +627,7 @@ class SelectorEngine:
                     continue
                 self._gemm(h, lw.gu_w, f, mode=K.GEMM_SWIGLU)
             nxt = w.llm[li + 1].in_ln if (fuse and li + 1 < len(w.llm)) else None
-            pend = self._producer(self._operand(f, "llm_f", Fp), lw.down_w, x, bias=None, res=x, gamma=nxt, name="llm",
+            pend = self._producer(self._operand(f, "llm_f", Fp, lw.down_w), lw.down_w, x, bias=None, res=x, gamma=nxt, name="llm",
                                   eps=cfg.rms_norm_eps, rms=True, dt=self.dtype)
         out = self._buf("llm_out", (N, D), torch.float32)
         K.rmsnorm(x, w.norm_w, out, D, cfg.rms_norm_eps)
