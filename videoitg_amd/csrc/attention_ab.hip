@@ -20,14 +20,26 @@ namespace vitg {
 
 constexpr float AB_LAZY_RESCALE_LOG2 = 8.0f;      // see attention_sp.hip: running max only moves on a > 2^8 jump
 
-template <typename T, int D, int NW>
+// PV16 (round 3, the default): O^T += V^T P on v_mfma_f32_16x16x32 instead of 32x32x16.
+//   * head dim 72 is 4.5 d-tiles of 16: five 16-row tiles (80 rows) instead of three 32-row tiles (96) - 20 MFMAs of 16 pipe cycles per 64-key
+//     tile and wave instead of 12 of 32 (320 against 384 cycles; QK^T stays at 10 x 32: d pads to 80 there either way);
+//   * the 16x16x32 shape draws less power per flop (tools/ubench/mfma_shape_power.hip: an MFMA-only kernel sustains 1.92 against 1.68 PFLOP/s
+//     inside the same package power cap) - and this kernel runs on that cap (profiles/r02_power_trace.txt).
+// P leaves the softmax in the 32x32 C layout (lane (q, h): 8 keys 16 kk + {4h..4h+3, 8+4h..8+4h+3} per 16-key block kk).  The 16x16x32 B operand
+// wants 16 queries x 4 lane groups g of 8 k-slots each: v_permlane32_swap + v_permlane16_swap of the register pair (p[2kb], p[2kb+1]) give, for
+// query tile 0 / 1, the rows [ (2kb, h0), (2kb, h1), (2kb+1, h0), (2kb+1, h1) ] - no LDS round trip, 2 swaps per pair of VGPRs.  The contraction
+// order is free as long as both operands agree: lane group g of the V^T fragment reads keys 32 kb + 16 (g >> 1) + 4 (g & 1) + {0..3, 8..11}
+// with two ds_read_b64_tr_b16.  V rows sit 160 B apart in LDS (80 elements: 72 + one pad chunk): rows r .. r+7 then cover all 64 banks exactly once,
+// which the two lane groups of a half-wave (h0 | h1 rows) need to stay conflict-free (192-B rows cannot give that).
+template <typename T, int D, int NW, bool PV16>
 __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     adopt_device_key_count(a);
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
     constexpr int KS = C::DK / 16;           // QK^T k-steps per 32-key half
-    constexpr int DT = C::DV / 32;           // PV d-tiles
-    constexpr int KT_BYTES = ATT_BK * C::LDK * 2, VT_BYTES = ATT_BK * C::LDV * 2;
+    constexpr int LDV = PV16 ? 80 : C::LDV;
+    constexpr int DT = PV16 ? 5 : C::DV / 32;   // PV d-tiles (of 16 / 32 rows)
+    constexpr int KT_BYTES = ATT_BK * C::LDK * 2, VT_BYTES = ATT_BK * LDV * 2;
     constexpr int V_BASE = 2 * KT_BYTES;     // LDS: [K0][K1][V0][V1][V2]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     }
 
     // ---- LDS-DMA staging: one global_load_lds_dwordx4 fills 1 KiB lane-linearly; the source address carries the layout ---
-    constexpr int K_CPR = C::LDK * 2 / 16, V_CPR = C::LDV * 2 / 16;       // 16-B slots per row = DMA instructions per tile
+    constexpr int K_CPR = C::LDK * 2 / 16, V_CPR = LDV * 2 / 16;          // 16-B slots per row = DMA instructions per tile
     constexpr int K_PW = (K_CPR + NW - 1) / NW, V_PW = (V_CPR + NW - 1) / NW;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto dma_src = [&](int ii, int cpr, int rs, bool is_k, int row_lim) -> unsigned {
@@ -111,16 +123,25 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     const char* kbase[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kbase[ks] = smem + k_lds_off<D>(ql, ks * 2 + h);      // + t*32 rows: row & 15 unchanged
-    const int voff = (4 * h + ((lane & 15) >> 2)) * (C::LDV * 2) + ((((lane >> 4) & 1) * 16) + 4 * (lane & 3)) * 2;
-    const char* vbase[DT];
+    const int g16 = lane >> 4;
+    const int voff = PV16 ? (16 * (g16 >> 1) + 4 * (g16 & 1) + ((lane & 15) >> 2)) * (LDV * 2) + (4 * (lane & 3)) * 2
+                          : (4 * h + ((lane & 15) >> 2)) * (LDV * 2) + ((((lane >> 4) & 1) * 16) + 4 * (lane & 3)) * 2;
+    const char* vbase[PV16 ? 1 : DT];
+    if constexpr (PV16) vbase[0] = smem + V_BASE + voff;
+    else {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) vbase[dt] = smem + V_BASE + voff + (D == 128 ? ((dt ^ ((lane & 15) >> 2)) * 64) : dt * 64);
+        for (int dt = 0; dt < DT; ++dt) vbase[dt] = smem + V_BASE + voff + (D == 128 ? ((dt ^ ((lane & 15) >> 2)) * 64) : dt * 64);
+    }
 
-    f32x16 o[DT];
+    // accumulators: 32x32 layout o[dt][r] = O[q][32 dt + 8 (r >> 2) + 4 h + (r & 3)], or (PV16) o16[dt][qt][r] = O[16 qt + (lane & 15)][16 dt + 4 (lane >> 4) + r]
+    f32x16 o[PV16 ? 1 : DT];
+    f32x4 o16[PV16 ? DT : 1][2];
 #pragma unroll
-    for (int i = 0; i < DT; ++i)
+    for (int i = 0; i < (PV16 ? 1 : DT); ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (PV16 ? DT : 1); ++i) { o16[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o16[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float m_run = -1e30f, l_run = 0.f;
     const int nkt = ceil_div(a.Sk, ATT_BK);
 
@@ -137,15 +158,40 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     };
     auto pv_mfma = [&](int vbuf, const vec8 (&p)[4]) {
         const int vo = vbuf * VT_BYTES;
+        if constexpr (PV16) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                // B operands of query tile 0 / 1 for the 32 keys of block kb: rows [ (2kb, h0), (2kb, h1), (2kb+1, h0), (2kb+1, h1) ]
+                const u32x4 X = bitcast<u32x4>(p[2 * kb]), Y = bitcast<u32x4>(p[2 * kb + 1]);
+                u32x4 P0, P1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x2 t = __builtin_amdgcn_permlane32_swap(X[i], Y[i], false, false);      // [X0 X1 Y0 Y1], [X2 X3 Y2 Y3]  (rows of 16 lanes)
+                    const u32x2 u = __builtin_amdgcn_permlane16_swap(t[0], t[1], false, false);      // [X0 X2 Y0 Y2], [X1 X3 Y1 Y3]
+                    P0[i] = u[0]; P1[i] = u[1];
+                }
+                const vec8 pb0 = bitcast<vec8>(P0), pb1 = bitcast<vec8>(P1);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const char* a0 = vbase[0] + vo + kb * 32 * (LDV * 2) + dt * 32;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 8 * (LDV * 2)));
+                    const vec8 vf = bitcast<vec8>(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    o16[dt][0] = T16<T>::mfma16(vf, pb0, o16[dt][0]);
+                    o16[dt][1] = T16<T>::mfma16(vf, pb1, o16[dt][1]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const char* a0 = vbase[dt] + vo + ((kk >> 1) * 32 + (kk & 1) * 16) * (C::LDV * 2);
+                const char* a0 = vbase[dt] + vo + ((kk >> 1) * 32 + (kk & 1) * 16) * (LDV * 2);
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 8 * (C::LDV * 2)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 8 * (LDV * 2)));
                 o[dt] = T16<T>::mfma32(bitcast<vec8>(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), p[kk], o[dt]);
             }
+        }
     };
     auto mask_tail = [&](int t, f32x16 (&s)[2]) {          // last, partial tile: lane (q, h) s[tt][r] is key t*64 + tt*32 + 8*(r>>2) + 4*h + (r&3)
         if (t * ATT_BK + ATT_BK > a.Sk) {
@@ -169,10 +215,18 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         if (__builtin_amdgcn_ballot_w64(m_new > m_run + AB_LAZY_RESCALE_LOG2) != 0) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
+            if constexpr (PV16) {
+                // the accumulators of query tile 0 / 1 sit in ALL four lane rows: row 0 (= row 2) / row 1 (= row 3) holds those queries' factor
+                const u32x2 aa = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(alpha), bitcast<uint32_t>(alpha), false, false);
+                const float a0 = bitcast<float>(aa[0]), a1 = bitcast<float>(aa[1]);
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+                for (int i = 0; i < DT; ++i) { o16[i][0] *= a0; o16[i][1] *= a1; }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
             m_run = m_new;
         }
         f32x2 psum2 = {0.f, 0.f};
@@ -247,6 +301,27 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     // ---- epilogue: lane (q, h) holds O[q][dt*32 + 8*(r>>2) + 4*h + (r&3)] -------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    if constexpr (PV16) {
+        const u32x2 ii = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(inv), bitcast<uint32_t>(inv), false, false);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float iq = bitcast<float>(ii[qt]);
+            const int qrow = q0 + 16 * qt + (lane & 15);
+            if (qrow < a.S) {
+                T* op = (T*)a.o + b * a.o_bs + (long)head * a.o_hs + (long)qrow * a.o_rs;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int d = dt * 16 + 4 * g16;
+                    if (d < D) {
+                        typename T16<T>::vec4 w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = T16<T>::from_f32(o16[dt][qt][e] * iq);
+                        *(typename T16<T>::vec4*)(op + d) = w;
+                    }
+                }
+            }
+        }
+    } else {
     const int qrow = q0 + ql;
     if (qrow < a.S) {
         T* op = (T*)a.o + b * a.o_bs + (long)head * a.o_hs + (long)qrow * a.o_rs;
@@ -263,30 +338,33 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
                 }
             }
     }
+    }
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, bool PV16>
 static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
-    const size_t lds = 2 * (ATT_BK * C::LDK * 2) + 3 * (ATT_BK * C::LDV * 2);
-    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
+    const size_t lds = 2 * (ATT_BK * C::LDK * 2) + 3 * (ATT_BK * (PV16 ? 80 : C::LDV) * 2);
+    static bool done_dev[16] = {false};          // per device: the attribute belongs to the device's copy of the kernel
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
-    if (cur_dev != done_dev) {
-        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done_dev = cur_dev;
+    if (cur_dev >= 16 || !done_dev[cur_dev]) {
+        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW, PV16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (cur_dev < 16) done_dev[cur_dev] = true;
     }
-    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW, PV16>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
 // called by vitg_attention (attention.hip); hd 72 only (hd 128 runs the software-pipelined kernel)
 // waves = 8: 256 queries per block, two blocks per CU.  waves = 16: 512 queries per block, ONE block per CU sharing one K/V ring - the same
 // 4 waves per SIMD (each SIMD holds two group-A and two group-B waves), half the K/V bytes streamed out of L2 per query.
-int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, hipStream_t s) {
-    if (waves == 16) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 16>(a, batch, heads, s) : launch_ab<f16_t, 72, 16>(a, batch, heads, s);
-    return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8>(a, batch, heads, s) : launch_ab<f16_t, 72, 8>(a, batch, heads, s);
+// pv32 (attn_ab = 4, A/B and cross-check): the round-2 form with PV on v_mfma_f32_32x32x16 (head dim padded to 96 there).
+int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, bool pv32, hipStream_t s) {
+    if (pv32) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, false>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, false>(a, batch, heads, s);
+    if (waves == 16) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 16, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 16, true>(a, batch, heads, s);
+    return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true>(a, batch, heads, s);
 }
 
 }  // namespace vitg
