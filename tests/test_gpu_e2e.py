@@ -367,12 +367,17 @@ def test_infer_entry_point_runs_offline():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--model", "synthetic:tiny", "--video", "synthetic", "--topk", "8"],
-                         capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
-    import ast
-    sel = ast.literal_eval(out.stdout.strip().splitlines()[-1])
-    assert len(sel) == 8 and sel == sorted(sel) and len(set(sel)) == 8
+    import tempfile
+    with tempfile.TemporaryDirectory() as vis:
+        out = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--model", "synthetic:tiny", "--video", "synthetic", "--topk", "8",
+                              "--save-dir", vis], capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        import ast
+        lines = out.stdout.strip().splitlines()
+        sel = ast.literal_eval(next(l for l in lines if l.startswith("[")))
+        assert len(sel) == 8 and sel == sorted(sel) and len(set(sel)) == 8
+        # infer.py:81-94 of the reference: the selected frames as JPEGs, frame_<rank>_idx<original index>.jpg
+        assert sorted(os.listdir(vis)) == [f"frame_{i:03d}_idx{f}.jpg" for i, f in enumerate(sel)]
 
 
 def test_graph_captured_forward_replays_bit_identically(golden_dir):

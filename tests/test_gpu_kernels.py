@@ -212,9 +212,10 @@ def test_rope(ops, dtype):
     assert (got - want).abs().max().item() <= EPS16[dtype] * want.abs().max().item() + 1e-6
 
 
-@pytest.mark.parametrize("pix_dtype", [torch.float32, torch.float16])
-def test_patchify_matches_conv(ops, pix_dtype):
-    T, R, ps, Dv = 3, 56, 14, 32
+@pytest.mark.parametrize("R", [56, 62, 70, 112, 384])       # 56 / 112 / 384: whole-row coalesced kernel; 62 / 70: per-element kernel (rows not 16-B granular)
+@pytest.mark.parametrize("pix_dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_patchify_matches_conv(ops, pix_dtype, R):
+    T, ps, Dv = 3, 14, 32
     pix = rnd((T, 3, R, R), 60, dtype=torch.bfloat16)
     w = rnd((Dv, 3, ps, ps), 61, 0.05, torch.bfloat16)
     want = F.conv2d(pix, w, stride=ps).flatten(2).transpose(1, 2).reshape(-1, Dv)
