@@ -433,3 +433,25 @@ def test_bilinear_pool16(ops, dtype, T, G, HW, D):
     got = out.float().cpu()
     assert (got[:, D:] == 0).all()
     assert (got[:, :D] - want).abs().max().item() <= EPS16[dtype] * want.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dispatcher_ops_with_residual_aliasing_output(ops, dtype):
+    """the engine passes `res` aliasing `out` (x = a w^T + x) through torch.ops.videoitg.gemm / gemm_res16, whose schemas mark
+    only `out` as mutated.  The contract is EAGER (torch_ops.py docstring): the aliased call must equal the call on a separate copy of the
+    residual, for the fp32 stream and for the 16-bit one."""
+    import videoitg_amd.torch_ops  # noqa: F401  (registers torch.ops.videoitg.*)
+    M, N, K = 1000, 1152, 640
+    a, w, b = rnd((M, K), 1, dtype=dtype).to(dtype).cuda(), rnd((N, K), 2, K ** -0.5, dtype=dtype).to(dtype).cuda(), rnd((N,), 3, 0.1, torch.float32).cuda()
+    x32 = rnd((M, N), 4, 1.0, torch.float32).cuda()
+    sep, ali = torch.empty_like(x32), x32.clone()
+    torch.ops.videoitg.gemm(a, w, sep, ops.GEMM_F32, None, b, 0, x32.clone(), 0, None)
+    torch.ops.videoitg.gemm(a, w, ali, ops.GEMM_F32, None, b, 0, ali, 0, None)
+    assert torch.equal(sep, ali)
+    x16 = rnd((M, N), 5, 1.0, dtype=dtype).to(dtype).cuda()
+    sep16, ali16 = torch.empty_like(x16), x16.clone()
+    torch.ops.videoitg.gemm_res16(a, w, sep16, b, x16.clone(), None, 0)
+    torch.ops.videoitg.gemm_res16(a, w, ali16, b, ali16, None, 0)
+    assert torch.equal(sep16, ali16)
+    with pytest.raises(NotImplementedError):                      # no CPU registration: the product has no host path
+        torch.ops.videoitg.gemm(a.cpu(), w.cpu(), sep.cpu(), ops.GEMM_F32, None, b.cpu(), 0, None, 0, None)

@@ -440,12 +440,11 @@ static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
     const size_t lds = 2 * (ATT_BK * C::LDK * 2 + ATT_BK * C::LDV * 2);
-    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (cur_dev != done_dev) {
-        hipFuncSetAttribute((const void*)attn_kernel<T, D, TR, NW, ABL, PIPE, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done_dev = cur_dev;
+    static std::atomic<unsigned> done_mask{0};   // per device: the attribute belongs to the device's copy of the kernel
+    const int cur_dev = current_device();
+    if (!device_done(done_mask, cur_dev)) {
+        (void)hipFuncSetAttribute((const void*)attn_kernel<T, D, TR, NW, ABL, PIPE, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        mark_device_done(done_mask, cur_dev);
     }
     dim3 grid(ceil_div(a.S, NW * 32) * heads * batch);
     hipLaunchKernelGGL((attn_kernel<T, D, TR, NW, ABL, PIPE, DMA>), grid, dim3(NW * 64), lds, s, a);
@@ -502,8 +501,7 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
         // tools/attn_cp_shapes.py: 1660 queries x 28 heads -> 196 big blocks on 256 CUs = 0.77 beat 364 small ones on 512 slots = 0.71,
         // 344 vs 371 us; the previous rule "fewer than 384 big blocks -> small blocks" picked the slower one there; 6460 queries: 0.95 vs
         // 0.93, 1120 vs 1203 us); a tie goes to the small blocks (3260 queries: 644 vs 684 us), long launches to the big ones.
-        static int cus = 0;
-        if (!cus) { int d = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d); if (cus <= 0) cus = 256; }
+        const int cus = device_cu_count(current_device());
         const double r8 = (double)ceil_div(S, 256) * heads * batch / cus, r4 = (double)ceil_div(S, 128) * heads * batch / (2.0 * cus);
         const double e8 = r8 / ceil(r8), e4 = r4 / ceil(r4);
         if (r8 < 4.0 && e4 >= e8) nw = 4;

@@ -336,12 +336,11 @@ static int launch_sp(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
     const size_t lds = 2 * (ATT_BK * C::LDK * 2 + ATT_BK * C::LDV * 2);
-    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (cur_dev != done_dev) {
+    static std::atomic<unsigned> done_mask{0};   // per device: the attribute belongs to the device's copy of the kernel
+    const int cur_dev = current_device();
+    if (!device_done(done_mask, cur_dev)) {
         (void)hipFuncSetAttribute((const void*)attn_sp_kernel<T, D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done_dev = cur_dev;
+        mark_device_done(done_mask, cur_dev);
     }
     hipLaunchKernelGGL((attn_sp_kernel<T, D, NW>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();

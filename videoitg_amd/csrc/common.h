@@ -5,6 +5,7 @@
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace vitg {
 
@@ -82,6 +83,22 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Per-device host-side caches: one bit / one slot per device instead of a single "last device" variable, so host threads driving
+// different GPUs neither thrash nor race each other's state.  Set-up work guarded by a bit is idempotent (hipFuncSetAttribute), and the bit is
+// set AFTER it ran, so a second thread either repeats it or sees it finished.
+inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+inline bool device_done(const std::atomic<unsigned>& mask, int dev) { return (mask.load(std::memory_order_acquire) >> (dev & 31)) & 1u; }
+inline void mark_device_done(std::atomic<unsigned>& mask, int dev) { mask.fetch_or(1u << (dev & 31), std::memory_order_release); }
+inline int device_cu_count(int dev) {
+    static std::atomic<int> cus[32];
+    int c = cus[dev & 31].load(std::memory_order_relaxed);
+    if (c <= 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cus[dev & 31].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
 
 // Host-side tuning knobs (vitg_set_option / environment VITG_*): kernel selection for A/B measurements and tests.
 struct Tuning {

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void patchify_rows_kernel(const TI* __restrict
     TO* lds = (TO*)psm;                                    // [3 * ps][R]
     const int t = blockIdx.x / G, py = blockIdx.x % G;
     const int rows = 3 * ps, cpr = R / 8;                  // 8-element chunks per pixel row
+#pragma unroll 4                                          // four rows of loads in flight per thread (the loop is load-latency bound otherwise)
     for (int i = threadIdx.x; i < rows * cpr; i += blockDim.x) {
         const int rr = i / cpr, ch = i % cpr;
         const int c = rr / ps, ky = rr % ps;
@@ -631,10 +632,9 @@ extern "C" int vitg_rank(const float* logits, int n, float* scores, int* order, 
     if (n > 8192) return VITG_ERR_SHAPE;
     int p2 = 1;
     while (p2 < n) p2 <<= 1;
-    static int done_dev = -1;
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (cur_dev != done_dev) { (void)hipFuncSetAttribute((const void*)rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8); done_dev = cur_dev; }
+    static std::atomic<unsigned> done_mask{0};
+    const int cur_dev = current_device();
+    if (!device_done(done_mask, cur_dev)) { (void)hipFuncSetAttribute((const void*)rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8); mark_device_done(done_mask, cur_dev); }
     hipLaunchKernelGGL(rank_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, (hipStream_t)stream, logits, n, p2, scores, order);
     return CHECK_LAUNCH();
 }

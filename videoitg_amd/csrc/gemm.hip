@@ -192,16 +192,15 @@ static int launch(const GemmArgs& g, int mode, hipStream_t s) {
 using namespace vitg;
 
 static void set_attrs() {
-    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (cur_dev == done_dev) return;
-    done_dev = cur_dev;
+    static std::atomic<unsigned> done_mask{0};   // per device: the attribute belongs to the device's copy of the kernel
+    const int cur_dev = current_device();
+    if (device_done(done_mask, cur_dev)) return;
     const int lds = 2 * 2 * BM * BK * 2;
 #define SETA(T, Mo) hipFuncSetAttribute((const void*)gemm128_kernel<T, Mo>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
     SETA(bf16_t, MODE_STORE16); SETA(bf16_t, MODE_F32); SETA(bf16_t, MODE_SWIGLU);
     SETA(f16_t, MODE_STORE16); SETA(f16_t, MODE_F32); SETA(f16_t, MODE_SWIGLU);
 #undef SETA
+    mark_device_done(done_mask, cur_dev);
 }
 
 #if VITG_PROFILING_BUILD
@@ -327,11 +326,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 extern "C" int vitg_gemm_splitk_plan(int M, int N, int K, int* splits, long* workspace_bytes) {
     if (!splits || !workspace_bytes) return VITG_ERR_ARG;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
+    const int cus = device_cu_count(current_device());
     const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
     int sp = 1;
     // worth it only when one round of 256x256 tiles leaves most of the chip idle and every split still has a real K loop

@@ -823,12 +823,11 @@ static int launch256p(GemmArgs g, hipStream_t s) {
 template <typename T, int MODE, int BN, int WM, int STAGES, int BK, bool ASMR = false, int PH = 0, int BM = G2_BM, bool NRM = false>
 static int launch256(GemmArgs g, hipStream_t s) {
     constexpr int lds = STAGES * (BM * BK * 2 + BN * BK * 2);
-    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (cur_dev != done_dev) {
+    static std::atomic<unsigned> done_mask{0};   // per device: the attribute belongs to the device's copy of the kernel
+    const int cur_dev = current_device();
+    if (!device_done(done_mask, cur_dev)) {
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<T, MODE, BN, WM, STAGES, BK, ASMR, PH, BM, NRM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        done_dev = cur_dev;
+        mark_device_done(done_mask, cur_dev);
     }
     g.tiles_m = ceil_div(g.M, BM);
     g.tiles_n = ceil_div(g.N, BN);
@@ -836,8 +835,7 @@ static int launch256(GemmArgs g, hipStream_t s) {
     // panels in its L2): 4 measured best (+0.5 % on the step over 8; 16 and 32 lose 10-20 %, profiles/r01_gemm_shapes.md section 7)
     g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
     // one block per CU walking the tile list ("software relaunch") when there are at least two tiles per CU and one block fills a CU
-    static int cus = 0;
-    if (!cus) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur_dev);
+    const int cus = device_cu_count(cur_dev);
     const int nwg = g.tiles_m * g.tiles_n;
     // default since round 2: in-step A/B in fp16, two alternations: 734.8 -> 732.7 ms, GEMM 1073 -> 1079 TF/s (gpurun_out/r02_ab_flags.log);
     // gemm_flags bit24 switches back to one hardware block per tile (A/B and the bit-identity test)
@@ -887,12 +885,7 @@ static bool gemm_mi16_selected(int mode) {
     return mm == 0 || ((mm >> mode) & 1);
 }
 static int choose_cfg(const GemmArgs& g, int mode) {
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
+    const int cus = device_cu_count(current_device());
     auto cost = [&](int bm, int bn, double eff, int blocks_per_cu) {
         const long tiles = (long)ceil_div(g.M, bm) * ceil_div(g.N, bn);
         const long rounds = (tiles + (long)cus * blocks_per_cu - 1) / ((long)cus * blocks_per_cu);

@@ -294,7 +294,9 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
                 amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
                 const unsigned bits = __float_as_uint(amax * (1.0f / 448.0f));
                 int ex = (int)((bits >> 23) & 255u) - 127 + ((bits & 0x7fffffu) ? 1 : 0);
-                ex = max(ex, -126);                          // amax = 0 (or denormal): any scale will do, the bytes are zero
+                ex = min(max(ex, -126), 127);                // amax = 0 (or denormal): any scale will do, the bytes are zero; amax = inf / NaN (exponent 255):
+                                                             // clamped so that the shift below stays defined - inv becomes 0 and inf * 0 = NaN / NaN * 0 = NaN
+                                                             // reach the e4m3 bytes as NaN instead of a garbage scale silently rescaling the block
                 const float inv = __uint_as_float((unsigned)(127 - ex) << 23);
                 sc2 |= (unsigned)(ex + 127) << (8 * nt);
                 const int row = mt * 32 + frow;
@@ -329,12 +331,11 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
 template <typename T, int MODE, int BM, int BN, bool MXA = false, bool MXO = false>
 static int launch_fp8(Gemm8Args ga, hipStream_t s) {
     constexpr int lds = F8_STAGES * (BM + BN) * F8_ROWB;
-    static int done_dev = -1;            // per device: the attribute belongs to the device's copy of the kernel
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (cur_dev != done_dev) {
+    static std::atomic<unsigned> done_mask{0};   // per device: the attribute belongs to the device's copy of the kernel
+    const int cur_dev = current_device();
+    if (!device_done(done_mask, cur_dev)) {
         (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<T, MODE, BM, BN, MXA, MXO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        done_dev = cur_dev;
+        mark_device_done(done_mask, cur_dev);
     }
     ga.g.tiles_m = ceil_div(ga.g.M, BM);
     ga.g.tiles_n = ceil_div(ga.g.N, BN);
@@ -584,7 +585,8 @@ extern "C" int vitg_quant_rows_fp8(const void* x, long ldx, int in_dtype, void* 
 extern "C" int vitg_norm_quant_fp8(const float* x, long ldx, const float* w, const float* b, void* out8, long ldo, float* scale,
                                    long M, int D, float eps, void* stream) {
     if (M <= 0) return 0;
-    if (D <= 0 || D > 4096 || D % 4 || ldx % 4 || ldo % 16 || ldo < D || ldo > 4096) return VITG_ERR_ALIGN;
+    if (D <= 0 || D > 4096 || ldo > 4096 || ldo < D) return VITG_ERR_SHAPE;          // (the row lives in registers: hidden sizes up to 4096)
+    if (D % 4 || ldx % 4 || ldo % 16) return VITG_ERR_ALIGN;
     if (!w) return VITG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((M + 3) / 4)), blk(256);
