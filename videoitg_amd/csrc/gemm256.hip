@@ -919,7 +919,9 @@ static int choose_cfg(const GemmArgs& g, int mode) {
         // flags bit12: A/B (16-bit outputs off the tall tile); bit14: A/B (fp32-residual GEMMs off it)
         const bool resid10 = mode == MODE_F32 || (mode == MODE_STORE16 && (g.res || g.res16));
         const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : resid10 ? 1.05 : (gemm_mi16_selected(mode) ? 1.05 : ((tuning().gemm_flags & 4096) ? 0.96 : 1.08)), 1);
-        if (c10 < 0.97 * best) { best = c10; cfg = 10; }
+        // the 3 % hysteresis protects the 256x256 default; between the two wide tiles the cheaper one wins outright (fc1: N = 4352 is 11.3 tiles of
+        // 384 but 17 of 256 - 1033 against 1015 TF/s on the tall tile, while qkv, N = 9 x 384, stays on the wide one: 1131 against 1078)
+        if (cfg == 9 ? c10 < best : c10 < 0.97 * best) { best = c10; cfg = 10; }
     }
     return cfg;
 }
