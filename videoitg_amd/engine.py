@@ -291,6 +291,9 @@ class SelectorEngine:
         self._poolsrc: Dict[tuple, object] = {}
         self._splitk: Dict[tuple, tuple] = {}        # (M, N, K) -> (splits, workspace bytes) from vitg_gemm_splitk_plan
         self._side: Optional[torch.cuda.Stream] = None   # context-parallel layers: K|V projection + exchange run here, under the Q projection
+        # VITG_CP_OVERLAP=0 (A/B): fused QKV projection and a blocking exchange, as in round 2.  The split costs one rank ~1 ms of compute per step
+        # (two sub-round launches instead of one, tools/cp_rank_time.py) and buys the exchange - est. 0.1-0.15 ms x 28 layers - off the critical path
+        self.cp_overlap = os.environ.get("VITG_CP_OVERLAP", "1") not in ("", "0")
 
     # workspace: ONE buffer per name, grown to the largest row count seen and handed out as a [:rows] view, so a run over
     # documents with varying prompt lengths / frame counts holds max-size buffers instead of one set per distinct shape.
@@ -575,7 +578,7 @@ class SelectorEngine:
         pend = None                                       # layer 0 normalises the assembled embeddings with the stand-alone kernel
         fuse = kv_gather is None                          # (the context-parallel ranks take the split-K path for o / down instead)
         for li, lw in enumerate(w.llm):
-            if kv_gather is not None and hasattr(kv_gather, "local_rows"):
+            if kv_gather is not None and hasattr(kv_gather, "local_rows") and self.cp_overlap:
                 # context-parallel rank: K|V FIRST, written straight into this rank's slot of the gather buffer, RoPE on the
                 # K heads, exchange launched - all on a side stream - while the main stream runs the Q projection and its RoPE; the
                 # attention then waits for the exchange only.  (K|V: 28 - 56 output tiles, Q: 98 at M = 1660 - the two GEMMs share the CUs.)
