@@ -1,0 +1,362 @@
+// C[M,N] = A[M,K] * W[N,K]^T on v_mfma_f32_16x16x32 (round 3).  Same block tiles, LDS-DMA operand ring, phased schedule and fused
+// epilogues as gemm256.hip's shipped configurations (256x256 / 256x384 / 384x256 x 64, 8 waves as 2 (M) x 4 (N)), with the
+// 32x32x16 MFMA replaced by the 16x16x32 one.
+//
+// Why: on MI355X the matrix pipes run against the 1400 W package power cap, and what the cap lets them sustain depends on the MFMA
+// SHAPE.  An MFMA-only kernel on N(0,1) fp16 operands holds 1.68 PFLOP/s with 32x32x16 and 1.92 PFLOP/s with 16x16x32 (bf16: 1.83 vs
+// 2.05; tools/ubench/mfma_shape_power.hip, profiles/r03_mfma_shape.md) - the same flops, the same accumulator registers, +14 % rate at
+// the same watts.  (hipBLASLt's gfx950 assembly kernel, MT256x256x64_MI16x16x1, is on that shape and was ahead of gemm256.hip by
+// exactly that margin on the large-N shapes, profiles/r02_gemm_timeline.md.)
+//
+// What changes against gemm256.hip:
+//   * fragments: a lane holds 8 consecutive k of ONE row - row = lane & 15, 16-B chunk (lane >> 4) of the 64-B (32-deep) k-step.  The
+//     LDS image ([rows][8 chunks x 16 B], chunk index XOR ((row >> 1) & 7), written lane-linearly by global_load_lds_dwordx4 from
+//     swizzled SOURCE addresses) is the one gemm256.hip uses: it is conflict-free for this read pattern too (each ds_read_b128 lane
+//     group covers the 16 rows once, 8 distinct swizzled chunks per row parity).
+//   * accumulators: f32x4 per 16x16 tile; lane holds features n0 + 4 (lane >> 4) .. + 3 of token m0 + (lane & 15)  (MFMA "A" = weight
+//     rows, "B" = activation rows, as in gemm256.hip: 4 consecutive output features of one token per lane).
+//   * schedule: a K-tile (64 deep) is 2 k-steps x (MT / MC) row chunks = NI intervals pairs [fragment reads + DMA issue | MC x NT MFMAs]
+//     delimited by raw s_barriers; the weight fragments of a k-step are read once and kept over its row chunks.  Waves 4-7 run one
+//     barrier behind waves 0-3, so on every SIMD one wave owns the matrix pipe while its sibling reads / issues DMA (the phased
+//     schedule of gemm256.hip, cfg 6).  16 MFMAs of 16x16x32 = 256 pipe cycles per interval, as 8 of 32x32x16 there.
+// Epilogues (bias, GELU tanh / erf, SwiGLU, fp32 residual preloaded into the accumulators, 16-bit or fp32 output) are restated for
+// the 16x16 accumulator layout: 32 rows at a time through a wave-private LDS window into full-row 16-B stores.
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace vitg {
+
+constexpr int G16_THREADS = 512;
+constexpr int MODE_RES16 = 3;      // internal: MODE_STORE16 with a residual preloaded into the accumulators (vitg_gemm_res16).  Its own instantiation:
+                                   // compiled into the plain 16-bit-output kernels the preload cost the wide tiles 15-20 spilled registers
+
+template <typename T, int MODE, int BM, int BN>
+__global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
+    typedef typename T16<T>::vec8 vec8;
+    GemmArgs g = g_;
+    constexpr bool RES16 = MODE == MODE_RES16;
+    constexpr int EMODE = RES16 ? MODE_STORE16 : MODE;   // epilogue form
+    if constexpr (MODE == MODE_F32) {
+        if (g.split_k > 1) {                              // split-K: block y takes its own K range into its own partial buffer (gemm256.hip)
+            const int sp = blockIdx.y;
+            const int nk_all = g.K / 64, per = nk_all / g.split_k, rem = nk_all % g.split_k;
+            const int k0 = sp * per + min(sp, rem);
+            g.A = (const char*)g.A + (size_t)k0 * 128;
+            g.W = (const char*)g.W + (size_t)k0 * 128;
+            g.K = (per + (sp < rem ? 1 : 0)) * 64;
+            g.out = (float*)g.out + (size_t)sp * g.split_stride;
+        }
+    }
+    constexpr int WM = 2, WN = 4;
+    constexpr int MT = BM / WM / 16;                     // 16-row activation tiles per wave (8 or 12)
+    constexpr int NT = BN / WN / 16;                     // 16-wide weight tiles per wave (4 or 6)
+    constexpr int MC = (MT == 12) ? 6 : 4;
+    constexpr int NC = MT / MC;                          // row chunks per k-step
+    constexpr int NI = 2 * NC;                           // intervals pairs per K-tile (2 k-steps of 32)
+    constexpr int ROWB = 128;                            // bytes per LDS row: 64 k x 2 B
+    constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+    constexpr int A_INSTR = A_BYTES / 1024 / 8, W_INSTR = W_BYTES / 1024 / 8, LPT = A_INSTR + W_INSTR;
+    static_assert(MT % MC == 0, "row chunks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg_ = g.tiles_m * g.tiles_n;
+    for (int vb = blockIdx.x; vb < nwg_; vb += gridDim.x) {
+    // per-lane quantities re-derived from an opaque copy of the thread id in every pass (hoisted they would stay live through the loop)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    int tm, tn;
+    block_to_tile(vb, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- DMA assignment (as gemm256.hip): one instruction = 8 rows x 128 B; lane -> (row = lane / 8, LDS chunk slot = lane % 8);
+    // source = wave-uniform tile base + per-lane 32-bit byte offset (saddr form), source chunk = slot ^ ((row >> 1) & 7)
+    const int drow = lane >> 3, dslot = lane & 7;
+    const char* const a_base = (const char*)g.A + (size_t)m0 * g.lda * 2;
+    const char* const w_base = (const char*)g.W + (size_t)n0 * g.ldw * 2;
+    unsigned a_cur[A_INSTR], w_cur[W_INSTR];
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+        const int R = (wave * A_INSTR + j) * 8 + drow;
+        a_cur[j] = ((unsigned)(min(R, g.M - 1 - m0) * g.lda) + (unsigned)((dslot ^ ((R >> 1) & 7)) << 3)) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) {
+        const int R = (wave * W_INSTR + j) * 8 + drow;
+        w_cur[j] = ((unsigned)(min(R, g.N - 1 - n0) * g.ldw) + (unsigned)((dslot ^ ((R >> 1) & 7)) << 3)) * 2u;
+    }
+    auto issue_one = [&](int kt, int j) {
+        char* st = smem + (kt & 1) * STAGE;
+        const size_t koff = (size_t)kt * ROWB;
+        const char* ka = a_base + koff;
+        const char* kw = w_base + koff;
+        unsigned off = j < A_INSTR ? a_cur[j] : w_cur[j - A_INSTR];
+        asm volatile("" : "+v"(off));                    // keeps base + offset in the saddr form (no per-lane 64-bit pointer)
+        if (j < A_INSTR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ka + off),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kw + off),
+                                             (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * W_INSTR + j - A_INSTR) * 1024), 16, 0, 0);
+    };
+
+    const int r16 = lane & 15, fq = lane >> 4;
+    // Accumulators: zero, or - fp32 residual update without activation - the residual tile itself (the read half of the
+    // read-modify-write then overlaps the main loop; these loads are older than every DMA in the vmcnt queue)
+    // (MODE_RES16 = vitg_gemm_res16: the 16-bit residual stream of the tower, or the fp32 position table, into a 16-bit output)
+    const bool acc_from_res = (MODE == MODE_F32 && g.res != nullptr && g.act == VITG_ACT_NONE) || RES16;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == MODE_F32 || RES16) {
+        if (acc_from_res) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + wr * (MT * 16) + mt * 16 + r16;
+                const int rm = g.res_mod > 0 ? m % g.res_mod : m;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = n0 + wc * (NT * 16) + nt * 16 + fq * 4;
+                    if (m < g.M && n < g.N) {
+                        if (g.res) acc[nt][mt] = *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+                        if constexpr (RES16) {
+                            if (g.res16) {
+                                const typename T16<T>::vec4 r = *(const typename T16<T>::vec4*)((const T*)g.res16 + (size_t)m * g.ldr16 + n);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[nt][mt][e] += T16<T>::to_f32(r[e]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // fragment byte offsets inside a stage: row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4), chunk = 4 ks + (lane >> 4); rows = base + 16 i + r16
+    int a_off[2], w_off[2];
+    {
+        const int sw = (r16 >> 1) & 7;                   // the same for row + 16 i
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 4 + fq) ^ sw) << 4;
+            a_off[ks] = (wr * (MT * 16) + r16) * ROWB + ch;
+            w_off[ks] = A_BYTES + (wc * (NT * 16) + r16) * ROWB + ch;
+        }
+    }
+
+    const int nk = g.K / 64;
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) issue_one(0, j);
+
+    vec8 fw[NT], fa[MC];
+    const bool grpB = wr == 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grpB) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // Intervals (global barrier index i), group A: R_j in 2j, M_j in 2j+1; group B one later (j = NI kt + ph).  Stage (kt+1)&1 is last
+    // read by B's R_{NI kt - 1} in interval 2 NI kt - 1 (B retires those reads - lgkmcnt(0) - before the barrier that ends it), so the
+    // DMA of tile kt+1 may be issued from interval 2 NI kt on: spread over the first NI-1 read phases of tile kt.  It has to be
+    // complete before A's R_{NI (kt+1)}: both groups drain vmcnt at the END of interval 2 NI (kt+1) - 1 (A after its last MFMA phase,
+    // B after its last read phase).
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        const char* st_ = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ph = 0; ph < NI; ++ph) {
+            const int ks = ph / NC, c = ph % NC;
+            if (c == 0) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) fw[i] = *(const vec8*)(st_ + w_off[ks] + i * (16 * ROWB));
+            }
+#pragma unroll
+            for (int i = 0; i < MC; ++i) fa[i] = *(const vec8*)(st_ + a_off[ks] + (c * MC + i) * (16 * ROWB));
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && ph < NI - 1) {
+#pragma unroll
+                for (int j = 0; j < LPT; ++j)
+                    if ((j * (NI - 1)) / LPT == ph) issue_one(kt + 1, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ph == NI - 1 && grpB) {
+                if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this stage is rewritten from the next interval on
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < MC; ++i) acc[nt][c * MC + i] = T16<T>::mfma16(fw[nt], fa[i], acc[nt][c * MC + i]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ph == NI - 1 && more && !grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();             // pairs group B's extra barrier
+
+    // ---- epilogue: 32 rows (two accumulator row-tiles) at a time through a wave-private LDS window -> full-row 16-B stores -------
+    __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring before it is reused
+    const int mw = m0 + wr * (MT * 16), nw = n0 + wc * (NT * 16);
+    if constexpr (EMODE == MODE_F32) {
+        constexpr int CH = NT * 4;                        // 16-B chunks (4 floats) per row: 16 or 24
+        constexpr int RB = NT * 64;
+        constexpr int SWZ = (CH & -CH) - 1;               // 15 or 7
+        auto swz = [](int row) { return RB % 256 == 0 ? (row & SWZ) : ((row >> 1) & SWZ); };
+        char* const stage = smem + wave * (32 * RB);
+#pragma unroll
+        for (int mp = 0; mp < MT / 2; ++mp) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x4 v = acc[nt][mp * 2 + h];
+                    const int nb = nw + nt * 16 + fq * 4;          // (the bias is re-read per row pair from L1: holding NT quads of it
+                    if (g.bias && nb < g.N) v += *(const f32x4*)(g.bias + nb);   //  over the epilogue spilled the wide tiles)
+                    if (g.act == VITG_ACT_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                    } else if (g.act == VITG_ACT_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                    }
+                    const int row = h * 16 + r16, c = nt * 4 + fq;
+                    *(f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4)) = v;
+                }
+            // the same wave reads back what it wrote: LDS operations of one wave complete in order
+            char* const ob = (char*)((float*)g.out + (size_t)(mw + mp * 32) * g.ldo + nw);
+#pragma unroll
+            for (int i = 0; i < 32 * CH / 64; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / CH, c = idx % CH;
+                f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4));
+                const int m = mw + mp * 32 + row, n = nw + c * 4;
+                if (m < g.M && n < g.N) {
+                    if (g.res && !acc_from_res) {
+                        const int rm = g.res_mod > 0 ? m % g.res_mod : m;
+                        v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
+                    }
+                    *(f32x4*)(ob + (unsigned)(row * g.ldo + c * 4) * 4u) = v;
+                }
+            }
+        }
+    } else {
+        constexpr int NTO = EMODE == MODE_SWIGLU ? NT / 2 : NT;        // output 16-column tiles per wave
+        constexpr int CH = NTO * 2;                                   // 16-B chunks (8 halfs) per row: 4, 8 or 12
+        constexpr bool POW2 = (CH & (CH - 1)) == 0;
+        constexpr int RB = NTO * 32 + (POW2 ? 0 : 16);                // padded rows when the chunk count is not a power of two
+        constexpr int SWZ = POW2 ? CH - 1 : 0;
+        constexpr int SH = CH == 4 ? 2 : CH == 8 ? 1 : 0;             // XOR takes the row bits above those that already spread over 256 B
+        char* const stage = smem + wave * (32 * RB);
+        const int n_out = EMODE == MODE_SWIGLU ? nw / 2 : nw;
+        const int n_lim = EMODE == MODE_SWIGLU ? g.N / 2 : g.N;
+#pragma unroll
+        for (int mp = 0; mp < MT / 2; ++mp) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    f32x4 v;
+                    if constexpr (EMODE == MODE_SWIGLU) {
+                        // weight rows are interleaved [32 gate | 32 up] (engine.pack_llm_layer): tiles 0-1 gate, 2-3 up of the wave's 64 features
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[nt][mp * 2 + h][e]) * acc[nt + NT / 2][mp * 2 + h][e];
+                    } else {
+                        v = acc[nt][mp * 2 + h];
+                        const int nb = nw + nt * 16 + fq * 4;      // (bias re-read per row pair from L1 instead of NT quads held over the epilogue)
+                        if (g.bias && nb < g.N) v += *(const f32x4*)(g.bias + nb);
+                        if (g.act == VITG_ACT_GELU_TANH) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                        } else if (g.act == VITG_ACT_GELU_ERF) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                        }
+                    }
+                    typename T16<T>::vec4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
+                    const int row = h * 16 + r16, c = nt * 2 + (fq >> 1);
+                    *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4) + (fq & 1) * 8) = o;
+                }
+            char* const ob = (char*)((T*)g.out + (size_t)(mw + mp * 32) * g.ldo + n_out);
+#pragma unroll
+            for (int i = 0; i < 32 * CH / 64; ++i) {
+                const int idx = i * 64 + lane;
+                const int row = idx / CH, c = idx % CH;
+                const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4));
+                const int m = mw + mp * 32 + row, n = n_out + c * 8;
+                if (m < g.M) {
+                    const unsigned boff = (unsigned)(row * g.ldo + c * 8) * 2u;
+                    if (n + 8 <= n_lim) *(u32x4*)(ob + boff) = v;
+                    else if (n + 4 <= n_lim) *(u32x2*)(ob + boff) = u32x2{v[0], v[1]};
+                }
+            }
+        }
+    }
+    if (vb + (int)gridDim.x < nwg_) {                    // another tile follows: every wave is done with its staging window
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    }   // tile loop
+}
+
+template <typename T, int MODE, int BM, int BN>
+static int launch16(GemmArgs g, hipStream_t s) {
+    constexpr int lds = 2 * (BM + BN) * 128;
+    static int done_dev[16] = {0};                       // per device: the attribute belongs to the device's copy of the kernel
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev >= 16 || !done_dev[cur_dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm16_kernel<T, MODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (cur_dev < 16) done_dev[cur_dev] = 1;
+    }
+    g.tiles_m = ceil_div(g.M, BM);
+    g.tiles_n = ceil_div(g.N, BN);
+    g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
+    static int cus_dev[16] = {0};
+    int cus = cur_dev < 16 ? cus_dev[cur_dev] : 0;
+    if (!cus) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur_dev);
+        if (cur_dev < 16) cus_dev[cur_dev] = cus;
+    }
+    const int nwg = g.tiles_m * g.tiles_n;
+    // one block per CU walking the tile list when there are at least two tiles per CU (gemm256.hip: "software relaunch")
+    const bool loop = nwg >= 2 * cus && !(tuning().gemm_flags & 0x1000000);
+    const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
+    hipLaunchKernelGGL((gemm16_kernel<T, MODE, BM, BN>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G16_THREADS), lds, s, g);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int MODE>
+static int launch16_m(const GemmArgs& g, int cfg, hipStream_t s) {
+    if (cfg == 10 && g.M >= 384) return launch16<T, MODE, 384, 256>(g, s);
+    if constexpr (MODE != MODE_SWIGLU) {
+        if (cfg == 9 && g.N >= 384) return launch16<T, MODE, 256, 384>(g, s);
+    }
+    return launch16<T, MODE, 256, 256>(g, s);
+}
+
+template <typename T>
+static int launch16_t(const GemmArgs& g, int mode, int cfg, hipStream_t s) {
+    if (mode == MODE_STORE16 && (g.res || g.res16)) return launch16_m<T, MODE_RES16>(g, cfg, s);
+    if (mode == MODE_SWIGLU) return launch16_m<T, MODE_SWIGLU>(g, cfg, s);
+    if (mode == MODE_F32) return launch16_m<T, MODE_F32>(g, cfg, s);
+    return launch16_m<T, MODE_STORE16>(g, cfg, s);
+}
+
+// cfg: the tile shape gemm256.hip's choose_cfg picked (6 = 256x256, 9 = 256x384, 10 = 384x256)
+int launch_gemm_mi16(const GemmArgs& g, int dtype, int mode, int cfg, hipStream_t s) {
+    return dtype == DT_BF16 ? launch16_t<bf16_t>(g, mode, cfg, s) : launch16_t<f16_t>(g, mode, cfg, s);
+}
+
+}  // namespace vitg
