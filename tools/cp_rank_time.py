@@ -38,6 +38,10 @@ class NoCommGatherer:
             torch.cuda.current_stream().wait_stream(producer_stream)
         return kv_all
 
+    def __call__(self, local):                                   # VITG_CP_OVERLAP=0: fused QKV projection, then this (round-2 form)
+        kv_all[plan.offset[rank]:plan.offset[rank] + local.shape[0]].copy_(local)
+        return kv_all
+
 
 gather = NoCommGatherer()
 
