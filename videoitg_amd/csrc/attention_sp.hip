@@ -37,13 +37,20 @@ namespace vitg {
 
 constexpr float LAZY_RESCALE_LOG2 = 8.0f;
 
-template <typename T, int D, int NW>
+// PV16 (round 3, hd 128): O^T += V^T P on v_mfma_f32_16x16x32 (eight 16-row d-tiles x 2 key blocks x 2 query tiles = 32 MFMAs of 16 cycles instead
+// of 16 of 32: same pipe cycles, the cheaper shape under the power cap - tools/ubench/mfma_shape_power.hip).  As in attention_ab.hip: P is re-laid
+// for the 16x16x32 B operand in registers (v_permlane32_swap + v_permlane16_swap per VGPR pair; here spread over the first four slices of the
+// interval that CONSUMES it), the V^T fragment of lane group g reads keys 32 kb + 16 (g >> 1) + 4 (g & 1) + {0..3, 8..11}.  V keeps its 256-B rows;
+// its chunk swizzle gains row bit 2 (the two lane groups of a half-wave read rows r..r+3 and r+4..r+7, which the round-2 swizzle put on the same
+// banks).  One PV "step" of the interleaved stream = one V^T fragment + its two MFMAs, so the slice structure is unchanged.
+template <typename T, int D, int NW, bool PV16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     adopt_device_key_count(a);
+    static_assert(!PV16 || D == 128, "PV16 is written for head dim 128");
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
     constexpr int KS = C::DK / 16;           // QK^T k-steps per 32-key half
-    constexpr int DT = C::DV / 32;           // PV d-tiles
+    constexpr int DT = PV16 ? C::DV / 16 : C::DV / 32;   // PV d-tiles (of 16 / 32 rows)
     constexpr int KT_BYTES = ATT_BK * C::LDK * 2, VT_BYTES = ATT_BK * C::LDV * 2;
     constexpr int V_BASE = 2 * KT_BYTES;     // LDS: [K0][K1][V0][V1]
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     auto dma_src = [&](int ii, int cpr, int rs, bool is_k, int row_lim) -> unsigned {
         const int j = ii * 64 + lane;
         int row = j / cpr, c = j % cpr;
-        if (D == 128) c = is_k ? (c ^ (row & 15)) : (c ^ ((row & 3) << 2));
+        if (D == 128) c = is_k ? (c ^ (row & 15)) : (c ^ ((row & 3) << 2) ^ (PV16 ? (((row >> 2) & 1) << 1) : 0));
         else c = min(c, C::CH - 1);          // pad slots re-read the row's last data chunk (finite filler)
         row = min(row, row_lim);
         return (unsigned)(row * rs + c * 8) * 2u;
@@ -128,16 +135,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     const char* kbase[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kbase[ks] = smem + k_lds_off<D>(ql, ks * 2 + h);      // + t*32 rows: row & 15 unchanged
+    const int g16 = lane >> 4;
     const int voff = (4 * h + ((lane & 15) >> 2)) * (C::LDV * 2) + ((((lane >> 4) & 1) * 16) + 4 * (lane & 3)) * 2;
     const char* vbase[DT];
+    if constexpr (PV16) {
+        // lane (d16 = lane & 15, g): rows 16 (g >> 1) + 4 (g & 1) + ((lane & 15) >> 2) (+ 32 kb, + 8 for the second read); 16-B chunk of d-tile dt:
+        // (2 dt + ((lane & 3) >> 1)) ^ swizzle(row), swizzle = ((row & 3) << 2) ^ (((row >> 2) & 1) << 1) - a function of the lane only
+        const int vrow = 16 * (g16 >> 1) + 4 * (g16 & 1) + ((lane & 15) >> 2);
+        const int xs = (((lane & 15) >> 2) << 2) ^ ((g16 & 1) << 1);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) vbase[dt] = smem + V_BASE + voff + (D == 128 ? ((dt ^ ((lane & 15) >> 2)) * 64) : dt * 64);
+        for (int dt = 0; dt < DT; ++dt)
+            vbase[dt] = smem + V_BASE + vrow * (C::LDV * 2) + (((2 * dt + ((lane & 3) >> 1)) ^ xs) << 4) + (lane & 1) * 8;
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vbase[dt] = smem + V_BASE + voff + (D == 128 ? ((dt ^ ((lane & 15) >> 2)) * 64) : dt * 64);
+    }
 
-    f32x16 o[DT];
+    // accumulators: 32x32 layout o[dt][r] = O[q][32 dt + 8 (r >> 2) + 4 h + (r & 3)], or (PV16) o16[dt][qt][r] = O[16 qt + (lane & 15)][16 dt + 4 (lane >> 4) + r]
+    f32x16 o[PV16 ? 1 : DT];
+    f32x4 o16[PV16 ? DT : 1][2];
 #pragma unroll
-    for (int i = 0; i < DT; ++i)
+    for (int i = 0; i < (PV16 ? 1 : DT); ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (PV16 ? DT : 1); ++i) { o16[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o16[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float m_run = -1e30f, l_run = 0.f;
     const int nkt = ceil_div(a.Sk, ATT_BK);
 
@@ -151,8 +173,37 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
                 s[t] = ks == 0 ? T16<T>::mfma32(kf, qf[0], f32x16{}) : T16<T>::mfma32(kf, qf[ks], s[t]);
             }
     };
+    // PV16: VGPR index i (0..3) of the register pair (p[2kb], p[2kb+1]) -> B operands of query tile 0 / 1 (rows [(2kb,h0) (2kb,h1) (2kb+1,h0) (2kb+1,h1)])
+    auto swap_p = [&](vec8 (&p)[4], int kb, int i) {
+        u32x4 X = bitcast<u32x4>(p[2 * kb]), Y = bitcast<u32x4>(p[2 * kb + 1]);
+        const u32x2 t = __builtin_amdgcn_permlane32_swap(X[i], Y[i], false, false);
+        const u32x2 u = __builtin_amdgcn_permlane16_swap(t[0], t[1], false, false);
+        X[i] = u[0]; Y[i] = u[1];
+        p[2 * kb] = bitcast<vec8>(X); p[2 * kb + 1] = bitcast<vec8>(Y);
+    };
+    auto v16_frag = [&](int vbuf, int kb, int dt) -> vec8 {
+        const char* a0 = vbase[dt] + (vbuf * VT_BYTES + kb * 32 * (C::LDV * 2));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 8 * (C::LDV * 2)));
+        return bitcast<vec8>(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     // O += V^T P^T for one tile out of V buffer `vbuf`; k-step kk covers keys (kk>>1)*32 + (kk&1)*16 + {8*(j>>2) + 4*h + (j&3)}
-    auto pv_mfma = [&](int vbuf, const vec8 (&p)[4]) {
+    // (the drain after the last interval; PV16: p is still in the softmax layout here and is re-laid first)
+    auto pv_mfma = [&](int vbuf, vec8 (&p)[4]) {
+        if constexpr (PV16) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) swap_p(p, kb, i);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const vec8 vf = v16_frag(vbuf, kb, dt);
+                    o16[dt][0] = T16<T>::mfma16(vf, p[2 * kb], o16[dt][0]);
+                    o16[dt][1] = T16<T>::mfma16(vf, p[2 * kb + 1], o16[dt][1]);
+                }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -162,11 +213,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 8 * (C::LDV * 2)));
                 o[dt] = T16<T>::mfma32(bitcast<vec8>(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), p[kk], o[dt]);
             }
+        }
     };
 
     // One barrier interval.  PAR = t & 1.  s_cur = S(t) (in), s_nxt = S(t+1) (out), p_cur = P(t) (out), p_prv = P(t-1) (in).
     auto interval = [&](int t, auto par_c, auto qk_c, auto pv_c, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], vec8 (&p_cur)[4],
-                        const vec8 (&p_prv)[4]) {
+                        vec8 (&p_prv)[4]) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool HAS_QK = decltype(qk_c)::value, HAS_PV = decltype(pv_c)::value;
         if (!(PROF_BUILD && (a.ablate & 8))) {                             // (ablate: profiling only, tools/attn_ablate.py)
@@ -185,10 +237,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
         // MFMA i of the interval (QK^T steps first, then PV steps) is followed by slice i of the softmax VALU stream; a
         // sched_barrier after every slice keeps the machine scheduler from re-bunching either stream.  The LDS fragment for
         // MFMA i+2 is requested in slice i (three fragment registers in rotation).
-        constexpr int NQK = HAS_QK ? 2 * KS : 0, NPV = HAS_PV ? 4 * DT : 0, NM = NQK + NPV;
+        constexpr int NQK = HAS_QK ? 2 * KS : 0, NPV = HAS_PV ? (PV16 ? 2 * DT : 4 * DT) : 0, NM = NQK + NPV;
+        static_assert(!PV16 || !HAS_PV || NQK == 0 || NQK >= 4, "the P re-layout of PV16 rides the first four slices, ahead of the first PV step");
         auto frag = [&](int i) -> vec8 {
             if (i < NQK) return *(const vec8*)(kbase[i % KS] + ((PAR ^ 1) * KT_BYTES + (i / KS) * 32 * (C::LDK * 2)));
             const int j = i - NQK, kk = j / DT, dt = j % DT;
+            if constexpr (PV16) return v16_frag(PAR ^ 1, kk, dt);          // kk = key block (0 / 1), one fragment feeds both query tiles
             const char* a0 = vbase[dt] + ((PAR ^ 1) * VT_BYTES + ((kk >> 1) * 32 + (kk & 1) * 16) * (C::LDV * 2));
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 8 * (C::LDV * 2)));
@@ -200,6 +254,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
                 s_nxt[tt] = ks == 0 ? T16<T>::mfma32(f, qf[0], f32x16{}) : T16<T>::mfma32(f, qf[ks], s_nxt[tt]);
             } else {
                 const int j = i - NQK;
+                if constexpr (PV16) {
+                    o16[j % DT][0] = T16<T>::mfma16(f, p_prv[2 * (j / DT)], o16[j % DT][0]);
+                    o16[j % DT][1] = T16<T>::mfma16(f, p_prv[2 * (j / DT) + 1], o16[j % DT][1]);
+                } else
                 o[j % DT] = T16<T>::mfma32(f, p_prv[j / DT], o[j % DT]);
             }
         };
@@ -242,11 +300,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) exp_pair(e);
         } else {
+            if constexpr (PV16 && HAS_PV && NQK == 0) {                  // (last interval of a sequence: no QK^T steps to hide the re-layout behind)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) swap_p(p_prv, kb, q);
+            }
             vec8 fr[3];
             fr[0] = frag(0);
             fr[1] = frag(1);
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
+                if constexpr (PV16 && HAS_PV && NQK > 0) {
+                    if (i < 4) { swap_p(p_prv, i >> 1, (i & 1) * 2); swap_p(p_prv, i >> 1, (i & 1) * 2 + 1); }
+                }
                 if (i + 2 < NM && !(PROF_BUILD && (a.ablate & 16) && i + 2 > NQK)) fr[(i + 2) % 3] = frag(i + 2);      // (ablate bit4: profiling - V^T fragments not re-read)
                 mfma_step(i, fr[i % 3]);
                 if (i < 2) row_max(i);
@@ -265,10 +332,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
         if (grew_late) {                                   // after the PV(t-1) MFMAs: P(t-1) was relative to the old max
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
+            if constexpr (PV16) {
+                const u32x2 aa = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(alpha), bitcast<uint32_t>(alpha), false, false);
+                const float a0 = bitcast<float>(aa[0]), a1 = bitcast<float>(aa[1]);
+#pragma unroll
+                for (int i = 0; i < DT; ++i) { o16[i][0] *= a0; o16[i][1] *= a1; }
+            } else {
 #pragma unroll
             for (int i = 0; i < DT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
             m_run = m_new;
         }
         l_run += psum2[0] + psum2[1];
@@ -313,6 +387,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     // ---- epilogue: lane (q, h) holds O[q][dt*32 + 8*(r>>2) + 4*h + (r&3)] -------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    if constexpr (PV16) {
+        const u32x2 ii = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(inv), bitcast<uint32_t>(inv), false, false);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float iq = bitcast<float>(ii[qt]);
+            const int qrow = q0 + 16 * qt + (lane & 15);
+            if (qrow < a.S) {
+                T* op = (T*)a.o + b * a.o_bs + (long)head * a.o_hs + (long)qrow * a.o_rs;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    typename T16<T>::vec4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = T16<T>::from_f32(o16[dt][qt][e] * iq);
+                    *(typename T16<T>::vec4*)(op + dt * 16 + 4 * g16) = w;
+                }
+            }
+        }
+    } else {
     const int qrow = q0 + ql;
     if (qrow < a.S) {
         T* op = (T*)a.o + b * a.o_bs + (long)head * a.o_hs + (long)qrow * a.o_rs;
@@ -329,9 +421,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
                 }
             }
     }
+    }
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, bool PV16 = false>
 static int launch_sp(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
@@ -339,15 +432,18 @@ static int launch_sp(AttnArgs a, int batch, int heads, hipStream_t s) {
     static std::atomic<unsigned> done_mask{0};   // per device: the attribute belongs to the device's copy of the kernel
     const int cur_dev = current_device();
     if (!device_done(done_mask, cur_dev)) {
-        (void)hipFuncSetAttribute((const void*)attn_sp_kernel<T, D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_sp_kernel<T, D, NW, PV16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         mark_device_done(done_mask, cur_dev);
     }
-    hipLaunchKernelGGL((attn_sp_kernel<T, D, NW>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_sp_kernel<T, D, NW, PV16>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
-// called by vitg_attention (attention.hip)
-int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, hipStream_t s) {
+// called by vitg_attention (attention.hip).  hd 128 with 8 waves runs PV on v_mfma_f32_16x16x32 (round 3) unless pv32 asks for the round-2 form
+// (attn_sp = 3: A/B and cross-check)
+int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv32, hipStream_t s) {
+    if (head_dim == 128 && nw == 8 && !pv32)
+        return dtype == DT_BF16 ? launch_sp<bf16_t, 128, 8, true>(a, batch, heads, s) : launch_sp<f16_t, 128, 8, true>(a, batch, heads, s);
 #define SP(T, D) (nw == 3 ? launch_sp<T, D, 3>(a, batch, heads, s) : nw == 4 ? launch_sp<T, D, 4>(a, batch, heads, s) : launch_sp<T, D, 8>(a, batch, heads, s))
     if (dtype == DT_BF16) return head_dim == 72 ? SP(bf16_t, 72) : SP(bf16_t, 128);
     return head_dim == 72 ? SP(f16_t, 72) : SP(f16_t, 128);
