@@ -451,7 +451,7 @@ static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv32, hipStream_t s);   // attention_sp.hip
+int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv16, hipStream_t s);   // attention_sp.hip
 int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, bool pv32, hipStream_t s);                 // attention_ab.hip
 
 }  // namespace vitg
@@ -518,13 +518,13 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     // equal to the plain loop (549 vs 555 TF/s, profiles/r01_attention.md), so it is opt-in: attn_pipe = 1
     // Software-pipelined loop (attention_sp.hip): default for hd 128 (LLM shape 1023 vs 916 TF/s); for hd 72 the per-tile
     // kernel at 4 waves/SIMD is still ahead (630 vs 597 TF/s), profiles/r01_attention.md.  attn_sp = 1 / 2 pins it on / off.
-    if (tr && (tuning().attn_sp == 1 || tuning().attn_sp == 3 || (tuning().attn_sp == 0 && head_dim == 128 && !a.ablate))) {
+    if (tr && (tuning().attn_sp == 1 || ((tuning().attn_sp == 0 || tuning().attn_sp == 3) && head_dim == 128 && !a.ablate))) {
         rc = attention_sp_dispatch(a, batch, heads, head_dim, dtype, nw, tuning().attn_sp == 3, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
     // hd 72 default: the half-tile-out-of-phase kernel (attention_ab.hip, +5 % over the per-tile loop in same-call A/B) whenever
     // 256-query blocks fill the chip and no other variant is pinned; attn_ab = 1 / 2 forces it on / off
-    const bool ab_auto = tuning().attn_ab == 0 && !nw_env && nw == 8 && !tuning().attn_pipe && !tuning().attn_dma && tuning().attn_sp != 1 && tuning().attn_sp != 3;
+    const bool ab_auto = tuning().attn_ab == 0 && !nw_env && nw == 8 && !tuning().attn_pipe && !tuning().attn_dma && tuning().attn_sp != 1;
     if (tr && head_dim == 72 && !a.ablate && (tuning().attn_ab == 1 || tuning().attn_ab == 3 || tuning().attn_ab == 4 || ab_auto) && tuning().attn_sp != 1) {
         rc = attention_ab_dispatch(a, batch, heads, dtype, tuning().attn_ab == 3 ? 16 : 8, tuning().attn_ab == 4, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;

@@ -37,7 +37,7 @@ namespace vitg {
 
 constexpr float LAZY_RESCALE_LOG2 = 8.0f;
 
-// PV16 (round 3, hd 128): O^T += V^T P on v_mfma_f32_16x16x32 (eight 16-row d-tiles x 2 key blocks x 2 query tiles = 32 MFMAs of 16 cycles instead
+// PV16 (round 3, hd 128; OPT-IN - measured slower than the 32x32x16 form, see attention_sp_dispatch): O^T += V^T P on v_mfma_f32_16x16x32 (eight 16-row d-tiles x 2 key blocks x 2 query tiles = 32 MFMAs of 16 cycles instead
 // of 16 of 32: same pipe cycles, the cheaper shape under the power cap - tools/ubench/mfma_shape_power.hip).  As in attention_ab.hip: P is re-laid
 // for the 16x16x32 B operand in registers (v_permlane32_swap + v_permlane16_swap per VGPR pair; here spread over the first four slices of the
 // interval that CONSUMES it), the V^T fragment of lane group g reads keys 32 kb + 16 (g >> 1) + 4 (g & 1) + {0..3, 8..11}.  V keeps its 256-B rows;
@@ -439,10 +439,11 @@ static int launch_sp(AttnArgs a, int batch, int heads, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// called by vitg_attention (attention.hip).  hd 128 with 8 waves runs PV on v_mfma_f32_16x16x32 (round 3) unless pv32 asks for the round-2 form
-// (attn_sp = 3: A/B and cross-check)
-int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv32, hipStream_t s) {
-    if (head_dim == 128 && nw == 8 && !pv32)
+// called by vitg_attention (attention.hip).  pv16 (attn_sp = 3, hd 128 with 8 waves): PV on v_mfma_f32_16x16x32 - built, bit-for-bit tested and
+// measured 3-4 % SLOWER than PV on 32x32x16 here (2.50-2.54 against 2.43 ms on the LLM shape, profiles/r03_attention.md): there is no padding to drop
+// at hd 128, the 16x16 shape issues at ~17 instead of 16 cycles and the re-layout adds 16 swaps to a hand-interleaved stream.  Opt-in, not the default.
+int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv16, hipStream_t s) {
+    if (head_dim == 128 && nw == 8 && pv16)
         return dtype == DT_BF16 ? launch_sp<bf16_t, 128, 8, true>(a, batch, heads, s) : launch_sp<f16_t, 128, 8, true>(a, batch, heads, s);
 #define SP(T, D) (nw == 3 ? launch_sp<T, D, 3>(a, batch, heads, s) : nw == 4 ? launch_sp<T, D, 4>(a, batch, heads, s) : launch_sp<T, D, 8>(a, batch, heads, s))
     if (dtype == DT_BF16) return head_dim == 72 ? SP(bf16_t, 72) : SP(bf16_t, 128);

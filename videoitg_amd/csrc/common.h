@@ -115,7 +115,7 @@ struct Tuning {
     int attn_pipe;     // 0 off (default) | 1 cross-tile pipelined hd-72 variant
     int attn_dma;      // 0 auto (DMA for hd 72, registers for hd 128) | 1 LDS-DMA K/V staging | 2 register staging
     int attn_ab;       // hd 72: 0 auto | 1 half-tile-out-of-phase kernel (attention_ab.hip) | 2 off | 3 the same kernel with 16 waves / 512 queries per block | 4 its PV-on-32x32x16 form
-    int attn_sp;       // 0 auto | 1 software-pipelined kernel (attention_sp.hip) | 2 per-tile kernel (attention.hip) | 3 software-pipelined, PV on 32x32x16
+    int attn_sp;       // 0 auto | 1 software-pipelined kernel (attention_sp.hip) | 2 per-tile kernel (attention.hip) | 3 hd 128: software-pipelined with PV on 16x16x32 (opt-in, slower)
 };
 Tuning& tuning();
 
