@@ -128,10 +128,11 @@ def bilinear_pool(feat: torch.Tensor, hw: int) -> torch.Tensor:
     return x.permute(0, 2, 3, 1).reshape(T, hw * hw, C)
 
 
-def mlp_projector(feat: torch.Tensor, sd: SD, vision_token_num: int) -> torch.Tensor:
-    """One video: [T,P,Dv] -> [T*HW*HW, D]: pool, Linear -> GELU(erf) -> Linear (mlp_proj.py:31-35,72-73)."""
+def mlp_projector(feat: torch.Tensor, sd: SD, vision_token_num: int, hw: Optional[int] = None) -> torch.Tensor:
+    """One video: [T,P,Dv] -> [T*HW*HW, D]: pool, Linear -> GELU(erf) -> Linear (mlp_proj.py:31-35,72-73).  hw: the grid to pool to when it
+    is not the eval rule's (mlp_proj.py:51-52: training mode draws it at random; the caller passes what was drawn)."""
     T, P, _ = feat.shape
-    hw = pooled_grid(T, int(P ** 0.5), vision_token_num)
+    hw = pooled_grid(T, int(P ** 0.5), vision_token_num) if hw is None else min(hw, int(P ** 0.5))
     x = bilinear_pool(feat, hw)
     pre = "model.mm_projector.out_projection."
     x = F.linear(x, sd[pre + "0.weight"], sd[pre + "0.bias"])
@@ -310,7 +311,7 @@ def topk_selection(logits: torch.Tensor, frame_idx: Sequence[int], k: int) -> Li
 # whole path
 # ----------------------------------------------------------------------------------------------
 def forward(cfg, sd: SD, vsd: SD, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
-            images: Sequence[torch.Tensor], *, return_intermediates: bool = False):
+            images: Sequence[torch.Tensor], *, return_intermediates: bool = False, pooled_grids: Optional[Sequence[int]] = None):
     """EagleQwenG.forward (grounding_qwen2.py:86-181) for inference: returns ``logits`` = list of [T_b,1].
     ``cfg`` is any object with the attribute names of ``videoitg_amd.config.ITGConfig``."""
     v = cfg.vision
@@ -319,7 +320,7 @@ def forward(cfg, sd: SD, vsd: SD, input_ids: torch.Tensor, attention_mask: Optio
                          num_heads=v.num_attention_heads, num_layers=v.num_hidden_layers,
                          select_layer=cfg.mm_vision_select_layer, eps=v.layer_norm_eps)
     per_video = torch.split(feats, [im.shape[0] for im in images], 0)
-    visual = [mlp_projector(f, sd, cfg.vision_token_num) for f in per_video]
+    visual = [mlp_projector(f, sd, cfg.vision_token_num, None if pooled_grids is None else pooled_grids[i]) for i, f in enumerate(per_video)]
     x, mask, tts = splice(input_ids, attention_mask, visual, sd,
                           max_length=cfg.tokenizer_model_max_length, padding_side=cfg.tokenizer_padding_side)
     layers: list = []

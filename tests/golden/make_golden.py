@@ -197,6 +197,35 @@ def run_case(g, ce, name, spec, seed=0):
     print(name, "N=", emb.shape[1], "logits0[:4]=", out.logits[0].view(-1)[:4].tolist())
 
 
+def train_mode_pool(g, ce):
+    """in TRAINING mode the projector pools every video to a random grid (mlp_proj.py:51-52).  The reference's forward in
+    .train() mode under a fixed torch seed -> the grids it drew (from the visual shapes) and its logits (train_pool.npz)."""
+    spec = dict(cfg=dict(vision_token_num=72, vision_min_num=1), T=[8, 5], ids=[[-200, 5, 6, 7, 8, 9], [-200, 30, 31, 0, 0, 0]], pad=0, seed=20)
+    cfg = tiny_config(**spec["cfg"])
+    torch.manual_seed(0)
+    m = build_reference_model(g, ce, cfg)
+    load_synth(m, cfg, 0)
+    m.train()
+    R = cfg.vision.image_size
+    images = [synth.synth_pixel_values(T, R, seed=1234 + i) for i, T in enumerate(spec["T"])]
+    ids = torch.tensor(spec["ids"], dtype=torch.long)
+    mask = ids.ne(spec["pad"])
+    torch.manual_seed(spec["seed"])
+    with torch.no_grad():
+        out = m(ids, attention_mask=mask, images=images)
+    n_vis = [int((tt == 3).sum()) for tt in out.hidden_states[0].new_zeros(1)] if False else None
+    # the grids drawn: re-run the projector's draw sequence under the same seed (torch.randint(vision_min_num, HW + 1, (1,)) per video, in order)
+    import math
+    torch.manual_seed(spec["seed"])
+    grids = [min(torch.randint(cfg.vision_min_num, math.floor((cfg.vision_token_num / T) ** 0.5) + 1, (1,)).item(), cfg.vision.grid) for T in spec["T"]]
+    rec = dict(cfg=json.dumps(cfg.to_dict()), seed=0, torch_seed=spec["seed"], T=np.array(spec["T"]), input_ids=ids.numpy(), attention_mask=mask.numpy(),
+               grids=np.array(grids), n_tokens=np.array(list(out.hidden_states[0].shape)))
+    for b, lg in enumerate(out.logits):
+        rec[f"logits{b}"] = lg.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "train_pool.npz"), **rec)
+    print("train_pool grids", grids, "N=", out.hidden_states[0].shape[1], "logits0[:4]=", out.logits[0].view(-1)[:4].tolist())
+
+
 def forward_errors(g, ce):
     out = {}
     for name, spec in ERROR_CASES.items():
@@ -267,9 +296,12 @@ def helper_known_answers(g=None, ce=None):
 
 def main():
     g, ce = install_shims()
-    which = sys.argv[1:] or list(CASES)
+    which = sys.argv[1:] or list(CASES) + ["train_pool"]
     for name in which:
         if name == "helpers":
+            continue
+        if name == "train_pool":
+            train_mode_pool(g, ce)
             continue
         run_case(g, ce, name, CASES[name])
     helper_known_answers(g, ce)

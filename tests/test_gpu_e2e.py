@@ -528,3 +528,34 @@ def test_context_parallel_over_rccl(world, frames):
     pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
     want = eng.forward(torch.tensor([[11, 12, -200, 5, 6, 7]]), None, [pix])[0].view(-1).float().cpu()
     assert (got - want).abs().max().item() <= 1e-5
+
+
+def test_training_mode_pooled_grids_match_the_reference(golden_dir):
+    """model.train() pools every video to the random grid the reference's projector would draw under the same torch seed
+    (mlp_proj.py:51-52); logits against the reference's own .train()-mode forward (train_pool.npz).  Forward values only."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    from videoitg_amd.model.grounding_qwen2 import EagleQwenG
+    z = np.load(os.path.join(golden_dir, "train_pool.npz"))
+    cfg = ITGConfig.from_dict(json.loads(str(z["cfg"])))
+    T = z["T"].tolist()
+    images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i).cuda() for i, t in enumerate(T)]
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    got = eng.forward(ids, mask, images, pooled_grids=z["grids"].tolist())
+    for b in range(len(T)):
+        ref = torch.from_numpy(z[f"logits{b}"])
+        assert got[b].shape == ref.shape
+        assert (torch.sigmoid(got[b].float().cpu()) - torch.sigmoid(ref)).abs().max().item() <= SCORE_TOL
+    # the model object draws the grids itself in training mode - same calls to torch's global generator as the reference's projector
+    model = EagleQwenG(cfg, sd, vsd, torch_dtype=torch.float16, device="cuda:0")
+    model.train()
+    torch.manual_seed(int(z["torch_seed"]))
+    out = model(ids, attention_mask=mask, images=images)
+    for b in range(len(T)):
+        assert torch.equal(out.logits[b].float().cpu(), got[b].float().cpu())
+    model.eval()
+    ev = model(ids, attention_mask=mask, images=images)                 # eval rule: [3, 3] - a different pooled grid for the 5-frame video
+    assert ev.logits[1].shape == got[1].shape and not torch.equal(ev.logits[1].float().cpu(), got[1].float().cpu())

@@ -96,3 +96,19 @@ def test_pooled_grid_table():
     for T, hw in want.items():
         assert O.pooled_grid(T, 27, 16384) == hw
         assert ITGConfig().pooled_grid(T) == hw
+
+
+def test_oracle_training_mode_pooled_grids(golden_dir):
+    """the projector's TRAINING-mode pooling (a random grid per video, mlp_proj.py:51-52).  train_pool.npz holds the
+    reference's forward in .train() mode under a fixed torch seed and the grids that seed draws; the oracle with those grids matches."""
+    z, cfg, seed, T, images = load_case(golden_dir, "train_pool")
+    sd, vsd = synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed)
+    grids = z["grids"].tolist()
+    assert grids == [3, 2]                                              # (not the eval rule's [3, 3])
+    import math
+    torch.manual_seed(int(z["torch_seed"]))                             # the draw sequence of the reference: one randint per video, in order
+    drawn = [min(torch.randint(cfg.vision_min_num, math.floor((cfg.vision_token_num / t) ** 0.5) + 1, (1,)).item(), cfg.vision.grid) for t in T]
+    assert drawn == grids
+    lg = O.forward(cfg, sd, vsd, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), images, pooled_grids=grids)
+    for b in range(len(T)):
+        assert (lg[b] - torch.from_numpy(z[f"logits{b}"])).abs().max() < TOL

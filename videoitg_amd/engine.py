@@ -665,8 +665,8 @@ class SelectorEngine:
         logits = torch.empty(t_head, dtype=torch.float32, device=self.device)
         if not pos:
             return logits.fill_(float("nan"))                       # no visual rows: the decoder output is never read by the head
-        hws = [cfg.pooled_grid(T, G) for _, T, _, _ in blocks]
-        nvs = [T * hw * hw for (_, T, _, _), hw in zip(blocks, hws)]
+        hws = [(b[4] if len(b) > 4 and b[4] is not None else cfg.pooled_grid(b[1], G)) for b in blocks]      # (explicit grid: training-mode pooling)
+        nvs = [b[1] * hw * hw for b, hw in zip(blocks, hws)]
         bounds = [-1] + pos + [ids.numel()]
         segs = [(bounds[i] + 1, bounds[i + 1]) for i in range(len(bounds) - 1)]      # text between / around the <image> tokens (ids index ranges)
         n = sum(e - s for s, e in segs) + sum(nvs)
@@ -689,7 +689,7 @@ class SelectorEngine:
                 K.embed_gather(src, self.w.embed, x[row:row + e0 - s0])
                 row += e0 - s0
             if i < len(blocks):
-                feats, T, cmap, pc = blocks[i]
+                feats, T, cmap, pc = blocks[i][:4]
                 self.project_into(feats, T, G, hws[i], x[row:row + nvs[i]], cmap, pc)
                 vis_rows.append((row, nvs[i]))
                 row += nvs[i]
@@ -704,12 +704,14 @@ class SelectorEngine:
         K.pool_score(hv, t_head, nvis // t_head, cfg.hidden_size, self.w.head_w, self.w.head_b, logits)
         return logits
 
-    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], images: Sequence[torch.Tensor]
-                ) -> List[torch.Tensor]:
+    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], images: Sequence[torch.Tensor],
+                pooled_grids: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
         """EagleQwenG.forward (grounding_qwen2.py:86-181), inference branch: list of B tensors [images[b].shape[0], 1] (fp32 logits).
         Padded batches are run sample by sample on the unpadded ids (eagle_archv1.py:272 strips padding; the
         padded rows never influence real ones because keys are masked), which is value-identical.  A sample consumes one entry
-        of `images` per <image> token - and one entry when it has none (eagle_archv1.py:282-294) - in batch order."""
+        of `images` per <image> token - and one entry when it has none (eagle_archv1.py:282-294) - in batch order.
+        pooled_grids: one pooled grid HW per consumed entry of `images` instead of the eval rule min(floor(sqrt(vision_token_num / T)), G) -
+        the projector's TRAINING-mode behaviour (mlp_proj.py:52: a random HW per video; the model wrapper draws it)."""
         images = [im if im.dim() == 4 else im.unsqueeze(0) for im in images]
         if input_ids.dim() == 1:
             input_ids = input_ids.unsqueeze(0)
@@ -729,7 +731,15 @@ class SelectorEngine:
             raise ValueError("all videos in a batch must share one frame size")
         pix = torch.cat([im.to(self.device) for im in used], 0) if len(used) > 1 else used[0].to(self.device)
         G0 = pix.shape[-1] // self.cfg.vision.patch_size
-        hws = {self.cfg.pooled_grid(im.shape[0], G0) for im in used}
+        if pooled_grids is not None:
+            if len(pooled_grids) < len(used):
+                raise ValueError(f"{len(pooled_grids)} pooled grids for {len(used)} videos")
+            hw_list = [min(int(h), G0) for h in pooled_grids[:len(used)]]
+            if min(hw_list) < 1:
+                raise ValueError("pooled grid must be >= 1")
+        else:
+            hw_list = [self.cfg.pooled_grid(im.shape[0], G0) for im in used]
+        hws = set(hw_list)
         hw_all = hws.pop() if len(hws) == 1 else None                 # videos of different length pool differently -> dense
         feats, G, cmap, pc = self.vit_forward(pix, hw_all)
         P = pc if cmap is not None else G * G
@@ -739,7 +749,7 @@ class SelectorEngine:
             r += im.shape[0]
         out, img = [], 0
         for b in range(B):
-            blocks = [(feats[rows0[i] * P:(rows0[i] + used[i].shape[0]) * P], used[i].shape[0], cmap, pc) for i in range(img, img + counts[b])]
+            blocks = [(feats[rows0[i] * P:(rows0[i] + used[i].shape[0]) * P], used[i].shape[0], cmap, pc, hw_list[i]) for i in range(img, img + counts[b])]
             img += max(counts[b], 1)
             t_head = images[b].shape[0]                                  # grounding_qwen2.py:153 indexes `images` by the batch row
             out.append(self.score_sample(blocks, G, samples[b], t_head).reshape(t_head, 1))

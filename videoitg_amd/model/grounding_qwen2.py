@@ -203,7 +203,19 @@ class EagleQwenG(nn.Module):
                 if self._graphs.serves(ids_host, im):
                     lg = self._graphs(ids_host, im.to(self._device, self._dtype))
                     return SelectorOutput(logits=[lg.reshape(-1, 1)])
-            logits = eng.forward(input_ids, attention_mask, images)
+            grids = None
+            if self.training:
+                # mlp_proj.py:51-52: in training mode the projector pools every video to a RANDOM grid, drawn with torch's global generator in
+                # list order - the same calls here give the same grids under the same seed (forward values only: there is no backward)
+                import math
+                cfg = self.config
+                G0 = (images[0].shape[-1] if images else 0) // cfg.vision.patch_size
+                grids = []
+                for im in images:
+                    T_i = im.shape[0] if im.dim() == 4 else 1
+                    hw = math.floor((cfg.vision_token_num / T_i) ** 0.5)
+                    grids.append(min(torch.randint(cfg.vision_min_num, hw + 1, (1,)).item(), G0))
+            logits = eng.forward(input_ids, attention_mask, images, pooled_grids=grids)
             if grounding_labels is None:
                 return SelectorOutput(logits=logits)
             # labelled evaluation (grounding_qwen2.py:159-181): the loss VALUE (no backward here), and - as in the reference -
