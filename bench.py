@@ -353,6 +353,7 @@ def main():
     timer = GemmTimer()
     ops.gemm = timer.wrap(ops.gemm)
     ops.gemm_splitk = timer.wrap(ops.gemm_splitk)       # (the o / down projections of a context-parallel rank; includes their reduce kernel)
+    ops.gemm_streamk = timer.wrap(ops.gemm_streamk)     # (the same projections on the stream-K partition; includes the reduce kernel)
     ops.gemm_res16 = timer.wrap(ops.gemm_res16)         # (patch embedding, out-proj and fc2 of the tower on its 16-bit residual stream)
     timer8 = GemmTimer()                                # --fp8: the layer GEMMs run here; patch-embed / projector stay on ops.gemm
     if args.fp8:

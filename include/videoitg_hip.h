@@ -107,6 +107,16 @@ int vitg_gemm_splitk_plan(int M, int N, int K, int* splits, long* workspace_byte
 int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
                      int ldo, const float* res, int ldr, float* workspace, int splits, void* stream);
 
+/* Stream-K form of the same GEMM (round 3) for FEWER output tiles than CUs and a long K - the same shapes one rank of an 8-GPU run has
+ * (o: 98 tiles x 56 K-tiles, down: 98 x 296 on 256 CUs), where split-K x2 leaves 60 CUs idle: the K-tiles of all output tiles are laid end to end
+ * and cut into equal runs, one per block (a block covers the tail of one tile and the head of the next); each segment's raw fp32 partial tile goes
+ * to its own workspace slot and a second kernel adds a tile's segments in block order, the bias and the residual (no atomics: bit-reproducible).
+ * vitg_gemm_streamk_plan: blocks == 0 means "does not apply" (use vitg_gemm_splitk_plan / vitg_gemm); otherwise pass blocks and a workspace of
+ * workspace_bytes to vitg_gemm_streamk.  out = A W^T + bias + res (fp32). */
+int vitg_gemm_streamk_plan(int M, int N, int K, int* blocks, long* workspace_bytes);
+int vitg_gemm_streamk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
+                      int ldo, const float* res, int ldr, float* workspace, int blocks, void* stream);
+
 /* ---- FP8 weight path (BASELINE.json configs[4]; videoitg_amd/csrc/gemm_fp8.hip) ------------------------------------------------
  * The reference runs fp16 everywhere (/root/reference/eagle/model/builder.py:59), so this is an additional precision tier of the
  * same GEMM call sites as vitg_gemm: weights are stored as OCP e4m3fn bytes with one fp32 scale per OUTPUT CHANNEL (quantised

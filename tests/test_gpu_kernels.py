@@ -455,3 +455,36 @@ def test_dispatcher_ops_with_residual_aliasing_output(ops, dtype):
     assert torch.equal(sep16, ali16)
     with pytest.raises(NotImplementedError):                      # no CPU registration: the product has no host path
         torch.ops.videoitg.gemm(a.cpu(), w.cpu(), sep.cpu(), ops.GEMM_F32, None, b.cpu(), 0, None, 0, None)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1660, 3584, 3584), (1660, 3584, 18944), (700, 1024, 4096), (300, 520, 2048), (1660, 1152, 2048)])
+def test_gemm_streamk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K):
+    """stream-K (o / down projection of one context-parallel rank: fewer output tiles than CUs): every block gets an equal run of K-tiles across tile
+    boundaries, partial tiles are added in block order.  Same value as the one-pass fp32-residual GEMM up to fp32 re-association, bit-identical from
+    run to run (no atomics); ragged M / N tiles included."""
+    blocks, nbytes = ops.gemm_streamk_plan(M, N, K)
+    if blocks == 0:
+        pytest.skip("stream-K does not apply to this shape on this device")
+    a, w = rnd((M, K), 41, dtype=dtype).to(dtype).cuda(), (rnd((N, K), 42, dtype=dtype) * K ** -0.5).to(dtype).cuda()
+    bias, res = rnd((N,), 43).cuda(), rnd((M, N), 44).cuda()
+    want = res.clone()
+    ops.gemm(a, w, want, mode=ops.GEMM_F32, bias=bias, res=want)
+    ws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda")
+    outs = []
+    for _ in range(2):
+        x = res.clone()
+        ops.gemm_streamk(a, w, x, ws, blocks, bias=bias, res=x)
+        outs.append(x)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_gemm_streamk_plan_covers_the_per_rank_shapes(ops):
+    name, cus = ops.device_info()
+    b_o, _ = ops.gemm_streamk_plan(1660, 3584, 3584)
+    b_d, ws_d = ops.gemm_streamk_plan(1660, 3584, 18944)
+    assert 0 < b_o <= cus and 0 < b_d <= cus and ws_d == b_d * 2 * 65536 * 4
+    assert ops.gemm_streamk_plan(12860, 3584, 18944)[0] == 0           # enough tiles for every CU: the plain GEMM
+    assert ops.gemm_streamk_plan(1660, 3584, 1152)[0] == 0             # K too short to cut

@@ -37,4 +37,14 @@ for M in (1660, 3260, 6460):
                 for _ in range(10): ops.gemm_splitk(a, w, out, ws, sp, res=out)
                 e1.record(); torch.cuda.synchronize()
                 sk = f" | split-K x{sp} (incl. reduce) {2.0 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9:6.0f}"
+        if mode == ops.GEMM_F32:
+            nbk, wsb = ops.gemm_streamk_plan(M, N, K)
+            if nbk > 0:
+                ws = torch.empty(wsb // 4, dtype=torch.float32, device="cuda")
+                for _ in range(3): ops.gemm_streamk(a, w, out, ws, nbk, res=out)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): ops.gemm_streamk(a, w, out, ws, nbk, res=out)
+                e1.record(); torch.cuda.synchronize()
+                sk += f" | stream-K {nbk} blocks (incl. reduce) {2.0 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9:6.0f}"
         print(f"M={M:5d} {name:7s} TF/s: auto {res[0]} | tile128 {res[1]} | cfg6 256x256 {res[2]} | cfg2 256x128 {res[3]} | cfg9 256x384 {res[4]} | cfg10 384x256 {res[5]}{sk}", flush=True)

@@ -362,6 +362,80 @@ extern "C" int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, 
     return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
 }
 
+// ---- stream-K for fp32-residual GEMMs with fewer output tiles than CUs (round 3; kernel side: gemm_mi16.hip, SK) -----------------------------
+namespace vitg {
+// out[m, n] = sum over the segments of tile (m / 256, n / 256), in block order, + bias[n] + res[m, n].  Tile t owns K-tile units [t KT, (t+1) KT) of the
+// tile-major unit line; block b holds units [b U, (b+1) U): its slot 0 is the tile it starts in, slot 1 the next one.
+__global__ __launch_bounds__(256) void streamk_reduce_kernel(const float* __restrict__ ws, int tiles_m, int KT, int U, const float* __restrict__ bias,
+                                                             const float* __restrict__ res, int ldr, float* __restrict__ out, int ldo, int M, int N) {
+    const int t = blockIdx.x >> 2, rq = blockIdx.x & 3;            // 4 blocks per tile, 64 rows each; a wave per row, 4 columns per lane
+    const int tm = t % tiles_m, tn = t / tiles_m;
+    const long u_lo = (long)t * KT, u_hi = u_lo + KT - 1;
+    const int b0 = (int)(u_lo / U), b1 = (int)(u_hi / U);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = tn * 256 + lane * 4;
+    for (int r = rq * 64 + wv; r < rq * 64 + 64; r += 4) {
+        const int m = tm * 256 + r;
+        if (m >= M || n >= N) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int b = b0; b <= b1; ++b) {
+            const int slot = ((long)b * U / KT == t) ? 0 : 1;
+            v += *(const f32x4*)(ws + ((size_t)b * 2 + slot) * 65536 + (size_t)r * 256 + lane * 4);
+        }
+        if (bias) v += *(const f32x4*)(bias + n);
+        if (res) v += *(const f32x4*)(res + (size_t)m * ldr + n);
+        *(f32x4*)(out + (size_t)m * ldo + n) = v;
+    }
+}
+}  // namespace vitg
+
+// U = K-tile units per block, blocks = ceil(total / U); 0 blocks = stream-K does not apply to this shape
+static void streamk_partition(int M, int N, int K, int* U, int* blocks) {
+    *U = 0; *blocks = 0;
+    if (M < 256 || N < 256 || K <= 0 || K % 64 || N % 4) return;
+    const int cus = device_cu_count(current_device());
+    const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    const int KT = K / 64;
+    // fewer tiles than three quarters of the CUs, and enough K per tile that a block's run (<= one tile's worth: at most two segments) is long
+    if (tiles * 4 > (long)cus * 3 || KT < 32) return;
+    const long total = tiles * KT;
+    int u = (int)((total + cus - 1) / cus);
+    if (u < 16) u = 16;
+    if (u > KT) return;
+    *U = u;
+    *blocks = (int)((total + u - 1) / u);
+}
+
+extern "C" int vitg_gemm_streamk_plan(int M, int N, int K, int* blocks, long* workspace_bytes) {
+    if (!blocks || !workspace_bytes) return VITG_ERR_ARG;
+    int U = 0;
+    streamk_partition(M, N, K, &U, blocks);
+    *workspace_bytes = (long)*blocks * 2 * 65536 * 4;
+    return 0;
+}
+
+extern "C" int vitg_gemm_streamk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
+                                 int ldo, const float* res, int ldr, float* workspace, int blocks, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (blocks < 1 || !workspace) return VITG_ERR_ARG;
+    if (N % 4 || ldo % 4 || (res && ldr % 4) || (lda % 8) || (ldw % 8)) return VITG_ERR_ALIGN;
+    if (K <= 0 || K % 64 != 0) return VITG_ERR_SHAPE;
+    if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
+    int U = 0, want = 0;
+    streamk_partition(M, N, K, &U, &want);
+    if (want != blocks) return VITG_ERR_ARG;                       // the partition is the plan's: blocks and workspace size come from it
+    GemmArgs g = {};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.act = VITG_ACT_NONE; g.out = workspace; g.ldo = 256; g.split_k = 1;
+    g.sk_kt = K / 64; g.sk_units = U;
+    const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (launch_gemm_mi16_streamk(g, dtype, blocks, s) != 0) return VITG_ERR_LAUNCH;
+    hipLaunchKernelGGL(streamk_reduce_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, s, workspace, ceil_div(M, 256), g.sk_kt, U, bias, res, ldr,
+                       out, ldo, M, N);
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}
+
 #if VITG_PROFILING_BUILD
 // ---- LayerNorm / RMSNorm folded into the GEMMs on either side of it (round 2; measured slower than the stand-alone norm pass, kept
 //      in the profiling library: include/videoitg_hip_profiling.h, profiles/r02_fused_norm.md) ------------------------------------------

@@ -38,6 +38,7 @@ struct GemmArgs {
     const float* nrm_stats;   // consumer: [M][2] (mean, rstd)
     const float* nrm_colsum;  // consumer: s[n] = sum_k gamma[k] W[n,k] (LayerNorm) or null (RMSNorm: no mean term)
     unsigned* xcd_sync;       // profiling build, gemm_flags bit26: 8 per-XCD arrival counters (128 B apart), zeroed before the launch
+    int sk_units, sk_kt;      // stream-K (vitg_gemm_streamk, gemm_mi16.hip): K-tile units per block / K-tiles per output tile; 0 = off
     int split_k;              // MODE_F32 only: gridDim.y = split_k blocks share one output tile, block y accumulates its K range and
     long split_stride;        // writes the raw fp32 partial tile to out + y * split_stride floats (vitg_gemm_splitk reduces them)
 };
@@ -270,6 +271,7 @@ int launch_gemm256(const GemmArgs& g, int dtype, int mode, hipStream_t s);   // 
 bool gemm256_applicable(const GemmArgs& g, int mode);
 int gemm256_pick_cfg(const GemmArgs& g, int mode);                                // the tile shape auto mode takes for this shape (2 / 6 / 9 / 10)
 int gemm256_norm_cols(const GemmArgs& g);                                       // gemm256.hip
+int launch_gemm_mi16_streamk(const GemmArgs& g, int dtype, int blocks, hipStream_t s);   // gemm_mi16.hip: raw fp32 partial tiles of a stream-K partition
 int launch_gemm_mi16(const GemmArgs& g, int dtype, int mode, int cfg, hipStream_t s);   // gemm_mi16.hip: the same tiles on v_mfma_f32_16x16x32
 int launch_gemm_w4(const GemmArgs& g, int dtype, int mode, hipStream_t s);      // gemm_w4.hip
 bool gemm_w4_applicable(const GemmArgs& g, int mode);

@@ -30,8 +30,15 @@ constexpr int G16_THREADS = 512;
 constexpr int MODE_RES16 = 3;      // internal: MODE_STORE16 with a residual preloaded into the accumulators (vitg_gemm_res16).  Its own instantiation:
                                    // compiled into the plain 16-bit-output kernels the preload cost the wide tiles 15-20 spilled registers
 
-template <typename T, int MODE, int BM, int BN>
+// SK (stream-K, vitg_gemm_streamk): for fp32-residual GEMMs with FEWER output tiles than CUs and a long K (o / down projection of one
+// context-parallel rank: 98 tiles of 256x256 on 256 CUs).  The tiles' K-tiles are laid end to end (tile-major) and cut into equal runs of
+// sk_units, one run per block: a block works on the tail of one tile and the head of the next (at most two segments, sk_units <= K-tiles
+// per tile) and stores each segment's raw fp32 partial tile into its own workspace slot [block][segment][256][256]; a row-parallel kernel
+// then adds a tile's segments in block order, the bias and the residual (fixed order, no atomics: run-to-run bit-identical).  Every CU gets
+// the same number of K-tiles - split-K x2 left 60 of 256 CUs idle on these shapes.
+template <typename T, int MODE, int BM, int BN, bool SK = false>
 __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
+    static_assert(!SK || MODE == MODE_F32, "stream-K partials are fp32 tiles");
     typedef typename T16<T>::vec8 vec8;
     GemmArgs g = g_;
     constexpr bool RES16 = MODE == MODE_RES16;
@@ -61,7 +68,17 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     static_assert(MT % MC == 0, "row chunks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg_ = g.tiles_m * g.tiles_n;
-    for (int vb = blockIdx.x; vb < nwg_; vb += gridDim.x) {
+    int sk_t0 = 0, sk_k0 = 0, sk_c0 = 0, sk_c1 = 0;      // stream-K: first tile, first K-tile in it, K-tiles in it, K-tiles in the next tile
+    if constexpr (SK) {
+        const long total = (long)nwg_ * g.sk_kt;
+        const long u0 = (long)blockIdx.x * g.sk_units, u1 = min(u0 + (long)g.sk_units, total);
+        if (u0 >= total) return;
+        sk_t0 = (int)(u0 / g.sk_kt); sk_k0 = (int)(u0 % g.sk_kt);
+        sk_c0 = (int)min((long)(g.sk_kt - sk_k0), u1 - u0);
+        sk_c1 = (int)(u1 - u0) - sk_c0;
+    }
+    const int item_end = SK ? (sk_c1 > 0 ? 2 : 1) : nwg_, item_step = SK ? 1 : (int)gridDim.x;
+    for (int vb = SK ? 0 : (int)blockIdx.x; vb < item_end; vb += item_step) {
     // per-lane quantities re-derived from an opaque copy of the thread id in every pass (hoisted they would stay live through the loop)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -69,14 +86,16 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
     int tm, tn;
-    block_to_tile(vb, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    if constexpr (SK) { const int t = sk_t0 + vb; tm = t % g.tiles_m; tn = t / g.tiles_m; }
+    else block_to_tile(vb, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA assignment (as gemm256.hip): one instruction = 8 rows x 128 B; lane -> (row = lane / 8, LDS chunk slot = lane % 8);
     // source = wave-uniform tile base + per-lane 32-bit byte offset (saddr form), source chunk = slot ^ ((row >> 1) & 7)
     const int drow = lane >> 3, dslot = lane & 7;
-    const char* const a_base = (const char*)g.A + (size_t)m0 * g.lda * 2;
-    const char* const w_base = (const char*)g.W + (size_t)n0 * g.ldw * 2;
+    const int kfirst = SK ? (vb == 0 ? sk_k0 : 0) : 0;   // first K-tile of this work item
+    const char* const a_base = (const char*)g.A + (size_t)m0 * g.lda * 2 + (size_t)kfirst * 128;
+    const char* const w_base = (const char*)g.W + (size_t)n0 * g.ldw * 2 + (size_t)kfirst * 128;
     unsigned a_cur[A_INSTR], w_cur[W_INSTR];
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         }
     }
 
-    const int nk = g.K / 64;
+    const int nk = SK ? (vb == 0 ? sk_c0 : sk_c1) : g.K / 64;
 #pragma unroll
     for (int j = 0; j < LPT; ++j) issue_one(0, j);
 
@@ -234,19 +253,22 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                     *(f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4)) = v;
                 }
             // the same wave reads back what it wrote: LDS operations of one wave complete in order
-            char* const ob = (char*)((float*)g.out + (size_t)(mw + mp * 32) * g.ldo + nw);
+            // stream-K: the segment's raw partial goes to its workspace slot as a whole BM x BN tile (rows past M hold finite filler nobody reads)
+            const int om = SK ? wr * (MT * 16) : mw, on = SK ? wc * (NT * 16) : nw, oM = SK ? BM : g.M, oN = SK ? BN : g.N, oldo = SK ? BN : g.ldo;
+            float* const obase = SK ? (float*)g.out + ((size_t)blockIdx.x * 2 + vb) * (size_t)(BM * BN) : (float*)g.out;
+            char* const ob = (char*)(obase + (size_t)(om + mp * 32) * oldo + on);
 #pragma unroll
             for (int i = 0; i < 32 * CH / 64; ++i) {
                 const int idx = i * 64 + lane;
                 const int row = idx / CH, c = idx % CH;
                 f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4));
-                const int m = mw + mp * 32 + row, n = nw + c * 4;
-                if (m < g.M && n < g.N) {
-                    if (g.res && !acc_from_res) {
+                const int m = om + mp * 32 + row, n = on + c * 4;
+                if (m < oM && n < oN) {
+                    if (!SK && g.res && !acc_from_res) {
                         const int rm = g.res_mod > 0 ? m % g.res_mod : m;
                         v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
                     }
-                    *(f32x4*)(ob + (unsigned)(row * g.ldo + c * 4) * 4u) = v;
+                    *(f32x4*)(ob + (unsigned)(row * oldo + c * 4) * 4u) = v;
                 }
             }
         }
@@ -304,7 +326,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
             }
         }
     }
-    if (vb + (int)gridDim.x < nwg_) {                    // another tile follows: every wave is done with its staging window
+    if (vb + item_step < item_end) {                     // another tile follows: every wave is done with its staging window
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -337,6 +359,26 @@ static int launch16(GemmArgs g, hipStream_t s) {
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
     hipLaunchKernelGGL((gemm16_kernel<T, MODE, BM, BN>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G16_THREADS), lds, s, g);
     return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch16_sk(GemmArgs g, int blocks, hipStream_t s) {
+    constexpr int lds = 2 * (256 + 256) * 128;
+    static std::atomic<unsigned> done_mask{0};
+    const int cur_dev = current_device();
+    if (!device_done(done_mask, cur_dev)) {
+        (void)hipFuncSetAttribute((const void*)gemm16_kernel<T, MODE_F32, 256, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        mark_device_done(done_mask, cur_dev);
+    }
+    g.tiles_m = ceil_div(g.M, 256);
+    g.tiles_n = ceil_div(g.N, 256);
+    g.group_m = 4;
+    hipLaunchKernelGGL((gemm16_kernel<T, MODE_F32, 256, 256, true>), dim3(blocks), dim3(G16_THREADS), lds, s, g);
+    return (int)hipGetLastError();
+}
+
+int launch_gemm_mi16_streamk(const GemmArgs& g, int dtype, int blocks, hipStream_t s) {
+    return dtype == DT_BF16 ? launch16_sk<bf16_t>(g, blocks, s) : launch16_sk<f16_t>(g, blocks, s);
 }
 
 template <typename T, int MODE>

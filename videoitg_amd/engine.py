@@ -294,6 +294,8 @@ class SelectorEngine:
         # VITG_CP_OVERLAP=0 (A/B): fused QKV projection and a blocking exchange, as in round 2.  The split costs one rank ~1 ms of compute per step
         # (two sub-round launches instead of one, tools/cp_rank_time.py) and buys the exchange - est. 0.1-0.15 ms x 28 layers - off the critical path
         self.cp_overlap = os.environ.get("VITG_CP_OVERLAP", "1") not in ("", "0")
+        # fp32-residual GEMMs with fewer output tiles than CUs (one context-parallel rank): stream-K partition instead of split-K x2 (VITG_STREAMK=0: A/B)
+        self.stream_k = os.environ.get("VITG_STREAMK", "1") not in ("", "0")
 
     # workspace: ONE buffer per name, grown to the largest row count seen and handed out as a [:rows] view, so a run over
     # documents with varying prompt lengths / frame counts holds max-size buffers instead of one set per distinct shape.
@@ -385,10 +387,15 @@ class SelectorEngine:
             M, N, Kd = a.shape[0], w.shape[0], w.shape[1]
             plan = self._splitk.get((M, N, Kd))
             if plan is None:
-                plan = self._splitk[(M, N, Kd)] = K.gemm_splitk_plan(M, N, Kd)
-            if plan[0] > 1:
-                ws = self._buf("splitk_ws", (plan[0] * M * N,), torch.float32)
-                return K.gemm_splitk(a, w, out, ws, plan[0], bias=kw.get("bias"), res=kw.get("res"))
+                sk = K.gemm_streamk_plan(M, N, Kd) if self.stream_k else (0, 0)
+                plan = self._splitk[(M, N, Kd)] = ("stream", sk[0], sk[1]) if sk[0] > 0 else ("split",) + tuple(K.gemm_splitk_plan(M, N, Kd))
+            if plan[0] == "stream":
+                # stream-K (round 3): every CU gets the same number of K-tiles; the partials of a tile are added in block order (bit-reproducible)
+                ws = self._buf("streamk_ws", (plan[2] // 4,), torch.float32)
+                return K.gemm_streamk(a, w, out, ws, plan[1], bias=kw.get("bias"), res=kw.get("res"))
+            if plan[1] > 1:
+                ws = self._buf("splitk_ws", (plan[1] * M * N,), torch.float32)
+                return K.gemm_splitk(a, w, out, ws, plan[1], bias=kw.get("bias"), res=kw.get("res"))
         return K.gemm(a, w, out, **kw)
 
     # ---- which tokens does the bilinear pool read? (mlp_proj.py:57-68 semantics: align_corners=False) ----------------

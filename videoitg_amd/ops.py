@@ -164,6 +164,27 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, workspace: 
     return out
 
 
+def gemm_streamk_plan(M: int, N: int, K: int):
+    """-> (blocks, workspace_bytes): blocks == 0 means stream-K does not apply to the shape (vitg_gemm_streamk_plan)"""
+    nb_, ws_ = C.c_int(0), C.c_long(0)
+    _lib.call("vitg_gemm_streamk_plan", M, N, K, C.byref(nb_), C.byref(ws_))
+    return nb_.value, ws_.value
+
+
+def gemm_streamk(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor, blocks: int, *,
+                 bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out(fp32) = a @ w.T + bias + res through a stream-K partition into `blocks` equal K-runs (vitg_gemm_streamk), fixed summation order"""
+    _req(a)
+    _req(w, a.dtype)
+    _req(out, torch.float32)
+    _req(workspace, torch.float32)
+    M, K, N = a.shape[0], w.shape[1], w.shape[0]
+    assert a.shape[1] == K and workspace.numel() >= blocks * 2 * 65536
+    _lib.call("vitg_gemm_streamk", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, N, K, dt_code(a.dtype), _ptr(bias), _ptr(out),
+              out.stride(0), _ptr(res), 0 if res is None else res.stride(0), _ptr(workspace), blocks, _stream())
+    return out
+
+
 def pad128(n: int) -> int:
     return (n + 127) // 128 * 128
 

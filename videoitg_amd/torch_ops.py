@@ -62,6 +62,10 @@ _def("gemm_splitk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int 
      lambda a, w, out, workspace, splits, bias=None, res=None: (_raw.gemm_splitk(a, w, out, workspace, splits, bias=bias, res=res), None)[1],
      lambda *a, **k: None)
 
+_def("gemm_streamk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int blocks, Tensor? bias=None, Tensor? res=None) -> ()",
+     lambda a, w, out, workspace, blocks, bias=None, res=None: (_raw.gemm_streamk(a, w, out, workspace, blocks, bias=bias, res=res), None)[1],
+     lambda *a, **k: None)
+
 # ---- norm folded into the GEMMs around it (profiling library only: measured slower than the stand-alone norm kernels)
 if _raw._lib.PROFILING:
   _def("gemm_norm_producer(Tensor a, Tensor w, Tensor(a!) out, Tensor res, Tensor next_gamma, Tensor(b!) xh, Tensor(c!) partials, "
@@ -188,6 +192,13 @@ class _Namespace:
         _ops.gemm_splitk(a, w, out, workspace, splits, bias, res)
         return out
 
+    gemm_streamk_plan = staticmethod(_raw.gemm_streamk_plan)
+
+    @staticmethod
+    def gemm_streamk(a, w, out, workspace, blocks, *, bias=None, res=None):
+        _ops.gemm_streamk(a, w, out, workspace, blocks, bias, res)
+        return out
+
     @staticmethod
     def layernorm(x, w, b, out, d, eps):
         _ops.layernorm(x, w, b, out, d, eps)
@@ -283,4 +294,4 @@ class _Namespace:
 K = _Namespace()
 OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
                        "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx",
-                       "gemm_res16", "layernorm16", "bilinear_pool16"]
+                       "gemm_res16", "layernorm16", "bilinear_pool16", "gemm_streamk"]
