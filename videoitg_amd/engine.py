@@ -294,8 +294,9 @@ class SelectorEngine:
         # VITG_CP_OVERLAP=0 (A/B): fused QKV projection and a blocking exchange, as in round 2.  The split costs one rank ~1 ms of compute per step
         # (two sub-round launches instead of one, tools/cp_rank_time.py) and buys the exchange - est. 0.1-0.15 ms x 28 layers - off the critical path
         self.cp_overlap = os.environ.get("VITG_CP_OVERLAP", "1") not in ("", "0")
-        # fp32-residual GEMMs with fewer output tiles than CUs (one context-parallel rank): stream-K partition instead of split-K x2 (VITG_STREAMK=0: A/B)
-        self.stream_k = os.environ.get("VITG_STREAMK", "1") not in ("", "0")
+        # fp32-residual GEMMs with fewer output tiles than CUs (one context-parallel rank): VITG_STREAMK=1 runs them as a stream-K partition instead
+        # of split-K x2.  Opt-in: measured SLOWER on the per-rank o / down shapes (447 / 694 against 682 / 911 TF/s, profiles/r03_context_parallel.md)
+        self.stream_k = os.environ.get("VITG_STREAMK", "0") not in ("", "0")
 
     # workspace: ONE buffer per name, grown to the largest row count seen and handed out as a [:rows] view, so a run over
     # documents with varying prompt lengths / frame counts holds max-size buffers instead of one set per distinct shape.
