@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import fullsize  # noqa: E402
+from videoitg_amd import synth  # noqa: E402
 from videoitg_amd.config import ITGConfig  # noqa: E402
 
 # name -> (frames, resolution, prompt tokens).  c2 = BASELINE.json configs[1] (the bench workload), b0 = the reference-native
@@ -40,21 +41,32 @@ CASES = {
     # robustness: other weights (seed 1), other pixels, a 23-token prompt - the dtype decision must not hinge on one draw
     "depth16_224_s1": (16, 224, 23, 1, 777),
     "depth24_280_s2": (24, 280, 41, 2, 4242),
+    # planted per-frame signal (videoitg_amd.synth.planted_inputs: 32 bright frames among dark ones): a case whose Top-32 set is
+    # DECIDABLE for the lower-precision tiers (SURVEY.md section 7 hard part 2 iii).  c2p = the bench workload's size
+    "c2p_512x448": (512, 448, 60, 0, 1234, 32),
+    "depth16p_224": (16, 224, 60, 0, 1234, 4),
 }
+PLANT_SEED = 99
 
 
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     for name in sys.argv[1:]:
         T, R, L, wseed, pseed = (CASES[name] + (0, 1234))[:5]
+        plant_k = CASES[name][5] if len(CASES[name]) > 5 else 0
         cfg = ITGConfig()
-        ids, pix = fullsize.workload_inputs(cfg, T, R, L, pseed)
+        planted = None
+        if plant_k:
+            ids, pix, planted = synth.planted_inputs(cfg, T, R, L, pseed, plant_k, PLANT_SEED)
+        else:
+            ids, pix = fullsize.workload_inputs(cfg, T, R, L, pseed)
         t0 = time.time()
         with torch.inference_mode():
             out = fullsize.streaming_forward(cfg, ids, pix, seed=wseed, log=lambda m: print(f"[{name} +{time.time() - t0:.0f}s] {m}", flush=True))
-        rk = fullsize.ranking_summary(out["logits"], 32)
+        rk = fullsize.ranking_summary(out["logits"], plant_k or 32)
         rec = dict(case=name, frames=T, resolution=R, prompt_len=L, weight_seed=wseed, pixel_seed=pseed, prompt_seed=4321,
-                   llm_tokens=out["N"], logits=[float(x) for x in out["logits"].tolist()], **rk, checks=out["checks"],
+                   llm_tokens=out["N"], **({"plant": dict(k=plant_k, seed=PLANT_SEED, frames=planted, what="planted frames pixels*0.5+0.5, others pixels*0.5-0.5")}
+                                           if plant_k else {}), logits=[float(x) for x in out["logits"].tolist()], **rk, checks=out["checks"],
                    oracle=dict(kind="oracle/videoitg_oracle.py streamed by oracle/fullsize.py, torch CPU fp32",
                                torch=torch.__version__, threads=torch.get_num_threads(), seconds=out["seconds"]))
         path = os.path.join(HERE, f"full_{name}.json")

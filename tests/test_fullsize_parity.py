@@ -18,7 +18,9 @@ import torch
 
 SCORE_TOL = 1e-3
 TOL = {torch.float16: SCORE_TOL, torch.bfloat16: 2.5e-3}
-CASES = ["depth16_224", "depth16_224_s1", "depth24_280_s2", "c1_64x384", "b0_512x384", "c2_512x448"]
+CASES = ["depth16_224", "depth16_224_s1", "depth24_280_s2", "c1_64x384", "b0_512x384", "c2_512x448",
+         # planted per-frame signal (synth.planted_inputs): the oracle's Top-k is the planted set behind a wide gap
+         "depth16p_224", "c2p_512x448"]
 
 
 def load_case(golden_dir, name):
@@ -47,6 +49,12 @@ def test_fixtures_are_wellformed(golden_dir):
         if r["gap_k_k1"] is not None:
             assert abs((s[order[r["k"] - 1]] - s[order[r["k"]]]).item() - r["gap_k_k1"]) < 1e-7
         assert r["oracle"]["seconds"]["total"] > 0
+        if r.get("plant"):
+            # the planted frames ARE the oracle's Top-k, and the gap to the first unplanted frame is wide in logits (the point of the case)
+            from videoitg_amd import synth
+            assert r["plant"]["frames"] == synth.planted_frames(r["frames"], r["plant"]["k"], r["plant"]["seed"])
+            assert r["topk"] == sorted(r["plant"]["frames"]) and r["k"] == r["plant"]["k"]
+            assert (lg[order[r["k"] - 1]] - lg[order[r["k"]]]).item() > 1.0
     assert seen >= 1
 
 
@@ -58,7 +66,7 @@ def gpu_logits(rec, dtype):
     cfg = ITGConfig()
     dev = torch.device("cuda:0")
     eng = SelectorEngine(packed_random_weights(cfg, dtype, dev, seed=rec["weight_seed"]))
-    ids, pix = synth.workload_inputs(cfg, rec["frames"], rec["resolution"], rec["prompt_len"], rec["pixel_seed"])
+    ids, pix = synth.fixture_inputs(cfg, rec)
     got = eng.forward(ids, None, [pix.to(dtype).to(dev)])[0].view(-1)
     torch.cuda.synchronize()
     out = got.float().cpu()

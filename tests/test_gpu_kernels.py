@@ -22,24 +22,29 @@ def ops():
 
 
 @pytest.fixture(params=["auto", "tile128", "cfg2_256x128x32", "cfg6_phased", "cfg9_256x384", "cfg10_384x256",
-                        "cfg6_mi16", "cfg9_256x384_mi16", "cfg10_384x256_mi16", "cfg6_mi32", "cfg9_256x384_mi32", "cfg10_384x256_mi32"])
+                        "cfg6_mi16", "cfg9_256x384_mi16", "cfg10_384x256_mi16", "cfg6_mi32", "cfg9_256x384_mi32", "cfg10_384x256_mi32",
+                        "cfg10_384x256_mi16_wm4", "cfg10_384x256_mi16_wm2"])
 def gemm_cfg(request, ops):
     """Every SHIPPED GEMM kernel configuration is forced in turn (vitg_set_option), so the 256-tile kernels are covered at test
     sizes too (auto mode would pick the 128 tile for them); tile128 doubles as the cross-check set.  The research
     configurations of round 1 live in the profiling library and are not part of the product test matrix."""
     name = request.param
     # (the three wide tile shapes exist on both MFMA shapes: gemm_mi 16 = v_mfma_f32_16x16x32, gemm_mi16.hip; 32 = v_mfma_f32_32x32x16,
-    # gemm256.hip; 0 = the default)
+    # gemm256.hip; 0 = the default; wm4 / wm2 = the 384x256 tile's wave grid 4 x 2 / 2 x 4 forced for every epilogue mode)
+    wm4 = {"cfg10_384x256_mi16_wm4": 15, "cfg10_384x256_mi16_wm2": -1}.get(name, 0)
+    name_ = name.replace("_wm4", "").replace("_wm2", "")
     tile, cfg, mi = {"auto": (0, 0, 0), "tile128": (128, 0, 0), "cfg2_256x128x32": (256, 2, 0), "cfg6_phased": (256, 6, 0), "cfg9_256x384": (256, 9, 0),
                      "cfg10_384x256": (256, 10, 0), "cfg6_mi16": (256, 6, 16), "cfg9_256x384_mi16": (256, 9, 16), "cfg10_384x256_mi16": (256, 10, 16),
-                     "cfg6_mi32": (256, 6, 32), "cfg9_256x384_mi32": (256, 9, 32), "cfg10_384x256_mi32": (256, 10, 32)}[name]
+                     "cfg6_mi32": (256, 6, 32), "cfg9_256x384_mi32": (256, 9, 32), "cfg10_384x256_mi32": (256, 10, 32)}[name_]
     ops.set_option("gemm_tile", tile)
     ops.set_option("gemm_cfg", cfg)
     ops.set_option("gemm_mi", mi)
+    ops.set_option("gemm_wm4", wm4)
     yield name
     ops.set_option("gemm_tile", 0)
     ops.set_option("gemm_cfg", 0)
     ops.set_option("gemm_mi", 0)
+    ops.set_option("gemm_wm4", 0)
 
 
 @pytest.fixture(params=[(0, 0, 0, 0, 0), (4, 0, 2, 2, 2), (8, 0, 2, 2, 2), (4, 1, 2, 2, 2), (4, 0, 1, 2, 2), (8, 0, 1, 2, 2), (4, 0, 0, 1, 2), (8, 0, 0, 1, 2),

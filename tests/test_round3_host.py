@@ -56,3 +56,27 @@ def test_graph_cache_serves_only_what_a_capture_can(monkeypatch):
     assert gc.serves(torch.tensor([-200, 5, 6, 7]), pix)
     assert not gc.serves(torch.tensor([5, 6, 7]), pix)
     assert not gc.serves(torch.tensor([-200, 5, -200, 7]), pix)
+
+
+def test_planted_inputs_are_a_brightness_step_on_the_seeded_frames():
+    """synth.planted_inputs (the decidable Top-k case for the lower-precision tiers): k seeded frames bright, the rest dark, same prompt and
+    same base pixels as workload_inputs, values exactly representable in bf16 and fp16; fixture_inputs rebuilds both kinds of fixture"""
+    import torch
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig
+    cfg = ITGConfig()
+    ids0, pix0 = synth.workload_inputs(cfg, 12, 28, 7, 5)
+    ids, pix, planted = synth.planted_inputs(cfg, 12, 28, 7, 5, k=3, plant_seed=99)
+    assert torch.equal(ids, ids0) and planted == synth.planted_frames(12, 3, 99) and len(set(planted)) == 3 and planted == sorted(planted)
+    assert synth.planted_frames(12, 3, 99) != synth.planted_frames(12, 3, 100)
+    assert torch.equal(pix, pix.to(torch.bfloat16).float()) and torch.equal(pix, pix.half().float())
+    for t in range(12):
+        want = synth.round_16(pix0[t] * 0.5 + (0.5 if t in planted else -0.5))
+        assert torch.equal(pix[t], want)
+    assert pix[planted].mean() > 0.3 and pix[[t for t in range(12) if t not in planted]].mean() < -0.3
+    rec = dict(frames=12, resolution=28, prompt_len=7, pixel_seed=5, plant=dict(k=3, seed=99, frames=planted))
+    a, b = synth.fixture_inputs(cfg, rec)
+    assert torch.equal(a, ids) and torch.equal(b, pix)
+    rec.pop("plant")
+    a, b = synth.fixture_inputs(cfg, rec)
+    assert torch.equal(b, pix0)

@@ -13,7 +13,7 @@ from videoitg_amd.synth_device import packed_random_weights
 case = sys.argv[1] if len(sys.argv) > 1 else "c2_512x448"
 rec = json.load(open(os.path.join(ROOT, "tests", "golden", f"full_{case}.json")))
 cfg = ITGConfig(); dev = torch.device("cuda:0")
-ids, pix = synth.workload_inputs(cfg, rec["frames"], rec["resolution"], rec["prompt_len"], rec["pixel_seed"])
+ids, pix = synth.fixture_inputs(cfg, rec)          # (planted-signal fixtures, e.g. c2p_512x448, rebuild their own pixels)
 want = torch.tensor(rec["logits"]); pix = pix.half().to(dev)
 POLICIES = [("16-bit (fp16, tower stream fp16)", False),
             ("llm.gu+down", "llm.gu,llm.down"), ("llm (all four)", "llm"), ("llm.qkv+o", "llm.qkv,llm.o"),
@@ -22,8 +22,10 @@ POLICIES = [("16-bit (fp16, tower stream fp16)", False),
             ("vit (all four)", "vit"), ("all eight", True)]
 ref16 = None
 print(f"case {case}: oracle rank-{rec['k']}/{rec['k'] + 1} score gap {rec['gap_k_k1']}")
-print("| policy (GEMMs on e4m3 weights + e4m3 activations) | ms/step | frames/s | max dscore vs oracle | Top-32 overlap vs oracle | max dscore vs 16-bit HIP | Top-32 overlap vs 16-bit HIP |")
-print("|---|---|---|---|---|---|---|")
+oord, osc = rec["order"], rec["scores"]
+print("oracle score gaps rank k / k+1: " + ", ".join(f"k={k}: {osc[oord[k - 1]] - osc[oord[k]]:.2e}" for k in (1, 2, 4, 8, 16, 32)))
+print("| policy (GEMMs on e4m3 weights + e4m3 activations) | ms/step | frames/s | max dscore vs oracle | Top-32 overlap vs oracle | Top-1/2/4/8/16 kept vs oracle | max dscore vs 16-bit HIP | Top-32 overlap vs 16-bit HIP |")
+print("|---|---|---|---|---|---|---|---|")
 for name, fp8 in POLICIES:
     eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=fp8))
     lg = eng.forward(ids, None, [pix])[0].view(-1).float().cpu()
@@ -32,9 +34,12 @@ for name, fp8 in POLICIES:
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 3 * 1e3
     sc = torch.sigmoid(lg)
     ds = (sc - torch.sigmoid(want)).abs().max().item()
-    top = set(torch.sort(sc, descending=True, stable=True).indices[:rec["k"]].tolist())
+    mine = torch.sort(sc, descending=True, stable=True).indices.tolist()
+    top = set(mine[:rec["k"]])
+    ladder = "/".join(str(len(set(mine[:k]) & set(oord[:k]))) for k in (1, 2, 4, 8, 16))
     if ref16 is None:
         ref16 = (sc.clone(), set(top))
     d16 = (sc - ref16[0]).abs().max().item()
-    print(f"| {name} | {ms:.1f} | {rec['frames'] / ms * 1e3:.0f} | {ds:.2e} | {len(top & set(rec['topk']))}/{rec['k']} | {d16:.2e} | {len(top & ref16[1])}/{rec['k']} |", flush=True)
+    dlg = (lg - want).abs().max().item()
+    print(f"| {name} | {ms:.1f} | {rec['frames'] / ms * 1e3:.0f} | {ds:.2e} (logit {dlg:.2e}) | {len(top & set(rec['topk']))}/{rec['k']} | {ladder} | {d16:.2e} | {len(top & ref16[1])}/{rec['k']} |", flush=True)
     eng.release_workspace(); del eng; torch.cuda.empty_cache()

@@ -23,7 +23,7 @@ namespace vitg {
 static int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; }
 Tuning& tuning() {
     static Tuning t = {env_int("VITG_GEMM_TILE"), env_int("VITG_GEMM_CFG"), env_int("VITG_GEMM_FLAGS"), env_int("VITG_GEMM_STAGGER"), env_int("VITG_GEMM_GROUP"), env_int("VITG_GEMM_PREF"), env_int("VITG_GEMM_MI"), env_int("VITG_GEMM_MI_MODES"),
-                       env_int("VITG_ATTN_WAVES"), env_int("VITG_ATTN_PIPE"), env_int("VITG_ATTN_DMA"), env_int("VITG_ATTN_AB"), env_int("VITG_ATTN_SP")};
+                       env_int("VITG_ATTN_WAVES"), env_int("VITG_ATTN_PIPE"), env_int("VITG_ATTN_DMA"), env_int("VITG_ATTN_AB"), env_int("VITG_ATTN_SP"), env_int("VITG_GEMM_WM4")};
     return t;
 }
 }  // namespace vitg
@@ -39,6 +39,7 @@ extern "C" int vitg_set_option(const char* key, int value) {
     else if (!strcmp(key, "gemm_mi")) t.gemm_mi = value;
     else if (!strcmp(key, "gemm_pref")) t.gemm_pref = value;
     else if (!strcmp(key, "gemm_mi_modes")) t.gemm_mi_modes = value;
+    else if (!strcmp(key, "gemm_wm4")) t.gemm_wm4 = value;
     else if (!strcmp(key, "attn_waves")) t.attn_waves = value;
     else if (!strcmp(key, "attn_pipe")) t.attn_pipe = value;
     else if (!strcmp(key, "attn_dma")) t.attn_dma = value;

@@ -27,6 +27,7 @@
 namespace vitg {
 
 constexpr int G16_THREADS = 512;
+constexpr int WM4_DEFAULT_MODES = 0;   // epilogue modes whose 384x256 tile runs the 4 x 2 wave grid by default (gemm_wm4 = 0); see launch16_m
 constexpr int MODE_RES16 = 3;      // internal: MODE_STORE16 with a residual preloaded into the accumulators (vitg_gemm_res16).  Its own instantiation:
                                    // compiled into the plain 16-bit-output kernels the preload cost the wide tiles 15-20 spilled registers
 
@@ -36,7 +37,11 @@ constexpr int MODE_RES16 = 3;      // internal: MODE_STORE16 with a residual pre
 // per tile) and stores each segment's raw fp32 partial tile into its own workspace slot [block][segment][256][256]; a row-parallel kernel
 // then adds a tile's segments in block order, the bias and the residual (fixed order, no atomics: run-to-run bit-identical).  Every CU gets
 // the same number of K-tiles - split-K x2 left 60 of 256 CUs idle on these shapes.
-template <typename T, int MODE, int BM, int BN, bool SK = false>
+// WM (wave rows of the 8-wave block, 2 or 4; wave columns WN = 8 / WM).  The 384x256 tile as 2 x 4 gives a wave 192 x 64 (fragment bytes per flop
+// (192 + 64) / (192 * 64) = 0.0208); as 4 x 2 it gives 96 x 128 (0.0182, the figure of the 256x384 tile's 128 x 96) - the wide tiles differ by
+// 4-5 % on shapes both fit, and that is their LDS read traffic (profiles/r03_gemm_mi16.md).  The phased schedule is unchanged: waves 4-7 run
+// one barrier behind waves 0-3 (wave w and w + 4 share a SIMD).
+template <typename T, int MODE, int BM, int BN, bool SK = false, int WM = 2>
 __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     static_assert(!SK || MODE == MODE_F32, "stream-K partials are fp32 tiles");
     typedef typename T16<T>::vec8 vec8;
@@ -54,12 +59,14 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
             g.out = (float*)g.out + (size_t)sp * g.split_stride;
         }
     }
-    constexpr int WM = 2, WN = 4;
+    constexpr int WN = 8 / WM;
+    static_assert(WM == 2 || WM == 4, "wave grid");
     constexpr int MT = BM / WM / 16;                     // 16-row activation tiles per wave (8 or 12)
     constexpr int NT = BN / WN / 16;                     // 16-wide weight tiles per wave (4 or 6)
     // activation tiles per interval: 4 (16 MFMAs at NT = 4), except the SwiGLU GEMM on the 192-row wave tile, which runs intervals of 6 (24 MFMAs,
     // 8 barriers per K-tile instead of 12): gate/up +4.2 % (1272 -> 1326 TF/s), step +0.3 %; the same on fc1 / o-proj: -1 % / +-0 (tools/r03/ab_mc6.sh)
-    constexpr int MC = (MODE == MODE_SWIGLU && MT == 12) ? 6 : 4;
+    // the 96-row wave tile (WM = 4 on 384 rows: MT = 6, NT = 8) runs intervals of 3 activation tiles x 8 weight tiles = 24 MFMAs, 8 barriers per K-tile
+    constexpr int MC = MT == 6 ? 3 : (MODE == MODE_SWIGLU && MT == 12) ? 6 : 4;
     constexpr int NC = MT / MC;                          // row chunks per k-step
     constexpr int NI = 2 * NC;                           // intervals pairs per K-tile (2 k-steps of 32)
     constexpr int ROWB = 128;                            // bytes per LDS row: 64 k x 2 B
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     for (int j = 0; j < LPT; ++j) issue_one(0, j);
 
     vec8 fw[NT], fa[MC];
-    const bool grpB = wr == 1;
+    const bool grpB = wave >= 4;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grpB) __builtin_amdgcn_s_barrier();
@@ -290,9 +297,10 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                 for (int nt = 0; nt < NTO; ++nt) {
                     f32x4 v;
                     if constexpr (EMODE == MODE_SWIGLU) {
-                        // weight rows are interleaved [32 gate | 32 up] (engine.pack_llm_layer): tiles 0-1 gate, 2-3 up of the wave's 64 features
+                        // weight rows are interleaved [32 gate | 32 up] (engine.pack_llm_layer): of every 64 features of the wave, tiles 0-1 gate, 2-3 up
+                        const int gt = (nt >> 1) * 4 + (nt & 1);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[nt][mp * 2 + h][e]) * acc[nt + NT / 2][mp * 2 + h][e];
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[gt][mp * 2 + h][e]) * acc[gt + 2][mp * 2 + h][e];
                     } else {
                         v = acc[nt][mp * 2 + h];
                         const int nb = nw + nt * 16 + fq * 4;      // (bias re-read per row pair from L1 instead of NT quads held over the epilogue)
@@ -334,14 +342,14 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     }   // tile loop
 }
 
-template <typename T, int MODE, int BM, int BN>
+template <typename T, int MODE, int BM, int BN, int WM = 2>
 static int launch16(GemmArgs g, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 128;
     static int done_dev[16] = {0};                       // per device: the attribute belongs to the device's copy of the kernel
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     if (cur_dev >= 16 || !done_dev[cur_dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm16_kernel<T, MODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm16_kernel<T, MODE, BM, BN, false, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (cur_dev < 16) done_dev[cur_dev] = 1;
     }
     g.tiles_m = ceil_div(g.M, BM);
@@ -357,7 +365,7 @@ static int launch16(GemmArgs g, hipStream_t s) {
     // one block per CU walking the tile list when there are at least two tiles per CU (gemm256.hip: "software relaunch")
     const bool loop = nwg >= 2 * cus && !(tuning().gemm_flags & 0x1000000);
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
-    hipLaunchKernelGGL((gemm16_kernel<T, MODE, BM, BN>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G16_THREADS), lds, s, g);
+    hipLaunchKernelGGL((gemm16_kernel<T, MODE, BM, BN, false, WM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G16_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
 
@@ -381,9 +389,19 @@ int launch_gemm_mi16_streamk(const GemmArgs& g, int dtype, int blocks, hipStream
     return dtype == DT_BF16 ? launch16_sk<bf16_t>(g, blocks, s) : launch16_sk<f16_t>(g, blocks, s);
 }
 
+static int wm4_modes() {
+    const int v = tuning().gemm_wm4;
+    return v < 0 ? 0 : v == 0 ? WM4_DEFAULT_MODES : v;
+}
+
 template <typename T, int MODE>
 static int launch16_m(const GemmArgs& g, int cfg, hipStream_t s) {
-    if (cfg == 10 && g.M >= 384) return launch16<T, MODE, 384, 256>(g, s);
+    if (cfg == 10 && g.M >= 384) {
+        // gemm_wm4 (A/B, bit per epilogue mode: 1 16-bit output, 2 fp32 residual, 4 SwiGLU, 8 16-bit residual): the 4 x 2 wave grid (96 x 128 wave tiles)
+        constexpr int bit = MODE == MODE_STORE16 ? 1 : MODE == MODE_F32 ? 2 : MODE == MODE_SWIGLU ? 4 : 8;
+        if (wm4_modes() & bit) return launch16<T, MODE, 384, 256, 4>(g, s);
+        return launch16<T, MODE, 384, 256>(g, s);
+    }
     if constexpr (MODE != MODE_SWIGLU) {
         if (cfg == 9 && g.N >= 384) return launch16<T, MODE, 256, 384>(g, s);
     }

@@ -193,6 +193,35 @@ def workload_inputs(cfg: ITGConfig, T: int, R: int, prompt_len: int, pix_seed: i
     return ids, synth_pixel_values(T, R, seed=pix_seed)
 
 
+def planted_frames(T: int, k: int = 32, plant_seed: int = 99) -> list:
+    """the k frame indices (sorted) that carry the planted signal: a seeded draw without replacement"""
+    g = _gen(plant_seed, f"planted{T}x{k}")
+    return sorted(torch.randperm(T, generator=g)[:min(k, T)].tolist())
+
+
+def planted_inputs(cfg: ITGConfig, T: int, R: int, prompt_len: int, pix_seed: int = 1234, k: int = 32, plant_seed: int = 99):
+    """workload_inputs with a planted per-frame signal (hard part 2 iii): the k planted frames are bright
+    (pixels * 0.5 + 0.5), all others dark (pixels * 0.5 - 0.5).  With random-init weights the scores of `workload_inputs` crowd together
+    (rank-32/33 gap 1.5e-3 at 512 frames), so whether a lower-precision tier keeps the Top-32 SET is undecidable there; a global brightness
+    step survives the 26-layer tower, the pooling and the 28-layer decoder as a logit offset of several units, which makes the oracle's
+    Top-k = the planted set with a wide gap (recorded in the fixture).  -> (input_ids, pixel_values fp32 16-bit-exact, planted indices)"""
+    ids, pix = workload_inputs(cfg, T, R, prompt_len, pix_seed)
+    planted = planted_frames(T, k, plant_seed)
+    mask = torch.zeros(T, dtype=torch.bool)
+    mask[planted] = True
+    off = torch.where(mask, 0.5, -0.5).view(T, 1, 1, 1)
+    return ids, round_16(pix * 0.5 + off), planted
+
+
+def fixture_inputs(cfg: ITGConfig, rec: dict):
+    """(input_ids, pixel_values) of a complete-pass oracle fixture record (tests/golden/full_*.json)"""
+    if rec.get("plant"):
+        pl = rec["plant"]
+        ids, pix, _ = planted_inputs(cfg, rec["frames"], rec["resolution"], rec["prompt_len"], rec["pixel_seed"], pl["k"], pl["seed"])
+        return ids, pix
+    return workload_inputs(cfg, rec["frames"], rec["resolution"], rec["prompt_len"], rec["pixel_seed"])
+
+
 def synth_video_frames(seed: int, T: int, H: int, W: int):
     """uint8 [T,H,W,3] decoded-frame stand-in (numpy): noise blended with a smooth gradient, plus a full-contrast band so
     that the bicubic resize both interpolates mid-range values and overshoots into the [0, 255] clip."""
