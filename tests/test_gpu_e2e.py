@@ -80,11 +80,13 @@ def test_tr_read_and_scalar_v_paths_agree(golden_dir, name):
     """same kernel, two ways of reading V^T out of LDS: identical arithmetic, so near-identical logits"""
     from videoitg_amd import ops
     ops.set_option("attn_sp", 2)              # per-tile kernel for both head sizes (the scalar-V cross-check lives there)
+    ops.set_option("attn_ab", 2)              # (and not the out-of-phase hd-72 kernel, whose row sums are formed on the matrix pipe from the ROUNDED P)
     try:
         _, a, _ = run_case(golden_dir, name, torch.float16, variant=0)
         _, b, _ = run_case(golden_dir, name, torch.float16, variant=1)
     finally:
         ops.set_option("attn_sp", 0)
+        ops.set_option("attn_ab", 0)
     for x, y in zip(a, b):
         assert (x - y).abs().max().item() < 1e-4
 

@@ -48,9 +48,9 @@ def gemm_cfg(request, ops):
 
 
 @pytest.fixture(params=[(0, 0, 0, 0, 0), (4, 0, 2, 2, 2), (8, 0, 2, 2, 2), (4, 1, 2, 2, 2), (4, 0, 1, 2, 2), (8, 0, 1, 2, 2), (4, 0, 0, 1, 2), (8, 0, 0, 1, 2),
-                        (0, 0, 0, 2, 1), (0, 0, 0, 2, 3), (0, 0, 0, 2, 4), (8, 0, 0, 3, 0)],
+                        (0, 0, 0, 2, 1), (0, 0, 0, 2, 3), (0, 0, 0, 2, 4), (8, 0, 0, 3, 0), (0, 0, 0, 2, 5)],
                 ids=["auto", "waves4_reg", "waves8_reg", "waves4_pipelined", "waves4_dma", "waves8_dma", "waves4_swpipe", "waves8_swpipe",
-                     "half_tile_out_of_phase", "half_tile_out_of_phase_16_waves", "half_tile_out_of_phase_pv32", "waves8_swpipe_hd128_pv16"])
+                     "half_tile_out_of_phase", "half_tile_out_of_phase_16_waves", "half_tile_out_of_phase_pv32", "waves8_swpipe_hd128_pv16", "half_tile_out_of_phase_valu_rowsum"])
 def attn_waves(request, ops):
     keys = ("attn_waves", "attn_pipe", "attn_dma", "attn_sp", "attn_ab")
     for key, val in zip(keys, request.param):

@@ -452,7 +452,7 @@ static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
 }
 
 int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv16, hipStream_t s);   // attention_sp.hip
-int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, bool pv32, hipStream_t s);                 // attention_ab.hip
+int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, hipStream_t s);                 // attention_ab.hip
 
 }  // namespace vitg
 
@@ -525,8 +525,8 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     // hd 72 default: the half-tile-out-of-phase kernel (attention_ab.hip, +5 % over the per-tile loop in same-call A/B) whenever
     // 256-query blocks fill the chip and no other variant is pinned; attn_ab = 1 / 2 forces it on / off
     const bool ab_auto = tuning().attn_ab == 0 && !nw_env && nw == 8 && !tuning().attn_pipe && !tuning().attn_dma && tuning().attn_sp != 1;
-    if (tr && head_dim == 72 && !a.ablate && (tuning().attn_ab == 1 || tuning().attn_ab == 3 || tuning().attn_ab == 4 || ab_auto) && tuning().attn_sp != 1) {
-        rc = attention_ab_dispatch(a, batch, heads, dtype, tuning().attn_ab == 3 ? 16 : 8, tuning().attn_ab == 4, s);
+    if (tr && head_dim == 72 && !a.ablate && (tuning().attn_ab == 1 || tuning().attn_ab == 3 || tuning().attn_ab == 4 || tuning().attn_ab == 5 || ab_auto) && tuning().attn_sp != 1) {
+        rc = attention_ab_dispatch(a, batch, heads, dtype, tuning().attn_ab == 3 ? 16 : 8, tuning().attn_ab >= 4 ? tuning().attn_ab : 0, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
     const bool pipe72 = tr && head_dim == 72 && nw == 4 && tuning().attn_pipe == 1;

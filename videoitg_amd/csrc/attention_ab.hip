@@ -31,8 +31,14 @@ constexpr float AB_LAZY_RESCALE_LOG2 = 8.0f;      // see attention_sp.hip: runni
 // order is free as long as both operands agree: lane group g of the V^T fragment reads keys 32 kb + 16 (g >> 1) + 4 (g & 1) + {0..3, 8..11}
 // with two ds_read_b64_tr_b16.  V rows sit 160 B apart in LDS (80 elements: 72 + one pad chunk): rows r .. r+7 then cover all 64 banks exactly once,
 // which the two lane groups of a half-wave (h0 | h1 rows) need to stay conflict-free (192-B rows cannot give that).
-template <typename T, int D, int NW, bool PV16>
+// Row sums on the matrix pipe (PV16): the pad chunk of every V row (columns 72..79 of the 80) holds [1, 0, ..., 0] - written once per block, the DMA
+// skips those lanes - so column 72 of O^T += V^T P accumulates l = sum_k P[k] in the MFMAs that run anyway (d-tile 4, lane group 2, register 0).
+// The softmax then has no row-sum adds and no l rescale of its own (the lazy rescale of the accumulators covers that column like any other); l is the
+// sum of the SAME 16-bit-rounded P the numerator uses.
+// LSUM = that form (the default with PV16); false = the softmax adds its row sums on the VALU (attn_ab = 5: A/B and cross-check).
+template <typename T, int D, int NW, bool PV16, bool LSUM = PV16>
 __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
+    static_assert(!LSUM || PV16, "the row-sum column rides the 16x16x32 PV form");
     adopt_device_key_count(a);
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
@@ -86,10 +92,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         return (unsigned)(row * rs + c * 8) * 2u;
     };
     unsigned dk_off[K_PW], dv_off[V_PW];
+    bool dv_pad[V_PW];                       // PV16: this lane's slot is the pad chunk of its V row (holds the constant [1, 0, ..]: never written by the DMA)
 #pragma unroll
     for (int i = 0; i < K_PW; ++i) dk_off[i] = dma_src(wave_u + NW * i, K_CPR, a.k_rs, true, ATT_BK - 1);
 #pragma unroll
-    for (int i = 0; i < V_PW; ++i) dv_off[i] = dma_src(wave_u + NW * i, V_CPR, a.v_rs, false, ATT_BK - 1);
+    for (int i = 0; i < V_PW; ++i) {
+        dv_off[i] = dma_src(wave_u + NW * i, V_CPR, a.v_rs, false, ATT_BK - 1);
+        dv_pad[i] = LSUM && ((wave_u + NW * i) * 64 + lane) % V_CPR >= C::CH;
+    }
     auto issue_k = [&](int kt, int buf) {
         char* kb = smem + buf * KT_BYTES;
         const char* Kt = (const char*)(K + (long)kt * ATT_BK * a.k_rs);
@@ -113,8 +123,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
             const int ii = wave_u + NW * i;
             if (ii < V_CPR) {
                 const unsigned off = tail ? dma_src(ii, V_CPR, a.v_rs, false, a.Sk - 1 - kt * ATT_BK) : dv_off[i];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + off),
-                                                 (__attribute__((address_space(3))) void*)(vb + ii * 1024), 16, 0, 0);
+                if (!dv_pad[i])              // (the LDS side of the DMA is lane-linear whatever EXEC is: masked lanes leave their 16 B untouched)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + off),
+                                                     (__attribute__((address_space(3))) void*)(vb + ii * 1024), 16, 0, 0);
             }
         }
     };
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         const float m_new = fmaxf(m_run, mx);
         if (__builtin_amdgcn_ballot_w64(m_new > m_run + AB_LAZY_RESCALE_LOG2) != 0) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
+            if constexpr (!LSUM) l_run *= alpha;
             if constexpr (PV16) {
                 // the accumulators of query tile 0 / 1 sit in ALL four lane rows: row 0 (= row 2) / row 1 (= row 3) holds those queries' factor
                 const u32x2 aa = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(alpha), bitcast<uint32_t>(alpha), false, false);
@@ -239,16 +250,24 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
                 f32x2 v = {s[tt][r], s[tt][r + 1]};
                 v = __builtin_elementwise_fma(v, sc2, nm2);
                 v = f32x2{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
-                psum2 += v;
+                if constexpr (!LSUM) psum2 += v;
                 p[tt * 2 + (r >> 3)][r & 7] = T16<T>::from_f32(v[0]);
                 p[tt * 2 + (r >> 3)][(r & 7) + 1] = T16<T>::from_f32(v[1]);
             }
-        l_run += psum2[0] + psum2[1];
+        if constexpr (!LSUM) l_run += psum2[0] + psum2[1];
     };
 
     const bool group_b = wave_u >= NW / 2;
     f32x16 s[2];
     vec8 p[4];
+    if constexpr (LSUM) {                    // the constant pad chunk of the 3 x 64 V rows
+        for (int r = tid; r < 3 * ATT_BK; r += NW * 64) {
+            vec8 one;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) one[e] = T16<T>::from_f32(e == 0 ? 1.f : 0.f);
+            *(vec8*)(smem + V_BASE + (r / ATT_BK) * VT_BYTES + (r % ATT_BK) * (LDV * 2) + C::CH * 16) = one;
+        }
+    }
     issue_k(0, 0);
     issue_v(0, 0);
     __syncthreads();
@@ -305,7 +324,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         const u32x2 ii = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(inv), bitcast<uint32_t>(inv), false, false);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const float iq = bitcast<float>(ii[qt]);
+            // LSUM: l of query 16 qt + (lane & 15) = column 72 of its O row: d-tile 4, lane group 2, register 0
+            const float iq = LSUM ? 1.0f / __shfl(o16[DT - 1][qt][0], 32 + (lane & 15), 64) : bitcast<float>(ii[qt]);
             const int qrow = q0 + 16 * qt + (lane & 15);
             if (qrow < a.S) {
                 T* op = (T*)a.o + b * a.o_bs + (long)head * a.o_hs + (long)qrow * a.o_rs;
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, int D, int NW, bool PV16>
+template <typename T, int D, int NW, bool PV16, bool LSUM = PV16>
 static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
@@ -350,10 +370,10 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     if (cur_dev >= 16 || !done_dev[cur_dev]) {
-        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW, PV16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW, PV16, LSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (cur_dev < 16) done_dev[cur_dev] = true;
     }
-    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW, PV16>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW, PV16, LSUM>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -361,7 +381,10 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
 // waves = 8: 256 queries per block, two blocks per CU.  waves = 16: 512 queries per block, ONE block per CU sharing one K/V ring - the same
 // 4 waves per SIMD (each SIMD holds two group-A and two group-B waves), half the K/V bytes streamed out of L2 per query.
 // pv32 (attn_ab = 4, A/B and cross-check): the round-2 form with PV on v_mfma_f32_32x32x16 (head dim padded to 96 there).
-int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, bool pv32, hipStream_t s) {
+// form (attn_ab): 0 default | 4 PV on 32x32x16 (round 2) | 5 PV on 16x16x32 with the row sums on the VALU (round 3 before the row-sum column)
+int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, hipStream_t s) {
+    const bool pv32 = form == 4;
+    if (form == 5) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, false>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, false>(a, batch, heads, s);
     if (pv32) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, false>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, false>(a, batch, heads, s);
     if (waves == 16) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 16, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 16, true>(a, batch, heads, s);
     return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true>(a, batch, heads, s);
