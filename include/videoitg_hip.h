@@ -181,8 +181,10 @@ int vitg_rope(void* qkv, int ld, const float* cos_t, const float* sin_t, long N,
 
 /* Non-causal softmax(QK^T * scale) V, fp32 softmax, GQA (heads % kv_heads == 0), head_dim 72 or 128.
  * S queries attend to Sk keys (Sk == S on one GPU; Sk = all-gathered keys in the context-parallel LLM).
- * Strides in elements: *_bs batch, *_rs token row, *_hs head.  variant 0 = production path, 1 = cross-check
- * path that reads V from LDS with scalar loads instead of ds_read_b64_tr_b16.
+ * Strides in elements: *_bs batch, *_rs token row, *_hs head.  variant bit 0 = cross-check path that reads V from LDS with scalar
+ * loads instead of ds_read_b64_tr_b16; variant bit 1 (value 2) = q already holds Q * scale * log2(e) (the producing projection carries the
+ * factor in its q rows - what the engine does for the SigLIP tower): scores are exponentiated in base 2 with no further scaling, which lets
+ * the head-dim-72 kernel take them from the matrix pipe ready for exp2 (no multiply, no max subtraction on the VALU).
  * Replaces flash-attn 2 fwd: SigLIP (clip_encoder.py:117 forces flash_attention_2) and the bidirectional
  * Qwen2 attention (grounding_qwen2.py:45-53, is_causal=False). */
 int vitg_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads, int S,

@@ -161,6 +161,36 @@ def test_attention(ops, attn_waves, dtype, variant, B, H, HKV, S, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ab", [0, 6, 4, 2], ids=["scores_from_matrix_pipe", "valu_scale", "pv32", "per_tile_kernel"])
+@pytest.mark.parametrize("B,H,HKV,S,Sk,D", [(3, 2, 2, 729, 729, 72), (2, 16, 16, 1024, 1024, 72), (2, 3, 3, 100, 1024, 72), (1, 3, 3, 25, 25, 72), (1, 2, 2, 4, 4, 72),
+                                            (1, 2, 2, 300, 1000, 72), (1, 4, 2, 523, 523, 128)])
+def test_attention_with_prescaled_q(ops, dtype, ab, B, H, HKV, S, Sk, D):
+    """vitg_attention variant bit 1: q holds Q * scale * log2(e) (the tower's q projection carries the factor), scores are exponentiated in base 2
+    as they are.  The default head-dim-72 kernel then takes the scores from the matrix pipe already shifted by the running max (a constant pad
+    chunk in K, the shift in Q's pad column); the other kernels run with a unit scale.  S != Sk = the compact last tower layer; a spiked key in a
+    late tile forces the shift to move."""
+    c = D ** -0.5 * 1.4426950408889634
+    q, k, v = rnd((B, H, S, D), 20, dtype=dtype), rnd((B, HKV, Sk, D), 21, dtype=dtype), rnd((B, HKV, Sk, D), 22, dtype=dtype)
+    if Sk >= 300:
+        k[0, 0, 257] = (q[0, 0, 5] * 4).to(dtype).float()
+    qs = (q * c).to(dtype).float()                                   # what the projection's epilogue would have written
+    want = ref_attention(qs, k, v, 0.6931471805599453)               # softmax over ln(2) * (Q' K^T) = base-2 exponentials of Q' K^T
+    qf = qs.permute(0, 2, 1, 3).reshape(B * S, H * D).to(dtype).cuda().contiguous()
+    kv = torch.cat([k.permute(0, 2, 1, 3).reshape(B, Sk, HKV * D), v.permute(0, 2, 1, 3).reshape(B, Sk, HKV * D)], -1).to(dtype).cuda().contiguous().view(B * Sk, 2 * HKV * D)
+    o = torch.zeros((B * S, H * D), dtype=dtype, device="cuda")
+    ops.set_option("attn_ab", ab)
+    try:
+        ops.attention(qf, kv, kv[:, HKV * D:], o, batch=B, heads=H, kv_heads=HKV, seq=S, kv_seq=Sk, head_dim=D, q_strides=(S * H * D, H * D, D),
+                      k_strides=(Sk * 2 * HKV * D, 2 * HKV * D, D), v_strides=(Sk * 2 * HKV * D, 2 * HKV * D, D), o_strides=(S * H * D, H * D, D),
+                      scale=D ** -0.5, variant=2)
+    finally:
+        ops.set_option("attn_ab", 0)
+    got = o.float().cpu().view(B, S, H, D).permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 6 * EPS16[dtype] * v.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("D", [128, 72])
 def test_attention_spiked_key_forces_rescale(ops, attn_waves, dtype, D):
     """One key far above the rest in a late tile: exercises the online-softmax rescale with a large max jump."""

@@ -452,7 +452,7 @@ static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
 }
 
 int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv16, hipStream_t s);   // attention_sp.hip
-int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, hipStream_t s);                 // attention_ab.hip
+int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, bool qs, hipStream_t s);                 // attention_ab.hip
 
 }  // namespace vitg
 
@@ -488,8 +488,12 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
         return VITG_ERR_ARG;              // the product library has no ablation instantiations
 #endif
     }
-    const bool tr = variant != 1;
-    if (!tr) { }     // variant 1 = scalar LDS reads of V (cross-check path for the tr-read)
+    const bool tr = (variant & 1) == 0;  // variant bit 0 = scalar LDS reads of V (cross-check path for the tr-read)
+    // variant bit 1: q holds Q * scale * log2(e) already (the producing projection carries the factor in its weights; `scale` is then only
+    // documentation): every kernel exponentiates K Q^T in base 2 with a unit scale, and the default hd-72 kernel takes the scores from the matrix
+    // pipe ready for exp2 (attention_ab.hip, QS)
+    const bool q_prescaled = (variant & 2) != 0;
+    if (q_prescaled) a.scale_log2e = 1.0f;
     // Defaults from same-call A/B (profiles/r01_attention.md): 8 waves / 256 queries per block when that still yields enough
     // blocks to fill the chip, else 4; K/V staging by LDS-DMA for hd 72 (+16 %: no staging registers -> 3-4 waves/SIMD) and
     // through registers for hd 128 (DMA measured 3-6 % slower there).  attn_waves / attn_dma (1 = DMA, 2 = registers) pin them.
@@ -525,8 +529,8 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     // hd 72 default: the half-tile-out-of-phase kernel (attention_ab.hip, +5 % over the per-tile loop in same-call A/B) whenever
     // 256-query blocks fill the chip and no other variant is pinned; attn_ab = 1 / 2 forces it on / off
     const bool ab_auto = tuning().attn_ab == 0 && !nw_env && nw == 8 && !tuning().attn_pipe && !tuning().attn_dma && tuning().attn_sp != 1;
-    if (tr && head_dim == 72 && !a.ablate && (tuning().attn_ab == 1 || tuning().attn_ab == 3 || tuning().attn_ab == 4 || tuning().attn_ab == 5 || ab_auto) && tuning().attn_sp != 1) {
-        rc = attention_ab_dispatch(a, batch, heads, dtype, tuning().attn_ab == 3 ? 16 : 8, tuning().attn_ab >= 4 ? tuning().attn_ab : 0, s);
+    if (tr && head_dim == 72 && !a.ablate && (tuning().attn_ab == 1 || tuning().attn_ab >= 3 || ab_auto) && tuning().attn_sp != 1) {
+        rc = attention_ab_dispatch(a, batch, heads, dtype, tuning().attn_ab == 3 ? 16 : 8, tuning().attn_ab >= 4 ? tuning().attn_ab : 0, q_prescaled, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
     const bool pipe72 = tr && head_dim == 72 && nw == 4 && tuning().attn_pipe == 1;

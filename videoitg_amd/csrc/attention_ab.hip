@@ -36,9 +36,16 @@ constexpr float AB_LAZY_RESCALE_LOG2 = 8.0f;      // see attention_sp.hip: runni
 // The softmax then has no row-sum adds and no l rescale of its own (the lazy rescale of the accumulators covers that column like any other); l is the
 // sum of the SAME 16-bit-rounded P the numerator uses.
 // LSUM = that form (the default with PV16); false = the softmax adds its row sums on the VALU (attn_ab = 5: A/B and cross-check).
-template <typename T, int D, int NW, bool PV16, bool LSUM = PV16>
+// QS (scores leave the matrix pipe ready for exp2; needs Q pre-multiplied by scale * log2(e) - vitg_attention variant bit 1 - which the engine folds
+// into the q rows of the tower's qkv weights): the same pad column on the QK^T side.  K's pad chunk (d 72..79) holds [1, 0, ..], Q's pad element 72
+// holds -shift of its query, so S' = K Q'^T - shift comes out of the MFMAs that run anyway and P = exp2(S') needs neither the scale multiply nor
+// the max subtraction (one packed FMA per score pair less).  Softmax is shift-invariant per query, so the shift only has to be CONSISTENT between
+// the numerator, the row sum (same P) and the accumulator rescale (alpha = exp2(old shift - new shift)): it is the running max rounded to 16 bits,
+// moved - as before - only when a tile's scores exceed it by more than 2^8, and then that one tile subtracts the step on the VALU.
+template <typename T, int D, int NW, bool PV16, bool LSUM = PV16, bool QS = false>
 __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     static_assert(!LSUM || PV16, "the row-sum column rides the 16x16x32 PV form");
+    static_assert(!QS || LSUM, "the shift column comes with the row-sum column");
     adopt_device_key_count(a);
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
@@ -93,8 +100,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     };
     unsigned dk_off[K_PW], dv_off[V_PW];
     bool dv_pad[V_PW];                       // PV16: this lane's slot is the pad chunk of its V row (holds the constant [1, 0, ..]: never written by the DMA)
+    bool dk_pad[K_PW];                       // QS: the same for K (chunks 9, 10 of the 11)
 #pragma unroll
-    for (int i = 0; i < K_PW; ++i) dk_off[i] = dma_src(wave_u + NW * i, K_CPR, a.k_rs, true, ATT_BK - 1);
+    for (int i = 0; i < K_PW; ++i) {
+        dk_off[i] = dma_src(wave_u + NW * i, K_CPR, a.k_rs, true, ATT_BK - 1);
+        dk_pad[i] = QS && ((wave_u + NW * i) * 64 + lane) % K_CPR >= C::CH;
+    }
 #pragma unroll
     for (int i = 0; i < V_PW; ++i) {
         dv_off[i] = dma_src(wave_u + NW * i, V_CPR, a.v_rs, false, ATT_BK - 1);
@@ -109,8 +120,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
             const int ii = wave_u + NW * i;
             if (ii < K_CPR) {
                 const unsigned off = tail ? dma_src(ii, K_CPR, a.k_rs, true, a.Sk - 1 - kt * ATT_BK) : dk_off[i];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + off),
-                                                 (__attribute__((address_space(3))) void*)(kb + ii * 1024), 16, 0, 0);
+                if (!dk_pad[i])
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + off),
+                                                     (__attribute__((address_space(3))) void*)(kb + ii * 1024), 16, 0, 0);
             }
         }
     };
@@ -214,7 +226,43 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         }
     };
     // online softmax of one tile (lane-local + one exchange with lane^32), lazy rescale; P -> p (16-bit, MFMA B operand layout)
+    float shift = 0.f;                       // QS: what the Q pad column subtracts from this query's scores (a 16-bit value)
+    bool started = false;                    // QS: wave-uniform - a tile has been accumulated (the first tile always sets the shift)
     auto softmax = [&](f32x16 (&s)[2], vec8 (&p)[4]) {
+        if constexpr (QS) {
+            float mx = s[0][0];              // scores are already in log2 units and relative to `shift`
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tt][r]);
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(bitcast<uint32_t>(mx), bitcast<uint32_t>(mx), false, false);
+            mx = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1]));
+            if (!started || __builtin_amdgcn_ballot_w64(mx > AB_LAZY_RESCALE_LOG2) != 0) {
+                const float ns = T16<T>::to_f32(T16<T>::from_f32(shift + (started ? fmaxf(mx, 0.f) : mx)));      // new shift: never lowered, 16-bit exact
+                const float delta = ns - shift;
+                const float alpha = started ? __builtin_amdgcn_exp2f(-delta) : 0.f;
+                const u32x2 aa = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(alpha), bitcast<uint32_t>(alpha), false, false);
+                const float a0 = bitcast<float>(aa[0]), a1 = bitcast<float>(aa[1]);
+#pragma unroll
+                for (int i = 0; i < DT; ++i) { o16[i][0] *= a0; o16[i][1] *= a1; }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[tt][r] -= delta;                 // this tile was computed against the old shift
+                shift = ns;
+                started = true;
+                if (h == 1) qf[KS - 1][0] = T16<T>::from_f32(-ns);                  // element d = 72 of this query's Q row
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float v0 = __builtin_amdgcn_exp2f(s[tt][r]), v1 = __builtin_amdgcn_exp2f(s[tt][r + 1]);
+                    p[tt * 2 + (r >> 3)][r & 7] = T16<T>::from_f32(v0);
+                    p[tt * 2 + (r >> 3)][(r & 7) + 1] = T16<T>::from_f32(v1);
+                }
+            return;
+        }
         float mx = s[0][0];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
@@ -266,6 +314,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) one[e] = T16<T>::from_f32(e == 0 ? 1.f : 0.f);
             *(vec8*)(smem + V_BASE + (r / ATT_BK) * VT_BYTES + (r % ATT_BK) * (LDV * 2) + C::CH * 16) = one;
+        }
+    }
+    if constexpr (QS) {                      // the constant pad chunk (d 72..79) of the 2 x 64 K rows
+        for (int r = tid; r < 2 * ATT_BK; r += NW * 64) {
+            vec8 one;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) one[e] = T16<T>::from_f32(e == 0 ? 1.f : 0.f);
+            *(vec8*)(smem + (r / ATT_BK) * KT_BYTES + k_lds_off<D>(r % ATT_BK, C::CH)) = one;
         }
     }
     issue_k(0, 0);
@@ -361,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, int D, int NW, bool PV16, bool LSUM = PV16>
+template <typename T, int D, int NW, bool PV16, bool LSUM = PV16, bool QS = false>
 static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
@@ -370,10 +426,10 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     if (cur_dev >= 16 || !done_dev[cur_dev]) {
-        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW, PV16, LSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW, PV16, LSUM, QS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (cur_dev < 16) done_dev[cur_dev] = true;
     }
-    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW, PV16, LSUM>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW, PV16, LSUM, QS>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -382,8 +438,12 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
 // 4 waves per SIMD (each SIMD holds two group-A and two group-B waves), half the K/V bytes streamed out of L2 per query.
 // pv32 (attn_ab = 4, A/B and cross-check): the round-2 form with PV on v_mfma_f32_32x32x16 (head dim padded to 96 there).
 // form (attn_ab): 0 default | 4 PV on 32x32x16 (round 2) | 5 PV on 16x16x32 with the row sums on the VALU (round 3 before the row-sum column)
-int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, hipStream_t s) {
+// qs: Q arrives pre-multiplied by scale * log2(e) (a.scale_log2e == 1) and the default form may take the scores straight from the matrix pipe;
+// form 6 = pre-scaled Q WITHOUT that (the multiply by 1 and the max subtraction stay on the VALU: A/B)
+int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, bool qs, hipStream_t s) {
     const bool pv32 = form == 4;
+    if (qs && form == 0 && waves == 8)
+        return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, true, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, true, true>(a, batch, heads, s);
     if (form == 5) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, false>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, false>(a, batch, heads, s);
     if (pv32) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, false>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, false>(a, batch, heads, s);
     if (waves == 16) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 16, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 16, true>(a, batch, heads, s);

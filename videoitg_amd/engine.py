@@ -119,6 +119,10 @@ class PackedWeights:
     vit_dtype: Optional[torch.dtype] = None         # MFMA input type of the SigLIP tower (None = dtype): the tower tolerates bf16 (8-bit
                                                     # mantissa) inside the 1e-3 score bound, the 28-layer bidirectional LLM does not
                                                     # (profiles/r02_parity.md), so "tower bf16 + LLM fp16" is a supported mix
+    vit_q_prescaled: bool = None                    # the q rows (and bias) of the tower's qkv projection carry head_dim^-0.5 * log2(e): the attention
+                                                    # then exponentiates K Q^T as it leaves the matrix pipe (vitg_attention variant bit 1;
+                                                    # csrc/attention_ab.hip, QS).  One rounding of c * W instead of W - no extra rounding of Q.
+                                                    # None = on unless VITG_Q_PRESCALE=0
     fp8: object = False                             # BASELINE.json configs[4]: tower / decoder GEMM weights as e4m3fn + per-channel scales;
                                                     # True = both parts, "vit" / "llm" = that part only (the other stays 16-bit)
     patch_w: torch.Tensor = None; patch_b: torch.Tensor = None
@@ -137,6 +141,8 @@ class PackedWeights:
         self.fp8 = normalise_fp8(self.fp8)
         if self.vit_dtype is None:
             self.vit_dtype = self.dtype
+        if self.vit_q_prescaled is None:
+            self.vit_q_prescaled = os.environ.get("VITG_Q_PRESCALE", "1") not in ("", "0")
         self._packing = self.dtype                  # type the _w16 / _wl helpers currently emit (switched while the tower is packed)
         self._packing_part = "llm"
 
@@ -181,8 +187,10 @@ class PackedWeights:
         v = self.cfg.vision
         p = f"vision_model.encoder.layers.{i}."
         fvp = pad64(v.intermediate_size)
-        qkv_w = torch.cat([vsd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
-        qkv_b = torch.cat([vsd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        # softmax scale and the base-2 factor folded into the q projection (fp32, before the one rounding to 16 bits)
+        qs = v.head_dim ** -0.5 * 1.4426950408889634 if self.vit_q_prescaled else 1.0
+        qkv_w = torch.cat([vsd[p + f"self_attn.{n}_proj.weight"].float() * (qs if n == "q" else 1.0) for n in "qkv"], 0)
+        qkv_b = torch.cat([vsd[p + f"self_attn.{n}_proj.bias"].float() * (qs if n == "q" else 1.0) for n in "qkv"], 0)
         self._packing, self._packing_part = self.vit_dtype, "vit"
         self.vit.append(VitLayerW(
             ln1_w=self._f32(vsd[p + "layer_norm1.weight"]), ln1_b=self._f32(vsd[p + "layer_norm1.bias"]),
@@ -469,6 +477,7 @@ class SelectorEngine:
         mx_mlp = self.fp8_mx and all(isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight) for lw in w.vit)
         f = None if mx_mlp else self._buf("vit_f", (M, Fvp), vdt)      # (the MX path keeps the hidden activation in its own e4m3 buffer)
         scale = hd ** -0.5
+        vit_variant = self.attn_variant | (2 if w.vit_q_prescaled else 0)     # bit 1: Q arrives as Q * scale * log2(e) (PackedWeights.vit_q_prescaled)
         st = (P * 3 * Dv, 3 * Dv, hd)
         for li, lw in enumerate(full_layers):
             if pend is not None:
@@ -478,7 +487,7 @@ class SelectorEngine:
                 self._gemm(h, lw.qkv_w, qkv, mode=K.GEMM_STORE16, bias=lw.qkv_b)
             K.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
                         q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
-                        variant=self.attn_variant)
+                        variant=vit_variant)
             if r16:
                 update(o, lw.out_w, lw.out_b, x)
                 h = norm(x, lw.ln2_w, lw.ln2_b, "vit_h", lw.fc1_w)
@@ -522,7 +531,7 @@ class SelectorEngine:
         oc = self._buf("vit_oc", (Mc, Dvp), vdt, zero=True)
         K.attention(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
                     q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
-                    variant=self.attn_variant)
+                    variant=vit_variant)
         if r16:
             update(oc, lw.out_w, lw.out_b, xq)
         else:
