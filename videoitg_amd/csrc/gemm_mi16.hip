@@ -134,11 +134,27 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     // read-modify-write then overlaps the main loop; these loads are older than every DMA in the vmcnt queue)
     // (MODE_RES16 = vitg_gemm_res16: the 16-bit residual stream of the tower, or the fp32 position table, into a 16-bit output)
     const bool acc_from_res = (MODE == MODE_F32 && g.res != nullptr && g.act == VITG_ACT_NONE) || RES16;
+    // 16-bit output with a bias and no residual: the accumulators START at the bias (a lane's four features are the same for all its row tiles), so
+    // the epilogue has no add - the initialisation costs the same moves as zeroing.  gemm_flags bit27 keeps the add in the epilogue (A/B)
+    const bool bias_init = MODE == MODE_STORE16 && g.bias != nullptr && !(g.flags & 0x8000000);
+    const bool res_bias_init = RES16 && g.bias != nullptr && !(g.flags & 0x8000000);      // 16-bit residual form: the bias is added to the preloaded residual
+    // (the bias quads are requested here - older than every DMA in the vmcnt queue - and moved into the accumulators behind the wait for the first
+    // stage, so the first DMA round trip covers them)
     f32x4 acc[NT][MT];
+    f32x4 bq[MODE == MODE_STORE16 ? NT : 1];
+    if constexpr (MODE == MODE_STORE16) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i) {
+            const int nb = n0 + wc * (NT * 16) + i * 16 + fq * 4;
+            bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias_init && nb < g.N) bq[i] = *(const f32x4*)(g.bias + nb);
+        }
+    } else {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if constexpr (MODE == MODE_F32 || RES16) {
         if (acc_from_res) {
 #pragma unroll
@@ -156,6 +172,9 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[nt][mt][e] += T16<T>::to_f32(r[e]);
                             }
+                            // the bias joins the residual here (one L1 hit per accumulator quad, next to the residual load it rides with) instead
+                            // of being re-read in the epilogue, where every load is exposed
+                            if (res_bias_init) acc[nt][mt] += *(const f32x4*)(g.bias + n);
                         }
                     }
                 }
@@ -182,6 +201,12 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     vec8 fw[NT], fa[MC];
     const bool grpB = wave >= 4;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (MODE == MODE_STORE16) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = bq[i];
+    }
     __builtin_amdgcn_s_barrier();
     if (grpB) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                     } else {
                         v = acc[nt][mp * 2 + h];
                         const int nb = nw + nt * 16 + fq * 4;      // (bias re-read per row pair from L1 instead of NT quads held over the epilogue)
-                        if (g.bias && nb < g.N) v += *(const f32x4*)(g.bias + nb);
+                        if (g.bias && nb < g.N && !(MODE == MODE_STORE16 && bias_init) && !(RES16 && res_bias_init)) v += *(const f32x4*)(g.bias + nb);
                         if (g.act == VITG_ACT_GELU_TANH) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
