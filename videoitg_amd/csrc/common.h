@@ -79,6 +79,20 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float a = x * __builtin_fmaf(x * x, -0.10294324302f, -2.30220819814f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
+// two values at a time on the packed fp32 VALU forms (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: one issue per pair) - the same operations in the same
+// order as the scalar forms, so the results are bit-identical
+__device__ __forceinline__ f32x2 gelu_tanh_f2(f32x2 x) {
+    const f32x2 ca = {-0.10294324302f, -0.10294324302f}, cb = {-2.30220819814f, -2.30220819814f}, one = {1.0f, 1.0f};
+    const f32x2 a = x * __builtin_elementwise_fma(x * x, ca, cb);
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + one;
+    return x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 silu_mul_f2(f32x2 gate, f32x2 up) {          // silu(gate) * up
+    const f32x2 c = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
+    const f32x2 a = c * gate;
+    const f32x2 d = one + f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    return (gate * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])}) * up;
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 

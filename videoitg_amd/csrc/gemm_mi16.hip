@@ -85,6 +85,9 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         sk_c1 = (int)(u1 - u0) - sk_c0;
     }
     const int item_end = SK ? (sk_c1 > 0 ? 2 : 1) : nwg_, item_step = SK ? 1 : (int)gridDim.x;
+    // (Requesting the first operand stage of the NEXT tile before this tile's epilogue - so that the wait at the next tile's start does not cover
+    // the drain of the output stores and a DMA round trip back to back - was built and measured: 669.7-670.4 against 668.8-671.0 ms per step,
+    // nothing, at 10-23 more spilled registers per tile.  Not kept; gpurun_out/r03_c21.)
     for (int vb = SK ? 0 : (int)blockIdx.x; vb < item_end; vb += item_step) {
     // per-lane quantities re-derived from an opaque copy of the thread id in every pass (hoisted they would stay live through the loop)
     int tid = threadIdx.x;
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     // 16-bit output with a bias and no residual: the accumulators START at the bias (a lane's four features are the same for all its row tiles), so
     // the epilogue has no add - the initialisation costs the same moves as zeroing.  gemm_flags bit27 keeps the add in the epilogue (A/B)
     const bool bias_init = MODE == MODE_STORE16 && g.bias != nullptr && !(g.flags & 0x8000000);
-    const bool res_bias_init = RES16 && g.bias != nullptr && !(g.flags & 0x8000000);      // 16-bit residual form: the bias is added to the preloaded residual
+    // (the 16-bit-residual form keeps its bias add in the epilogue: adding it to the preloaded residual measured 0.5 % SLOWER in the step - 670.7-671.9
+    // against 667.2-668.3 ms, gpurun_out/r03_c20 - the preload is the load-heavy phase of those tiles)
     // (the bias quads are requested here - older than every DMA in the vmcnt queue - and moved into the accumulators behind the wait for the first
     // stage, so the first DMA round trip covers them)
     f32x4 acc[NT][MT];
@@ -172,9 +176,6 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[nt][mt][e] += T16<T>::to_f32(r[e]);
                             }
-                            // the bias joins the residual here (one L1 hit per accumulator quad, next to the residual load it rides with) instead
-                            // of being re-read in the epilogue, where every load is exposed
-                            if (res_bias_init) acc[nt][mt] += *(const f32x4*)(g.bias + n);
                         }
                     }
                 }
@@ -314,6 +315,10 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         char* const stage = smem + wave * (32 * RB);
         const int n_out = EMODE == MODE_SWIGLU ? nw / 2 : nw;
         const int n_lim = EMODE == MODE_SWIGLU ? g.N / 2 : g.N;
+        // the activation is selected ONCE per tile (three copies of the stage loop), not per accumulator quad: a run-time test inside the quad loop
+        // is a scalar branch per quad - 48-72 per tile - and cuts the stage into basic blocks the scheduler cannot overlap
+        auto stages = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
         for (int mp = 0; mp < MT / 2; ++mp) {
 #pragma unroll
@@ -324,18 +329,34 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                     if constexpr (EMODE == MODE_SWIGLU) {
                         // weight rows are interleaved [32 gate | 32 up] (engine.pack_llm_layer): of every 64 features of the wave, tiles 0-1 gate, 2-3 up
                         const int gt = (nt >> 1) * 4 + (nt & 1);
+                        const f32x4 ga = acc[gt][mp * 2 + h], up = acc[gt + 2][mp * 2 + h];
+                        if constexpr (ACT == -1) {               // (A/B: the scalar form)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[gt][mp * 2 + h][e]) * acc[gt + 2][mp * 2 + h][e];
+                            for (int e = 0; e < 4; ++e) v[e] = silu_f(ga[e]) * up[e];
+                        } else {
+                            const f32x2 lo = silu_mul_f2(f32x2{ga[0], ga[1]}, f32x2{up[0], up[1]}), hi = silu_mul_f2(f32x2{ga[2], ga[3]}, f32x2{up[2], up[3]});
+                            v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                        }
                     } else {
                         v = acc[nt][mp * 2 + h];
-                        const int nb = nw + nt * 16 + fq * 4;      // (bias re-read per row pair from L1 instead of NT quads held over the epilogue)
-                        if (g.bias && nb < g.N && !(MODE == MODE_STORE16 && bias_init) && !(RES16 && res_bias_init)) v += *(const f32x4*)(g.bias + nb);
-                        if (g.act == VITG_ACT_GELU_TANH) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                        } else if (g.act == VITG_ACT_GELU_ERF) {
+                        // (bias re-read per quad from L1 instead of NT quads held over the epilogue - held across the main loop OR across the stages they
+                        // spill the wide tiles; the 16-bit-output form has it in its accumulators already)
+                        const int nb = nw + nt * 16 + fq * 4;
+                        if (g.bias && nb < g.N && !(MODE == MODE_STORE16 && bias_init)) v += *(const f32x4*)(g.bias + nb);
+                        if constexpr (ACT == VITG_ACT_GELU_TANH) {
+                            const f32x2 lo = gelu_tanh_f2(f32x2{v[0], v[1]}), hi = gelu_tanh_f2(f32x2{v[2], v[3]});
+                            v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                        } else if constexpr (ACT == VITG_ACT_GELU_ERF) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                        } else if constexpr (ACT == -1) {        // (A/B, gemm_flags bit28: the activation tested per quad, scalar forms - the round-2 epilogue)
+                            if (g.act == VITG_ACT_GELU_TANH) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                            } else if (g.act == VITG_ACT_GELU_ERF) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                            }
                         }
                     }
                     typename T16<T>::vec4 o;
@@ -358,6 +379,11 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                 }
             }
         }
+        };   // stages
+        if (g.flags & 0x10000000) stages(std::integral_constant<int, -1>{});
+        else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_TANH) stages(std::integral_constant<int, VITG_ACT_GELU_TANH>{});
+        else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) stages(std::integral_constant<int, VITG_ACT_GELU_ERF>{});
+        else stages(std::integral_constant<int, VITG_ACT_NONE>{});
     }
     if (vb + item_step < item_end) {                     // another tile follows: every wave is done with its staging window
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
