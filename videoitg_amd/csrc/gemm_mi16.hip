@@ -159,8 +159,28 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
 #pragma unroll
             for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // Interior tiles (all of BM x BN inside M x N - every tile but the last row / column of tiles) take straight-line forms of the residual preload
+    // and of the output stages: no per-quad bounds predicate, no per-quad test of which residual pointers are set.  gemm_flags bit29 = off (A/B).
+    const bool interior = !(g.flags & 0x20000000) && m0 + BM <= g.M && n0 + BN <= g.N;
     if constexpr (MODE == MODE_F32 || RES16) {
         if (acc_from_res) {
+            if (RES16 && interior && g.res16 != nullptr && g.res == nullptr) {          // the tower's 16-bit stream
+                const T* const rb = (const T*)g.res16 + (size_t)(m0 + wr * (MT * 16) + r16) * g.ldr16 + (n0 + wc * (NT * 16) + fq * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const typename T16<T>::vec4 r = *(const typename T16<T>::vec4*)(rb + (size_t)(mt * 16) * g.ldr16 + nt * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[nt][mt][e] = T16<T>::to_f32(r[e]);
+                    }
+            } else if (MODE == MODE_F32 && interior && g.res_mod == 0) {                 // the decoder's fp32 stream (g.res is set: acc_from_res)
+                const float* const rb = g.res + (size_t)(m0 + wr * (MT * 16) + r16) * g.ldr + (n0 + wc * (NT * 16) + fq * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = *(const f32x4*)(rb + (size_t)(mt * 16) * g.ldr + nt * 16);
+            } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = m0 + wr * (MT * 16) + mt * 16 + r16;
@@ -179,6 +199,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                         }
                     }
                 }
+            }
             }
         }
     }
@@ -317,8 +338,9 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         const int n_lim = EMODE == MODE_SWIGLU ? g.N / 2 : g.N;
         // the activation is selected ONCE per tile (three copies of the stage loop), not per accumulator quad: a run-time test inside the quad loop
         // is a scalar branch per quad - 48-72 per tile - and cuts the stage into basic blocks the scheduler cannot overlap
-        auto stages = [&](auto act_c) {
+        auto stages = [&](auto act_c, auto in_c) {
         constexpr int ACT = decltype(act_c)::value;
+        constexpr bool IN = decltype(in_c)::value;           // interior tile: no bounds predicates
 #pragma unroll
         for (int mp = 0; mp < MT / 2; ++mp) {
 #pragma unroll
@@ -342,7 +364,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                         // (bias re-read per quad from L1 instead of NT quads held over the epilogue - held across the main loop OR across the stages they
                         // spill the wide tiles; the 16-bit-output form has it in its accumulators already)
                         const int nb = nw + nt * 16 + fq * 4;
-                        if (g.bias && nb < g.N && !(MODE == MODE_STORE16 && bias_init)) v += *(const f32x4*)(g.bias + nb);
+                        if (g.bias && (IN || nb < g.N) && !(MODE == MODE_STORE16 && bias_init)) v += *(const f32x4*)(g.bias + nb);
                         if constexpr (ACT == VITG_ACT_GELU_TANH) {
                             const f32x2 lo = gelu_tanh_f2(f32x2{v[0], v[1]}), hi = gelu_tanh_f2(f32x2{v[2], v[3]});
                             v = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -372,18 +394,22 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                 const int row = idx / CH, c = idx % CH;
                 const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4));
                 const int m = mw + mp * 32 + row, n = n_out + c * 8;
-                if (m < g.M) {
+                if (IN || m < g.M) {
                     const unsigned boff = (unsigned)(row * g.ldo + c * 8) * 2u;
-                    if (n + 8 <= n_lim) *(u32x4*)(ob + boff) = v;
+                    if (IN || n + 8 <= n_lim) *(u32x4*)(ob + boff) = v;
                     else if (n + 4 <= n_lim) *(u32x2*)(ob + boff) = u32x2{v[0], v[1]};
                 }
             }
         }
         };   // stages
-        if (g.flags & 0x10000000) stages(std::integral_constant<int, -1>{});
-        else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_TANH) stages(std::integral_constant<int, VITG_ACT_GELU_TANH>{});
-        else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) stages(std::integral_constant<int, VITG_ACT_GELU_ERF>{});
-        else stages(std::integral_constant<int, VITG_ACT_NONE>{});
+        typedef std::true_type IY;
+        typedef std::false_type IN_;
+        if (g.flags & 0x10000000) stages(std::integral_constant<int, -1>{}, IN_{});
+        else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_TANH) {
+            if (interior) stages(std::integral_constant<int, VITG_ACT_GELU_TANH>{}, IY{}); else stages(std::integral_constant<int, VITG_ACT_GELU_TANH>{}, IN_{});
+        } else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) stages(std::integral_constant<int, VITG_ACT_GELU_ERF>{}, IN_{});
+        else if (interior) stages(std::integral_constant<int, VITG_ACT_NONE>{}, IY{});
+        else stages(std::integral_constant<int, VITG_ACT_NONE>{}, IN_{});
     }
     if (vb + item_step < item_end) {                     // another tile follows: every wave is done with its staging window
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
