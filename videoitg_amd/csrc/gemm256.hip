@@ -943,7 +943,9 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
     // cap lets run 14 % faster than 32x32x16 on real operands (profiles/r03_mfma_shape.md)
     // (the residual forms of the 16-bit-output mode - vitg_gemm_res16 - exist in gemm_mi16.hip and the 128-tile kernel only; gemm_entry
     // never sends them here with the 256x128 tile)
-    if ((cfg == 6 || cfg == 9 || cfg == 10) && (gemm_mi16_selected(MODE) || (MODE == MODE_STORE16 && (g.res || g.res16))))
+    // (fp32 output WITH an activation - no caller in the engine - stays on this file's kernels: gemm_mi16.hip's fp32 epilogue carries none)
+    if ((cfg == 6 || cfg == 9 || cfg == 10) && !(MODE == MODE_F32 && g.act != VITG_ACT_NONE) &&
+        (gemm_mi16_selected(MODE) || (MODE == MODE_STORE16 && (g.res || g.res16))))
         return launch_gemm_mi16(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, cfg, s);
 #if VITG_PROFILING_BUILD
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)

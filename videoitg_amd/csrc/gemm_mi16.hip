@@ -287,6 +287,10 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         constexpr int SWZ = (CH & -CH) - 1;               // 15 or 7
         auto swz = [](int row) { return RB % 256 == 0 ? (row & SWZ) : ((row >> 1) & SWZ); };
         char* const stage = smem + wave * (32 * RB);
+        // (no activation in this epilogue: fp32 output with an activation runs on gemm256.hip's kernels, launch256_m)
+        auto stages32 = [&](auto in_c, auto bias_c) {
+        constexpr bool IN = decltype(in_c)::value;           // interior tile (or a stream-K partial tile): no bounds predicates, residual already in the accumulators
+        constexpr bool BIAS = decltype(bias_c)::value;
 #pragma unroll
         for (int mp = 0; mp < MT / 2; ++mp) {
 #pragma unroll
@@ -294,14 +298,9 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     f32x4 v = acc[nt][mp * 2 + h];
-                    const int nb = nw + nt * 16 + fq * 4;          // (the bias is re-read per row pair from L1: holding NT quads of it
-                    if (g.bias && nb < g.N) v += *(const f32x4*)(g.bias + nb);   //  over the epilogue spilled the wide tiles)
-                    if (g.act == VITG_ACT_GELU_TANH) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                    } else if (g.act == VITG_ACT_GELU_ERF) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                    if constexpr (BIAS) {
+                        const int nb = nw + nt * 16 + fq * 4;      // (the bias is re-read per quad from L1: holding NT quads of it over the epilogue spilled the wide tiles)
+                        if (IN || nb < g.N) v += *(const f32x4*)(g.bias + nb);
                     }
                     const int row = h * 16 + r16, c = nt * 4 + fq;
                     *(f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4)) = v;
@@ -317,8 +316,8 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                 const int row = idx / CH, c = idx % CH;
                 f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4));
                 const int m = om + mp * 32 + row, n = on + c * 4;
-                if (m < oM && n < oN) {
-                    if (!SK && g.res && !acc_from_res) {
+                if (IN || (m < oM && n < oN)) {
+                    if (!IN && !SK && g.res && !acc_from_res) {
                         const int rm = g.res_mod > 0 ? m % g.res_mod : m;
                         v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
                     }
@@ -326,6 +325,12 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                 }
             }
         }
+        };   // stages32
+        typedef std::true_type Y_;
+        typedef std::false_type N_;
+        const bool in32 = (SK || interior) && (SK || !g.res || acc_from_res);
+        if (SK || g.bias == nullptr) { if (in32) stages32(Y_{}, N_{}); else stages32(N_{}, N_{}); }
+        else { if (in32) stages32(Y_{}, Y_{}); else stages32(N_{}, Y_{}); }
     } else {
         constexpr int NTO = EMODE == MODE_SWIGLU ? NT / 2 : NT;        // output 16-column tiles per wave
         constexpr int CH = NTO * 2;                                   // 16-B chunks (8 halfs) per row: 4, 8 or 12
