@@ -343,9 +343,11 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         const int n_lim = EMODE == MODE_SWIGLU ? g.N / 2 : g.N;
         // the activation is selected ONCE per tile (three copies of the stage loop), not per accumulator quad: a run-time test inside the quad loop
         // is a scalar branch per quad - 48-72 per tile - and cuts the stage into basic blocks the scheduler cannot overlap
-        auto stages = [&](auto act_c, auto in_c) {
+        const bool has_bias = EMODE != MODE_SWIGLU && g.bias != nullptr && !(MODE == MODE_STORE16 && bias_init);      // a bias is still to be added here
+        auto stages = [&](auto act_c, auto in_c, auto bias_c) {
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool IN = decltype(in_c)::value;           // interior tile: no bounds predicates
+        constexpr int BIAS = decltype(bias_c)::value;        // 1 / 0: a bias is / is not added here (interior forms); -1: tested per quad (edge tiles)
 #pragma unroll
         for (int mp = 0; mp < MT / 2; ++mp) {
 #pragma unroll
@@ -369,7 +371,8 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                         // (bias re-read per quad from L1 instead of NT quads held over the epilogue - held across the main loop OR across the stages they
                         // spill the wide tiles; the 16-bit-output form has it in its accumulators already)
                         const int nb = nw + nt * 16 + fq * 4;
-                        if (g.bias && (IN || nb < g.N) && !(MODE == MODE_STORE16 && bias_init)) v += *(const f32x4*)(g.bias + nb);
+                        if constexpr (BIAS == 1) v += *(const f32x4*)(g.bias + nb);
+                        else if constexpr (BIAS == -1) { if (has_bias && nb < g.N) v += *(const f32x4*)(g.bias + nb); }
                         if constexpr (ACT == VITG_ACT_GELU_TANH) {
                             const f32x2 lo = gelu_tanh_f2(f32x2{v[0], v[1]}), hi = gelu_tanh_f2(f32x2{v[2], v[3]});
                             v = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -409,12 +412,22 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         };   // stages
         typedef std::true_type IY;
         typedef std::false_type IN_;
-        if (g.flags & 0x10000000) stages(std::integral_constant<int, -1>{}, IN_{});
+        typedef std::integral_constant<int, 1> B1;
+        typedef std::integral_constant<int, 0> B0;
+        typedef std::integral_constant<int, -1> BR;
+        typedef std::integral_constant<int, VITG_ACT_GELU_TANH> AT;
+        typedef std::integral_constant<int, VITG_ACT_NONE> AN;
+        if (g.flags & 0x10000000) stages(std::integral_constant<int, -1>{}, IN_{}, BR{});
         else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_TANH) {
-            if (interior) stages(std::integral_constant<int, VITG_ACT_GELU_TANH>{}, IY{}); else stages(std::integral_constant<int, VITG_ACT_GELU_TANH>{}, IN_{});
-        } else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) stages(std::integral_constant<int, VITG_ACT_GELU_ERF>{}, IN_{});
-        else if (interior) stages(std::integral_constant<int, VITG_ACT_NONE>{}, IY{});
-        else stages(std::integral_constant<int, VITG_ACT_NONE>{}, IN_{});
+            if (!interior) stages(AT{}, IN_{}, BR{});
+            else if (g.flags & 0x40000000) stages(AT{}, IY{}, BR{});          // (A/B: bias tested per quad)
+            else if (has_bias) stages(AT{}, IY{}, B1{});
+            else stages(AT{}, IY{}, B0{});
+        } else if (EMODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) stages(std::integral_constant<int, VITG_ACT_GELU_ERF>{}, IN_{}, BR{});
+        else if (!interior) stages(AN{}, IN_{}, BR{});
+        else if (g.flags & 0x40000000) stages(AN{}, IY{}, BR{});              // (A/B: bias tested per quad)
+        else if (EMODE != MODE_SWIGLU && has_bias) stages(AN{}, IY{}, B1{});
+        else stages(AN{}, IY{}, B0{});
     }
     if (vb + item_step < item_end) {                     // another tile follows: every wave is done with its staging window
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
