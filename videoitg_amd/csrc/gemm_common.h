@@ -1,5 +1,6 @@
 // Shared between the GEMM kernels (gemm.hip: 128x128 tile, gemm256.hip: 256xBN ring-buffered tile).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "../../include/videoitg_hip.h"
 
@@ -149,6 +150,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
         auto swz = [](int row) { return RB % 256 == 0 ? (row & SWZ) : ((row >> 1) & SWZ); };
                                                           // (Padding the row instead, as the 16-bit path does, costs registers here:
                                                           // the 256x384 fp32 kernel went from 19 to 256 spills.)
+        // the activation / bias tests are made once (two copies of the loop), not per accumulator quad: a run-time test in the quad loop is a
+        // scalar branch per quad and cuts the tile into basic blocks the scheduler cannot overlap (profiles/r03_gemm_epilogue.md)
+        auto body32 = [&](auto plain_c) {
+        constexpr bool PLAIN = decltype(plain_c)::value;      // no bias, no activation (the decoder's o / down projections)
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt) {
 #pragma unroll
@@ -159,6 +164,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][q4 * 4 + e];
                     const int n = n_base + nt * 32 + q4 * 8 + fh * 4;
+                    if constexpr (!PLAIN) {
                     if (g.bias && n < g.N) v += *(const f32x4*)(g.bias + n);
                     if (g.act == VITG_ACT_GELU_TANH) {
 #pragma unroll
@@ -166,6 +172,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                     } else if (g.act == VITG_ACT_GELU_ERF) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                    }
                     }
                     const int c = nt * 8 + q4 * 2 + fh;
                     *(f32x4*)(stage + frow * RB + ((c ^ swz(frow)) << 4)) = v;
@@ -192,6 +199,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                 }
             }
         }
+        };   // body32
+        if (g.bias == nullptr && g.act == VITG_ACT_NONE) body32(std::true_type{}); else body32(std::false_type{});
     } else {
         constexpr int NTO = MODE == MODE_SWIGLU ? 1 : NT;  // output 32-column tiles per wave
         constexpr int CH = NTO * 4;                        // 16-B chunks (8 halfs) per row
@@ -202,6 +211,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
         // bits ABOVE those.  (With the low bits, as round 1 had it, the 8-B staging writes of rows r, r + 8, r + 16, r + 24 met in the
         // same banks: 4-way conflicts on 48 writes per wave and tile; now 2-way, the minimum for 8-B writes at this row pitch.)
         constexpr int SH = CH == 4 ? 2 : CH == 8 ? 1 : 0;
+        auto body16 = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;           // chosen once per tile (see body32)
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt)
 #pragma unroll
@@ -215,8 +226,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = silu_f(rs * acc[0][mt][q4 * 4 + e]) * (rs * acc[NT - 1][mt][q4 * 4 + e]);
                         } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[0][mt][q4 * 4 + e]) * acc[NT - 1][mt][q4 * 4 + e];
+                            const f32x2 lo = silu_mul_f2(f32x2{acc[0][mt][q4 * 4], acc[0][mt][q4 * 4 + 1]}, f32x2{acc[NT - 1][mt][q4 * 4], acc[NT - 1][mt][q4 * 4 + 1]});
+                            const f32x2 hi = silu_mul_f2(f32x2{acc[0][mt][q4 * 4 + 2], acc[0][mt][q4 * 4 + 3]}, f32x2{acc[NT - 1][mt][q4 * 4 + 2], acc[NT - 1][mt][q4 * 4 + 3]});
+                            v = f32x4{lo[0], lo[1], hi[0], hi[1]};
                         }
                     } else {
 #pragma unroll
@@ -229,10 +241,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                             for (int e = 0; e < 4; ++e) v[e] = nrs[mt - MT0] * (v[e] - nmu[mt - MT0] * sn[e]);
                         }
                         if (g.bias && n < g.N) v += *(const f32x4*)(g.bias + n);
-                        if (g.act == VITG_ACT_GELU_TANH) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                        } else if (g.act == VITG_ACT_GELU_ERF) {
+                        if constexpr (ACT == VITG_ACT_GELU_TANH) {
+                            const f32x2 lo = gelu_tanh_f2(f32x2{v[0], v[1]}), hi = gelu_tanh_f2(f32x2{v[2], v[3]});
+                            v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                        } else if constexpr (ACT == VITG_ACT_GELU_ERF) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
                         }
@@ -243,6 +255,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                     const int row = (mt - MT0) * 32 + frow, c = nt * 4 + q4;
                     *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4) + fh * 8) = o;
                 }
+        };   // body16
+        if (MODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_TANH) body16(std::integral_constant<int, VITG_ACT_GELU_TANH>{});
+        else if (MODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) body16(std::integral_constant<int, VITG_ACT_GELU_ERF>{});
+        else body16(std::integral_constant<int, VITG_ACT_NONE>{});
         const int n_out = MODE == MODE_SWIGLU ? n_base / 2 : n_base;
         const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
 #pragma unroll

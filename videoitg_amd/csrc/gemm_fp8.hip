@@ -18,6 +18,7 @@
 // of the 64-deep step in its registers 0-3 / 4-7, for A and B alike (see the fragment offsets below).
 // C/D layout is the shape's (same as 32x32x16): lane (token = l & 31, h = l >> 5) holds features 8 (r >> 2) + 4 h + (r & 3).
 #include "gemm_common.h"
+#include <type_traits>
 
 namespace vitg {
 
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
         const int n_base = MODE == MODE_SWIGLU ? (n0 + wc * (NT * 32)) / 2 : n0 + wc * (NT * 32);     // first OUTPUT column of this wave
         const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
         unsigned char* const ob = (unsigned char*)g.out;
+        auto mx_rows = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;           // chosen once per tile, not per accumulator quad (gemm_common.h: body32)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             unsigned sc2 = 0;
@@ -270,16 +273,17 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
                     const int n = n_base + nt * 32 + q4 * 8 + fh * 4;
                     f32x4 t;
                     if constexpr (MODE == MODE_SWIGLU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = silu_f(acc[0][mt][q4 * 4 + e]) * acc[NT - 1][mt][q4 * 4 + e];
+                        const f32x2 lo = silu_mul_f2(f32x2{acc[0][mt][q4 * 4], acc[0][mt][q4 * 4 + 1]}, f32x2{acc[NT - 1][mt][q4 * 4], acc[NT - 1][mt][q4 * 4 + 1]});
+                        const f32x2 hi = silu_mul_f2(f32x2{acc[0][mt][q4 * 4 + 2], acc[0][mt][q4 * 4 + 3]}, f32x2{acc[NT - 1][mt][q4 * 4 + 2], acc[NT - 1][mt][q4 * 4 + 3]});
+                        t = f32x4{lo[0], lo[1], hi[0], hi[1]};
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) t[e] = acc[nt][mt][q4 * 4 + e];
                         if (g.bias && n < g.N) t += *(const f32x4*)(g.bias + n);
-                        if (g.act == VITG_ACT_GELU_TANH) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t[e] = gelu_tanh_f(t[e]);
-                        } else if (g.act == VITG_ACT_GELU_ERF) {
+                        if constexpr (ACT == VITG_ACT_GELU_TANH) {
+                            const f32x2 lo = gelu_tanh_f2(f32x2{t[0], t[1]}), hi = gelu_tanh_f2(f32x2{t[2], t[3]});
+                            t = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                        } else if constexpr (ACT == VITG_ACT_GELU_ERF) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) t[e] = gelu_erf_f(t[e]);
                         }
@@ -312,6 +316,10 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
                 else *sp = (unsigned char)sc2;
             }
         }
+        };   // mx_rows
+        if (MODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_TANH) mx_rows(std::integral_constant<int, VITG_ACT_GELU_TANH>{});
+        else if (MODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) mx_rows(std::integral_constant<int, VITG_ACT_GELU_ERF>{});
+        else mx_rows(std::integral_constant<int, VITG_ACT_NONE>{});
         // the same wave reads back what it wrote (LDS ops of one wave complete in order): 16-B chunks
 #pragma unroll
         for (int i = 0; i < MT * 32 * (RB / 16) / 64; ++i) {
