@@ -151,6 +151,7 @@ def planted_block(eng, cfg, T, R, prompt_len, seed, dtype, dev):
     forward of `eng` against its complete-pass oracle fixture (tests/golden/full_*p_*.json).  Unlike the plain workload - random-init scores
     crowd together, rank-32/33 gap 1.5e-3 - the oracle's Top-32 here is the planted set behind a wide gap, so "does this precision tier
     select the same frames" has a decidable answer (SURVEY.md section 7 hard part 2 iii).  None when no fixture matches."""
+    from videoitg_amd import ops, synth
     gdir = os.path.join(ROOT, "tests", "golden")
     for fn in sorted(os.listdir(gdir)) if os.path.isdir(gdir) else []:
         if not (fn.startswith("full_") and fn.endswith(".json")):
