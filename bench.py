@@ -112,6 +112,34 @@ def executed_gemm_flops(cfg, T, R, n_text, skip_dead_rows=True):
     return fl["gemm"] - skipped
 
 
+def layer_gemm_flops_by_name(cfg, T, R, n_text, skip_dead_rows=True):
+    """executed FLOPs of the eight layer GEMMs (videoitg_amd.engine.FP8_GEMMS) of one video: what an fp8 POLICY that covers only some of them
+    has to be priced on.  Sums to executed_gemm_flops - patch embedding - projector."""
+    fl = algorithmic_flops(cfg, T, R, n_text)
+    v = cfg.vision
+    G = R // v.patch_size
+    P = G * G
+    Dv, Fv, Lv = v.hidden_size, v.intermediate_size, cfg.num_vit_layers_needed()
+    D, Fl, Ll = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    kvw = cfg.num_key_value_heads * cfg.head_dim
+    N = fl["N"]
+    Pc = P
+    if skip_dead_rows and fl["hw"] < G:
+        sc = G / fl["hw"]
+        rows = set()
+        for o in range(fl["hw"]):
+            i0 = int(max((o + 0.5) * sc - 0.5, 0.0))
+            rows.update((i0, min(i0 + 1, G - 1)))
+        Pc = len(rows) ** 2
+    full, last = T * (Lv - 1) * 2.0 * P, T * 2.0                      # (rows x 2) of the Lv-1 complete layers / per-row factor of the last needed layer
+    return {"vit.qkv": full * 3 * Dv * Dv + last * (P * 2 * Dv * Dv + Pc * Dv * Dv),
+            "vit.out": full * Dv * Dv + last * Pc * Dv * Dv,
+            "vit.fc1": full * Dv * Fv + last * Pc * Dv * Fv,
+            "vit.fc2": full * Dv * Fv + last * Pc * Dv * Fv,
+            "llm.qkv": Ll * 2.0 * N * D * (D + 2 * kvw), "llm.o": Ll * 2.0 * N * D * D,
+            "llm.gu": Ll * 2.0 * N * 2 * D * Fl, "llm.down": Ll * 2.0 * N * D * Fl}
+
+
 def parity_block(T, R, prompt_len, seed, logits, order, tol=1e-3):
     """Compare this run's logits with the committed complete-pass ORACLE fixture for exactly this workload
     (tests/golden/full_*.json: data only - fp32 oracle logits computed in the build container on the same counter-generated
@@ -512,11 +540,13 @@ def main():
         if args.fp8:
             # the job itself ran on the fp8 weight path: the dominant kernel is gemm_fp8_kernel, priced against the dense fp8 peak
             n8, ms8 = timer8.summary()
-            layer_gemm = (executed_gemm_flops(cfg, T, R, ids.shape[1] - 1, eng.skip_dead_rows) - fl["patch"] - fl["proj"]) / world
+            by_name = layer_gemm_flops_by_name(cfg, T, R, ids.shape[1] - 1, eng.skip_dead_rows)
+            on8 = [k for k in by_name if eng.w.fp8_on(k)]                   # the GEMMs this policy runs on the fp8 kernel
+            layer_gemm = sum(by_name[k] for k in on8) / world
             ach8 = layer_gemm * args.steps / max(ms8 * 1e-3, 1e-9) / 1e12
             out["dtype"] = (f"fp8 policy '{args.fp8_policy}' (e4m3 weights per output channel + e4m3 activations into those layer GEMMs; "
                             f"{args.dtype} elsewhere)")
-            out["roofline"] = {"kernel": "gemm_fp8_kernel (layer GEMMs of the step)", "bound": "mfma", "achieved": round(ach8, 1), "peak": 5000.0,
+            out["roofline"] = {"kernel": "gemm_fp8_kernel (the layer GEMMs this policy runs on e4m3)", "gemms": on8, "bound": "mfma", "achieved": round(ach8, 1), "peak": 5000.0,
                                "unit": "TFLOP/s", "frac": round(ach8 / 5000.0, 4), "traffic": None, "launches": n8,
                                "avg_launch_ms": round(ms8 / max(n8, 1), 4), "gemm_share_of_step": round(ms8 / (dt * 1e3), 3)}
         if world == 1:
