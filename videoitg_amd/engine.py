@@ -52,9 +52,6 @@ class Fp8Weight:
         return Fp8Weight(self.w8[rows], self.sw[rows])
 
 
-_EXP_NOBIAS = os.environ.get("VITG_EXP_NOBIAS", "0") not in ("", "0")      # TIMING EXPERIMENT ONLY (wrong results): residual GEMMs of the tower without their bias
-
-
 def _fuse_norm_enabled() -> bool:
     from . import _lib as _l
     return _l.PROFILING and os.environ.get("VITG_FUSE_NORM", "0") not in ("", "0")
@@ -463,7 +460,7 @@ class SelectorEngine:
         def update(a, wt, bias, xs):
             """xs += a @ wt.T + bias  (16-bit stream: one rounding per update, fp32 accumulation inside the epilogue)"""
             if r16:
-                K.gemm_res16(a, wt, xs, bias=None if _EXP_NOBIAS else bias, res16=xs)
+                K.gemm_res16(a, wt, xs, bias=bias, res16=xs)
             else:
                 self._gemm(a, wt, xs, mode=K.GEMM_F32, bias=bias, res=xs)
 
