@@ -47,10 +47,12 @@ def test_gemm_fragment_packed_weights_store16_bit_identical(ops, dtype, M, N, K)
     a, w, b = rnd((M, K), 1, dtype=dtype).to(dtype).cuda(), rnd((N, K), 2, K ** -0.5, dtype=dtype).to(dtype).cuda(), rnd((N,), 3, 0.1, torch.float32).cuda()
     wf = ops.pack_weight_fragments(w)
     ops.set_option("gemm_cfg", 6)                                               # the kernel with the same k-order and wave tile
+    ops.set_option("gemm_mi", 32)                                               # (its 32x32x16 form: the 16x16x32 one starts its accumulators at the bias)
     try:
         ref = ops.gemm(a, w, torch.empty((M, N), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=ops.ACT_GELU_TANH)
     finally:
         ops.set_option("gemm_cfg", 0)
+        ops.set_option("gemm_mi", 0)
     got = ops.gemm(a, w, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=ops.ACT_GELU_TANH, wf=wf)
     assert torch.equal(got, ref)
     want = F.gelu(a.float() @ w.float().t() + b, approximate="tanh")
@@ -81,11 +83,13 @@ def test_gemm_persistent_deferred_epilogue_bit_identical(ops, dtype, M, N, K):
     outs = {}
     for cfg in (6, 13):
         ops.set_option("gemm_cfg", cfg)
+        ops.set_option("gemm_mi", 32)                                           # (cfg 6 in its 32x32x16 form, the one cfg 13 was derived from: bias added in the epilogue)
         try:
             outs[cfg] = [ops.gemm(a, w, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=act)
                          for act in (ops.ACT_NONE, ops.ACT_GELU_TANH, ops.ACT_GELU_ERF)]
         finally:
             ops.set_option("gemm_cfg", 0)
+            ops.set_option("gemm_mi", 0)
     for got, ref in zip(outs[13], outs[6]):
         assert torch.isfinite(got.float()).all()
         assert torch.equal(got, ref)
