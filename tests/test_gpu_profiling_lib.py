@@ -191,7 +191,7 @@ def test_fused_norm_consumer_rmsnorm_swiglu(ops, dtype):
 
 
 @pytest.mark.parametrize("name", ["depth16_224", "c1_64x384"])
-def test_fused_norm_forward_matches_unfused_and_oracle(golden_dir, name):
+def test_fused_norm_forward_matches_unfused_and_oracle(golden_dir, name, monkeypatch):
     """LayerNorm / RMSNorm folded into the neighbouring GEMMs (engine.fuse_norm) at full depth and width: same scores as the
     stand-alone-norm path to well inside the tolerance, and the 1e-3 gate against the complete oracle pass still holds (fp16)."""
     from videoitg_amd import synth
@@ -204,7 +204,9 @@ def test_fused_norm_forward_matches_unfused_and_oracle(golden_dir, name):
         pytest.skip("fixture not generated")
     rec = json.load(open(path))
     cfg = ITGConfig()
+    monkeypatch.setenv("VITG_FUSE_NORM", "1")            # the load-time constants of the fused consumers are only packed when the feature is on
     eng = SelectorEngine(packed_random_weights(cfg, torch.float16, "cuda:0", seed=rec["weight_seed"]))
+    assert eng.w.vit[0].qkv_cs is not None
     ids, pix = synth.workload_inputs(cfg, rec["frames"], rec["resolution"], rec["prompt_len"], rec["pixel_seed"])
     pix = pix.half().cuda()
     outs = {}
