@@ -494,9 +494,14 @@ extern "C" int vitg_layernorm16(const void* x, int ldx, const float* w, const fl
     if (D % 8 || ldo % 8 || ldx % 8) return VITG_ERR_ALIGN;
     if (ldo < D) return VITG_ERR_SHAPE;
     const int need = ceil_div(ldo, 512);
-    const long want = (M + 3) / 4;
-    const long cap = 16384;
-    dim3 blk(256), grid((unsigned)(want < cap ? want : cap));
+    // (VITG_LN16_CAP / VITG_LN16_BLOCK: A/B knobs for the grid cap and the block size; defaults measured, profiles/r03_residual16.md)
+    static const long cap_env = [] { const char* e = getenv("VITG_LN16_CAP"); return e ? atol(e) : 0L; }();
+    static const int blk_env = [] { const char* e = getenv("VITG_LN16_BLOCK"); return e ? atoi(e) : 0; }();
+    const int threads = (blk_env == 128 || blk_env == 512 || blk_env == 1024) ? blk_env : 256;
+    const int wpb = threads / 64;
+    const long want = (M + wpb - 1) / wpb;
+    const long cap = cap_env > 0 ? cap_env : 16384;
+    dim3 blk(threads), grid((unsigned)(want < cap ? want : cap));
     hipStream_t s = (hipStream_t)stream;
 #define LK(T, NV) do { if (want > cap) hipLaunchKernelGGL((ln16_kernel<T, NV, true>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); \
                         else hipLaunchKernelGGL((ln16_kernel<T, NV, false>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); } while (0)

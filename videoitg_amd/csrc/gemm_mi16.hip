@@ -21,6 +21,9 @@
 //     schedule of gemm256.hip, cfg 6).  16 MFMAs of 16x16x32 = 256 pipe cycles per interval, as 8 of 32x32x16 there.
 // Epilogues (bias, GELU tanh / erf, SwiGLU, fp32 residual preloaded into the accumulators, 16-bit or fp32 output) are restated for
 // the 16x16 accumulator layout: 32 rows at a time through a wave-private LDS window into full-row 16-B stores.
+// Late round 3 (profiles/r03_gemm_epilogue.md: 0.457 -> 0.50 of the MFMA roofline from this alone): every decision an epilogue needs - which
+// activation, bias or not, interior or edge tile, which residual pointers - is taken ONCE per tile and selects a straight-line copy of the
+// stage loop (lambda templates below); nothing is tested per accumulator quad.  16-bit-output GEMMs start their accumulators at the bias.
 #include "gemm_common.h"
 #include <type_traits>
 
