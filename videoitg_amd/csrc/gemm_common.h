@@ -152,8 +152,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                                                           // the 256x384 fp32 kernel went from 19 to 256 spills.)
         // the activation / bias tests are made once (two copies of the loop), not per accumulator quad: a run-time test in the quad loop is a
         // scalar branch per quad and cuts the tile into basic blocks the scheduler cannot overlap (profiles/r03_gemm_epilogue.md)
-        auto body32 = [&](auto plain_c) {
+        auto body32 = [&](auto plain_c, auto in_c) {
         constexpr bool PLAIN = decltype(plain_c)::value;      // no bias, no activation (the decoder's o / down projections)
+        constexpr bool IN = decltype(in_c)::value;            // this wave's tile lies inside M x N: no bounds predicates
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt) {
 #pragma unroll
@@ -184,7 +185,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                 const int row = idx / CH, c = idx % CH;
                 f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4));
                 const int m = m_base + (mt - MT0) * 32 + row, n = n_base + c * 4;
-                if (m < g.M && n < g.N) {
+                if (IN || (m < g.M && n < g.N)) {
                     if (g.res) {
                         const int rm = g.res_mod > 0 ? m % g.res_mod : m;
                         v += *(const f32x4*)(g.res + (size_t)rm * g.ldr + n);
@@ -200,7 +201,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
             }
         }
         };   // body32
-        if (g.bias == nullptr && g.act == VITG_ACT_NONE) body32(std::true_type{}); else body32(std::false_type{});
+        const bool in32 = m_base + MTN * 32 <= g.M && n_base + NT * 32 <= g.N;
+        if (g.bias == nullptr && g.act == VITG_ACT_NONE) { if (in32) body32(std::true_type{}, std::true_type{}); else body32(std::true_type{}, std::false_type{}); }
+        else body32(std::false_type{}, std::false_type{});
     } else {
         constexpr int NTO = MODE == MODE_SWIGLU ? 1 : NT;  // output 32-column tiles per wave
         constexpr int CH = NTO * 4;                        // 16-B chunks (8 halfs) per row
@@ -211,8 +214,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
         // bits ABOVE those.  (With the low bits, as round 1 had it, the 8-B staging writes of rows r, r + 8, r + 16, r + 24 met in the
         // same banks: 4-way conflicts on 48 writes per wave and tile; now 2-way, the minimum for 8-B writes at this row pitch.)
         constexpr int SH = CH == 4 ? 2 : CH == 8 ? 1 : 0;
-        auto body16 = [&](auto act_c) {
+        const int n_out = MODE == MODE_SWIGLU ? n_base / 2 : n_base;
+        const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
+        auto body16 = [&](auto act_c, auto in_c) {
         constexpr int ACT = decltype(act_c)::value;           // chosen once per tile (see body32)
+        constexpr bool IN = decltype(in_c)::value;            // this wave's tile lies inside M x N: no bounds predicates
 #pragma unroll
         for (int mt = MT0; mt < MT0 + MTN; ++mt)
 #pragma unroll
@@ -240,7 +246,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = nrs[mt - MT0] * (v[e] - nmu[mt - MT0] * sn[e]);
                         }
-                        if (g.bias && n < g.N) v += *(const f32x4*)(g.bias + n);
+                        if (g.bias && (IN || n < g.N)) v += *(const f32x4*)(g.bias + n);
                         if constexpr (ACT == VITG_ACT_GELU_TANH) {
                             const f32x2 lo = gelu_tanh_f2(f32x2{v[0], v[1]}), hi = gelu_tanh_f2(f32x2{v[2], v[3]});
                             v = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -255,31 +261,33 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                     const int row = (mt - MT0) * 32 + frow, c = nt * 4 + q4;
                     *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4) + fh * 8) = o;
                 }
-        };   // body16
-        if (MODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_TANH) body16(std::integral_constant<int, VITG_ACT_GELU_TANH>{});
-        else if (MODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) body16(std::integral_constant<int, VITG_ACT_GELU_ERF>{});
-        else body16(std::integral_constant<int, VITG_ACT_NONE>{});
-        const int n_out = MODE == MODE_SWIGLU ? n_base / 2 : n_base;
-        const int n_lim = MODE == MODE_SWIGLU ? g.N / 2 : g.N;
 #pragma unroll
         for (int i = 0; i < MTN * 32 * CH / 64; ++i) {
             const int idx = i * 64 + lane;
             const int row = idx / CH, c = idx % CH;
             const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4));
             const int m = m_base + row, n = n_out + c * 8;
-            if (m < g.M) {
+            if (IN || m < g.M) {
                 // wave-uniform tile origin (64-bit, scalar) + 32-bit byte offset: saddr stores, no 64-bit VALU per row.  The non-temporal
                 // variant (gemm_flags bit0, measured +-0) and the store-skipping ablation (bit1) exist only in a profiling build.
                 char* const ob = (char*)((T*)g.out + (size_t)m_base * g.ldo + n_out);
                 const unsigned boff = (unsigned)(row * g.ldo + c * 8) * 2u;
                 if (VITG_PROFILING_BUILD && (g.flags & 2)) continue;
-                if (n + 8 <= n_lim) {
+                if (IN || n + 8 <= n_lim) {
                     if (VITG_PROFILING_BUILD && (g.flags & 1)) __builtin_nontemporal_store(v, (u32x4*)(ob + boff));
                     else if (VITG_PROFILING_BUILD && (g.flags & 0xC00000)) store16_policy(ob, boff, v, (g.flags >> 22) & 3);
                     else *(u32x4*)(ob + boff) = v;
                 } else if (n + 4 <= n_lim) *(u32x2*)(ob + boff) = u32x2{v[0], v[1]};
             }
         }
+        };   // body16
+        const bool in16 = m_base + MTN * 32 <= g.M && n_base + NT * 32 <= g.N;
+        typedef std::integral_constant<int, VITG_ACT_GELU_TANH> AT_;
+        typedef std::integral_constant<int, VITG_ACT_NONE> AN_;
+        if (MODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_TANH) { if (in16) body16(AT_{}, std::true_type{}); else body16(AT_{}, std::false_type{}); }
+        else if (MODE != MODE_SWIGLU && g.act == VITG_ACT_GELU_ERF) body16(std::integral_constant<int, VITG_ACT_GELU_ERF>{}, std::false_type{});
+        else if (in16) body16(AN_{}, std::true_type{});
+        else body16(AN_{}, std::false_type{});
     }
 }
 

@@ -121,7 +121,8 @@ class PackedWeights:
                                                     # (profiles/r02_parity.md), so "tower bf16 + LLM fp16" is a supported mix
     vit_q_prescaled: bool = None                    # the q rows (and bias) of the tower's qkv projection carry head_dim^-0.5 * log2(e): the attention
                                                     # then exponentiates K Q^T as it leaves the matrix pipe (vitg_attention variant bit 1;
-                                                    # csrc/attention_ab.hip, QS).  One rounding of c * W instead of W - no extra rounding of Q.
+                                                    # csrc/attention_ab.hip, QS).  One rounding of c * W instead of W - no extra rounding of Q
+                                                    # (a checkpoint stored in 16 bits sees a second rounding of its q weights: 2^-12 relative).
                                                     # None = on unless VITG_Q_PRESCALE=0
     fp8: object = False                             # BASELINE.json configs[4]: tower / decoder GEMM weights as e4m3fn + per-channel scales;
                                                     # True = both parts, "vit" / "llm" = that part only (the other stays 16-bit)
