@@ -523,3 +523,58 @@ def test_gemm_streamk_plan_covers_the_per_rank_shapes(ops):
     assert 0 < b_o <= cus and 0 < b_d <= cus and ws_d == b_d * 2 * 65536 * 4
     assert ops.gemm_streamk_plan(12860, 3584, 18944)[0] == 0           # enough tiles for every CU: the plain GEMM
     assert ops.gemm_streamk_plan(1660, 3584, 1152)[0] == 0             # K too short to cut
+
+
+# ---- round 3, late: the epilogue forms of gemm_mi16.hip are selected once per tile; every form must give the same result ----------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [6, 9, 10], ids=["256x256", "256x384", "384x256"])
+@pytest.mark.parametrize("M", [66000, 1700], ids=["tile_loop", "one_tile_per_block"])
+def test_gemm_epilogue_forms_agree(ops, dtype, cfg, M):
+    """gemm_flags bits 27-30 switch the epilogue forms of the 16x16x32 kernels back to their earlier shape (profiles/r03_gemm_epilogue.md):
+    bit27 bias added in the epilogue instead of being the accumulators' start value, bit28 activation tested per accumulator quad + scalar
+    GELU / SiLU, bit29 no interior-tile forms, bit30 bias tested per quad.  Interior and edge tiles (M, N not multiples of the tile), the
+    tile loop (>= 2 tiles per CU) and the one-tile-per-block launch.  Bits 28-30 must be bit-identical to the default; bit27 moves one fp32
+    add, i.e. at most one 16-bit ulp."""
+    N, K = 1200, 1152                         # 4.7 / 3.1 column tiles: the last one is an edge tile
+    g = torch.Generator().manual_seed(77)
+    a = (torch.randn((M, K), generator=g) * 1.0).to(dtype).cuda()
+    w = (torch.randn((N, K), generator=g) * K ** -0.5).to(dtype).cuda()
+    gu = (torch.randn((2 * 1024, K), generator=g) * K ** -0.5).to(dtype).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    x16 = torch.randn((M, N), generator=g).to(dtype).cuda()
+    x32 = torch.randn((M, N), generator=g).cuda()
+
+    def run_all():
+        outs = []
+        for act in (ops.ACT_NONE, ops.ACT_GELU_TANH, ops.ACT_GELU_ERF):
+            outs.append(ops.gemm(a, w, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16, bias=b, act=act))
+        outs.append(ops.gemm(a, w, torch.full((M, N), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_STORE16))            # no bias
+        o = x16.clone()
+        outs.append(ops.gemm_res16(a, w, o, bias=b, res16=o))
+        o = x32.clone()
+        outs.append(ops.gemm(a, w, o, mode=ops.GEMM_F32, bias=b, res=o))
+        o = x32.clone()
+        outs.append(ops.gemm(a, w, o, mode=ops.GEMM_F32, res=o))
+        if cfg != 9:                                                                                                                  # (no 256x384 SwiGLU tile)
+            outs.append(ops.gemm(a, gu, torch.full((M, 1024), float("nan"), dtype=dtype, device="cuda"), mode=ops.GEMM_SWIGLU))
+        torch.cuda.synchronize()
+        return outs
+
+    ops.set_option("gemm_tile", 256); ops.set_option("gemm_cfg", cfg); ops.set_option("gemm_mi", 16)
+    try:
+        ref = run_all()
+        want = a.float() @ w.float().t() + b
+        assert (ref[0].float() - want).abs().max().item() <= EPS16[dtype] * want.abs().max().item() + 2e-4 * math.sqrt(K)
+        for bit in (27, 28, 29, 30):
+            ops.set_option("gemm_flags", 1 << bit)
+            got = run_all()
+            for i, (x, y) in enumerate(zip(got, ref)):
+                assert torch.isfinite(x.float()).all(), (bit, i)
+                if bit == 27 and i < 3:      # 16-bit output with a bias: the add sits at the other end of the fp32 sum
+                    d = (x.float() - y.float()).abs()
+                    assert (d <= 2 * EPS16[dtype] * y.float().abs() + 1e-6).all(), (bit, i, d.max().item())
+                else:
+                    assert torch.equal(x, y), (bit, i)
+    finally:
+        for k in ("gemm_flags", "gemm_tile", "gemm_cfg", "gemm_mi"):
+            ops.set_option(k, 0)
