@@ -79,8 +79,10 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float a = x * __builtin_fmaf(x * x, -0.10294324302f, -2.30220819814f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
-// two values at a time on the packed fp32 VALU forms (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: one issue per pair) - the same operations in the same
-// order as the scalar forms, so the results are bit-identical
+// two values at a time on the packed fp32 VALU forms (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) - the same operations in the same order as the
+// scalar forms, so the results are bit-identical.  (Half the instructions, NOT half the time: tools/ubench/valu_rate.hip measures 5.4 clocks per
+// v_pk_fma_f32 against 2.7 per v_fma_f32 on gfx950 - the same rate per value.  The gain of the epilogue rewrite came from taking the tests out of
+// the quad loop, profiles/r03_gemm_epilogue.md.)
 __device__ __forceinline__ f32x2 gelu_tanh_f2(f32x2 x) {
     const f32x2 ca = {-0.10294324302f, -0.10294324302f}, cb = {-2.30220819814f, -2.30220819814f}, one = {1.0f, 1.0f};
     const f32x2 a = x * __builtin_elementwise_fma(x * x, ca, cb);
