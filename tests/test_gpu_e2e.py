@@ -14,7 +14,7 @@ CASES = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ra
 SCORE_TOL = 1e-3
 
 
-def run_case(golden_dir, name, dtype, variant=0):
+def run_case(golden_dir, name, dtype, variant=0, q_prescaled=None):
     from videoitg_amd import synth
     from videoitg_amd.config import ITGConfig
     from videoitg_amd.engine import PackedWeights, SelectorEngine
@@ -24,7 +24,17 @@ def run_case(golden_dir, name, dtype, variant=0):
     T = z["T"].tolist()
     images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i) for i, t in enumerate(T)]
     sd, vsd = synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed)
-    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, dtype, "cuda:0"), attn_variant=variant)
+    if q_prescaled is None:
+        pw = PackedWeights.from_state_dicts(cfg, sd, vsd, dtype, "cuda:0")
+    else:                                                 # the tower's softmax scale folded into the q projection (default) or applied in the attention kernel
+        pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device("cuda:0"), vit_q_prescaled=q_prescaled)
+        pw.pack_vision_embeddings(vsd)
+        for i in range(cfg.num_vit_layers_needed()):
+            pw.pack_vision_layer(vsd, i)
+        pw.pack_projector_and_head(sd)
+        for i in range(cfg.num_hidden_layers):
+            pw.pack_llm_layer(sd, i)
+    eng = SelectorEngine(pw, attn_variant=variant)
     ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
     got = eng.forward(ids, mask, [im.cuda() for im in images])
     torch.cuda.synchronize()
@@ -73,6 +83,23 @@ def test_topk_index_sets_match_reference(golden_dir, name):
                 assert set(order[:k].tolist()) == set(oref[:k].tolist()), (name, b, k)
                 checked += 1
     assert checked >= 2
+
+
+@pytest.mark.parametrize("name", ["pool_post", "oddgrid", "two_images"])
+def test_q_prescale_on_and_off_both_match_the_reference(golden_dir, name):
+    """PackedWeights.vit_q_prescaled: head_dim^-0.5 * log2(e) in the q rows of the tower's qkv weights + vitg_attention variant bit 1 (scores leave the
+    matrix pipe ready for exp2) against the scale applied inside the attention kernel: each inside the golden tolerance on its own, and within two
+    16-bit roundings of each other"""
+    tol = GOLDEN_TOL[torch.float16].get(name, SCORE_TOL)
+    outs = {}
+    for qp in (True, False):
+        z, got, T = run_case(golden_dir, name, torch.float16, q_prescaled=qp)
+        for b in range(len(got)):
+            ref = torch.from_numpy(z[f"logits{b}"])
+            assert (torch.sigmoid(got[b]) - torch.sigmoid(ref)).abs().max().item() <= tol, (qp, name, b)
+        outs[qp] = got
+    for x, y in zip(outs[True], outs[False]):
+        assert (torch.sigmoid(x) - torch.sigmoid(y)).abs().max().item() <= 2 * tol
 
 
 @pytest.mark.parametrize("name", ["pool_post", "oddgrid"])

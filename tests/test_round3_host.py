@@ -80,3 +80,30 @@ def test_planted_inputs_are_a_brightness_step_on_the_seeded_frames():
     rec.pop("plant")
     a, b = synth.fixture_inputs(cfg, rec)
     assert torch.equal(b, pix0)
+
+
+def test_q_prescale_touches_only_the_q_rows_of_the_tower():
+    """PackedWeights.vit_q_prescaled folds head_dim^-0.5 * log2(e) into the q rows and the q bias of every tower layer, in fp32 before the one
+    rounding to 16 bits; k / v rows, the other GEMMs and the decoder are untouched"""
+    import math
+    import torch
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import PackedWeights
+    cfg = tiny_config()
+    vsd = synth.synth_vision_state_dict(cfg, 0)
+    packs = {}
+    for qp in (True, False):
+        pw = PackedWeights(cfg=cfg, dtype=torch.float16, device=torch.device("cpu"), vit_q_prescaled=qp)
+        pw.pack_vision_layer(vsd, 0)
+        packs[qp] = pw.vit[0]
+    Dv = cfg.vision.hidden_size
+    c = cfg.vision.head_dim ** -0.5 * math.log2(math.e)
+    p = "vision_model.encoder.layers.0.self_attn."
+    want_q = (vsd[p + "q_proj.weight"].float() * c).half()
+    assert torch.equal(packs[True].qkv_w[:Dv, :Dv], want_q)
+    assert torch.equal(packs[False].qkv_w[:Dv, :Dv], vsd[p + "q_proj.weight"].half())
+    assert torch.equal(packs[True].qkv_w[Dv:], packs[False].qkv_w[Dv:])
+    assert torch.allclose(packs[True].qkv_b[:Dv], vsd[p + "q_proj.bias"].float() * c) and torch.equal(packs[True].qkv_b[Dv:], packs[False].qkv_b[Dv:])
+    for n in ("out_w", "fc1_w", "fc2_w", "out_b", "fc1_b", "fc2_b"):
+        assert torch.equal(getattr(packs[True], n), getattr(packs[False], n))
