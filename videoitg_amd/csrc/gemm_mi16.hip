@@ -346,7 +346,24 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         const int n_lim = EMODE == MODE_SWIGLU ? g.N / 2 : g.N;
         // the activation is selected ONCE per tile (three copies of the stage loop), not per accumulator quad: a run-time test inside the quad loop
         // is a scalar branch per quad - 48-72 per tile - and cuts the stage into basic blocks the scheduler cannot overlap
-        const bool has_bias = EMODE != MODE_SWIGLU && g.bias != nullptr && !(MODE == MODE_STORE16 && bias_init);      // a bias is still to be added here
+        // 16-bit-residual form: the bias joins the accumulators in ONE pass here, behind the main loop (NT quad loads, then register adds), instead of a
+        // 16-B load per accumulator quad inside the stages (the stores between the stages keep the compiler from reusing them): step 669.2 -> 666.7 ms
+        // (+0.4 %, bit-identical; gpurun_out/r03_c42).  gemm_flags bit26 = per quad (A/B)
+        bool res_bias_done = false;
+        if constexpr (RES16) {
+            if (g.bias != nullptr && !(g.flags & 0x4000000)) {   // (A/B: gemm_flags bit26 = per quad in the stages)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int nb = nw + nt * 16 + fq * 4;
+                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                    if (nb < g.N) b4 = *(const f32x4*)(g.bias + nb);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] += b4;
+                }
+                res_bias_done = true;
+            }
+        }
+        const bool has_bias = EMODE != MODE_SWIGLU && g.bias != nullptr && !(MODE == MODE_STORE16 && bias_init) && !res_bias_done;      // a bias is still to be added here
         auto stages = [&](auto act_c, auto in_c, auto bias_c) {
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool IN = decltype(in_c)::value;           // interior tile: no bounds predicates
