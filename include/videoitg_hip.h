@@ -52,7 +52,9 @@ int vitg_device_info(char* name, int name_len);
  *               (gemm256.hip);  gemm_mi_modes  bit mask of epilogue modes on the 16x16x32 kernels (A/B);  gemm_pref  forced tile shape per mode (A/B)
  *   gemm_wm4    wave grid of the 384x256 tile on the 16x16x32 kernels: bit mask of epilogue modes (1 16-bit output, 2 fp32 residual, 4 SwiGLU, 8 16-bit
  *               residual) that run 4 x 2 waves (96 x 128 wave tiles) instead of 2 x 4 (192 x 64); -1 none; 0 the library default
- *   gemm_flags  bit8 wide tiles off, bits 11-14 cost-model A/B switches, bit24 one hardware block per tile instead of one block per CU walking the tile list (the default for long tile lists)
+ *   gemm_flags  bits 26-30: epilogue-form A/B switches of the 16x16x32 kernels (26 residual-form bias per quad, 27 bias in the epilogue instead of as the
+ *               accumulators' start value, 28 activation tested per quad + scalar GELU / SiLU, 29 no interior-tile forms, 30 bias tested per quad:
+ *               same results, profiles/r03_gemm_epilogue.md);  bit8 wide tiles off, bits 11-14 cost-model A/B switches, bit24 one hardware block per tile instead of one block per CU walking the tile list (the default for long tile lists)
  *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
  *   attn_ab     1 | 2  half-tile-out-of-phase hd-72 kernel on / off (default on; PV on v_mfma_f32_16x16x32, five 16-row d-tiles);  3 = 16 waves per block;
  *               4 = its round-2 form with PV on v_mfma_f32_32x32x16 (head dim padded to 96; A/B and cross-check);  5 = PV on 16x16x32 with the softmax row
