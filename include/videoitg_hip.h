@@ -58,7 +58,8 @@ int vitg_device_info(char* name, int name_len);
  *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
  *   attn_ab     1 | 2  half-tile-out-of-phase hd-72 kernel on / off (default on; PV on v_mfma_f32_16x16x32, five 16-row d-tiles);  3 = 16 waves per block;
  *               4 = its round-2 form with PV on v_mfma_f32_32x32x16 (head dim padded to 96; A/B and cross-check);  5 = PV on 16x16x32 with the softmax row
- *               sums on the VALU (the default forms them on the matrix pipe: a constant [1, 0, ..] pad chunk in every V row)
+ *               sums on the VALU (the default forms them on the matrix pipe: a constant [1, 0, ..] pad chunk in every V row);  6 = with pre-scaled Q
+ *               (vitg_attention variant bit 1) keep the multiply and the max subtraction on the VALU instead of taking the scores from the matrix pipe
  *   attn_sp     1 | 2  software-pipelined kernel on (both head sizes) / off (default: on for hd 128);  3 = hd 128 with PV on v_mfma_f32_16x16x32
  *               (measured 3-4 % slower than the default form; A/B and cross-check)
  * The research configurations of round 1 (gemm_cfg 1/3/4/5/7/8/11/13, fragment-packed weights, the ablation switches that produce

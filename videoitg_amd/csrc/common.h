@@ -130,7 +130,7 @@ struct Tuning {
     int attn_waves;    // 0 auto | 4 | 8
     int attn_pipe;     // 0 off (default) | 1 cross-tile pipelined hd-72 variant
     int attn_dma;      // 0 auto (DMA for hd 72, registers for hd 128) | 1 LDS-DMA K/V staging | 2 register staging
-    int attn_ab;       // hd 72: 0 auto | 1 half-tile-out-of-phase kernel (attention_ab.hip) | 2 off | 3 the same kernel with 16 waves / 512 queries per block | 4 its PV-on-32x32x16 form | 5 PV on 16x16x32 with VALU row sums
+    int attn_ab;       // hd 72: 0 auto | 1 half-tile-out-of-phase kernel (attention_ab.hip) | 2 off | 3 the same kernel with 16 waves / 512 queries per block | 4 its PV-on-32x32x16 form | 5 PV on 16x16x32 with VALU row sums | 6 pre-scaled Q without the shift column (A/B)
     int attn_sp;       // 0 auto | 1 software-pipelined kernel (attention_sp.hip) | 2 per-tile kernel (attention.hip) | 3 hd 128: software-pipelined with PV on 16x16x32 (opt-in, slower)
     int gemm_wm4;      // 384x256 tile of gemm_mi16.hip as a 4 x 2 wave grid (96 x 128 wave tiles): 0 library default | -1 never | bit mask of epilogue modes (1 16-bit output, 2 fp32 residual, 4 SwiGLU, 8 16-bit residual)
 };
