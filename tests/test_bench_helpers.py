@@ -45,3 +45,25 @@ def test_parity_block_against_the_committed_fixture():
     assert not bench.parity_block(512, 448, 60, 0, off, rec["order"])["pass"]
     assert bench.parity_block(512, 448, 60, 0, off, rec["order"], tol=0.15)["pass"]
     assert bench.parity_block(100, 448, 60, 0, lg[:100], list(range(100))) is None      # no fixture for this workload
+    # a looser precision tier (fp8) never passes on its score bound alone: losing the oracle's top frame / Top-32 set is reported and fails it
+    wrong = rec["order"][40:] + rec["order"][:40]
+    blk = bench.parity_block(512, 448, 60, 0, off, wrong, tol=0.15)
+    assert blk["within_score_tolerance"] and not blk["selects_same_frames"] and not blk["top1_kept"] and not blk["pass"]
+
+
+def test_plain_gpus_n_command_becomes_its_own_launcher(monkeypatch):
+    """`python bench.py --gpus 8` with no launcher around it (WORLD_SIZE unset) must start its ranks itself: it re-executes its own command
+    line under torch's elastic launcher, one process per GPU, rendezvous on 127.0.0.1 (the reference's counterpart is
+    `accelerate launch --num_processes=8`, scripts/eval_lmms_eval/videomme_grounding.sh:3-5)."""
+    seen = {}
+    monkeypatch.setattr(bench.os, "execv", lambda exe, cmd: seen.update(exe=exe, cmd=cmd))
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()                                                       # returns right after the (mocked) exec: no GPU is touched
+    cmd = seen["cmd"]
+    assert seen["exe"] == bench.sys.executable and cmd[:3] == [bench.sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]

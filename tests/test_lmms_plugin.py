@@ -101,3 +101,30 @@ def test_generate_until_writes_reference_jsonl(tmp_path):
         for a in range(len(want_idx) - 1):
             if (scores[a] - scores[a + 1]).item() > 2e-3:
                 assert o["index"].index(want_idx[a]) < o["index"].index(want_idx[a + 1])
+
+
+@pytest.mark.gpu
+def test_multi_visual_document_goes_through_as_the_reference_does_it(tmp_path):
+    """A document with several visuals: the reference encodes every one and passes the whole list as `images`
+    (/root/reference/lmms_eval/models/videoitg.py:276-300); with one `<image>` in the prompt the model scores images[0], the frame ids and
+    `video_path` come from the LAST visual, `num_frames` is the number of visuals (videoitg.py:312-315)."""
+    from PIL import Image
+    from videoitg_amd.lmms_plugin.models.videoitg import VideoITG
+    from videoitg_amd.mm_utils import get_seq_frames
+
+    def fake_loader(path, num_frames, target_fps):
+        idx = get_seq_frames(900 + 30 * len(path), 30.0, target_fps, num_frames)   # different sampled ids per "video"
+        rng = np.random.default_rng(len(path))
+        return [Image.fromarray(rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)) for _ in idx], idx
+
+    lm = VideoITG(pretrained="synthetic:tiny:0", device="cuda:0", num_frames=8, output_dir=str(tmp_path), video_loader=fake_loader)
+    lm.task_dict = {"t": {"test": {0: {"v": ["a.mp4", "bb.mp4"]}}}}
+    res = lm.generate_until([types.SimpleNamespace(args=("which frame?", {}, lambda d: [d["v"]], 0, "t", "test"))])[0]
+    first_only = lm.score("which frame?", ["a.mp4"])
+    ids_last = fake_loader("bb.mp4", 8, 1)[1]
+    ids_first = fake_loader("a.mp4", 8, 1)[1]
+    assert ids_last != ids_first
+    assert res["num_frames"] == 2 and res["video_path"] == "bb.mp4"
+    assert res["logits"] == first_only[1]                                             # the scores of images[0] ...
+    pos = [ids_first.index(i) for i in first_only[0]]
+    assert res["index"] == [ids_last[p] for p in pos]                                 # ... mapped through the LAST video's sampled ids

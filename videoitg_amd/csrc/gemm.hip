@@ -268,8 +268,11 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
 #endif
     // 16-bit output + residual (vitg_gemm_res16): the 256-wide tiles of gemm_mi16.hip, or - where auto mode would take the 256x128
     // tile or the shape is small / unaligned - the 128-tile kernel; gemm256.hip's own epilogues do not carry these forms
-    if (mode == VITG_GEMM_STORE16 && (res || res16) &&
-        !(force != 128 && gemm256_applicable(g, mode) && (ldr16 % 4 == 0) && gemm256_pick_cfg(g, mode) != 2 && N >= 256))
+    // (only the three tile configurations that exist in gemm_mi16.hip - 6 / 9 / 10, with the shape conditions launch256_m puts on
+    // 9 and 10 - carry the residual forms; any other forced gemm_cfg must NOT reach gemm256.hip's own epilogue, which would drop the residual)
+    const int cfg16 = (mode == VITG_GEMM_STORE16 && (res || res16) && force != 128 && gemm256_applicable(g, mode)) ? gemm256_pick_cfg(g, mode) : 0;
+    const bool res16_on_mi16 = (cfg16 == 6 || (cfg16 == 9 && N >= 384) || (cfg16 == 10 && M >= 384)) && (ldr16 % 4 == 0) && N >= 256;
+    if (mode == VITG_GEMM_STORE16 && (res || res16) && !res16_on_mi16)
         rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     else
     if (force != 128 && gemm256_applicable(g, mode)) rc = launch_gemm256(g, dtype, mode, s);

@@ -287,6 +287,7 @@ class SelectorEngine:
         # Default since the gate held on every complete-pass fixture (max |dscore| 3.1e-4 against 1.5e-4 on the fp32 stream, Top-K sets
         # identical, step -2.8 %: profiles/r03_residual16.md); VITG_RES16=0 / engine.residual16 = False restores the fp32 stream.
         self.residual16 = os.environ.get("VITG_RES16", "1") not in ("", "0")
+        self.vit_stream_bytes = 4                        # element size of the tower's residual stream in the LAST vit_forward (2 when the 16-bit stream ran)
         # LayerNorm / RMSNorm folded into the GEMMs around them (vitg_gemm_norm_*).  Measured 4 % SLOWER on the step than the stand-alone
         # norm kernels (profiles/r02_fused_norm.md), so the kernels live in the profiling library and this switch only exists there.
         # (never together with fp8 layer weights - the fused consumers only exist for 16-bit operands)
@@ -446,7 +447,9 @@ class SelectorEngine:
         a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.vdtype)
         eps, vdt = v.layer_norm_eps, self.vdtype
         # (fp16 only: a bf16 stream would carry 8 mantissa bits through 26 layers; never together with fp8 tower GEMMs or the fused norm)
-        r16 = self.residual16 and vdt == torch.float16 and not w.fp8_part("vit") and not self.fuse_norm and Dv % 8 == 0
+        # (and only when the projector runs in the same type: vitg_bilinear_pool16 writes the pooled rows in the tower's type - ADVICE r3)
+        r16 = self.residual16 and vdt == torch.float16 and self.dtype == vdt and not w.fp8_part("vit") and not self.fuse_norm and Dv % 8 == 0
+        self.vit_stream_bytes = 2 if r16 else 4          # what this call's residual stream really was (bench.py prices LayerNorm / pool on it)
         x = self._buf("vit_x16" if r16 else "vit_x", (M, Dv), vdt if r16 else torch.float32)
         src = self.pool_sources(G, hw) if (hw is not None and self.skip_dead_rows and len(w.vit) > 0) else None
         full_layers = w.vit if src is None else w.vit[:-1]

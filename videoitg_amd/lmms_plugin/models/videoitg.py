@@ -125,21 +125,34 @@ class VideoITG(_Base):
             out.extend(i) if isinstance(i, (list, tuple)) else out.append(i)
         return out
 
-    def score(self, contexts: str, visual):
-        """One document: -> (frame ids in descending score order, scores rounded to 2 dp, #visuals)."""
+    def score(self, contexts: str, visuals):
+        """One document: -> (frame ids in descending score order, scores rounded to 2 dp, #visuals).
+
+        Every visual of the document is encoded and the whole list is handed to the model as `images`, exactly as
+        /root/reference/lmms_eval/models/videoitg.py:276-301 does.  The prompt holds ONE `<image>`, so the model scores
+        `images[0]` (eagle_archv1.py consumes one entry per `<image>`; grounding_qwen2.py:153 reshapes by `images[0].shape[0]`),
+        while the frame ids come from the LAST video loaded (the reference's `sampled_frames` is the loop variable that survives
+        the loop).  For the one-video documents of every real task the two coincide; for a multi-visual document this reproduces
+        the reference's result, including its IndexError when the first visual has more frames than the last video sampled."""
         from PIL import Image
         from ...torch_ops import K as ops
-        if isinstance(visual, Image.Image):
-            frames, sampled = [visual], [0]
-        else:
-            frames, sampled = self._video_loader(visual, self.num_frames, self.target_fps)
-        pix = self.image_processor.preprocess(frames, return_tensors="pt")["pixel_values"].half().to(self.device)
+        if not isinstance(visuals, (list, tuple)):
+            visuals = [visuals]
+        videos, sampled = [], None
+        for visual in visuals:
+            if isinstance(visual, Image.Image):
+                frames = [visual]
+                if sampled is None:
+                    sampled = [0]                       # (the reference has no frame list for a bare image: a one-image document maps to id 0)
+            else:
+                frames, sampled = self._video_loader(visual, self.num_frames, self.target_fps)
+            videos.append(self.image_processor.preprocess(frames, return_tensors="pt")["pixel_values"].half().to(self.device))
         prompt = DEFAULT_IMAGE_TOKEN + contexts + "\n"                                    # videoitg.py:289
         ids = [tokenizer_image_token(prompt, self.tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt")]
         pad_id = self.tokenizer.pad_token_id if self.tokenizer.pad_token_id is not None else self.tokenizer.eos_token_id
         ids = pad_sequence(self.tokenizer, ids, batch_first=True, padding_value=pad_id).to(self.device)
         with torch.inference_mode():
-            resp = self.model(ids, attention_mask=ids.ne(pad_id), images=[pix])
+            resp = self.model(ids, attention_mask=ids.ne(pad_id), images=videos)
             scores, order = ops.rank(resp.logits[0].view(-1).float())
         order = order.cpu().tolist()
         # the reference's model is .half(): its logit leaves out_proj as fp16 and the sigmoid is evaluated on that fp16 value and rounded to
@@ -147,7 +160,7 @@ class VideoITG(_Base):
         # stays the stable fp32 one (ties of the fp16 scores are broken by the fp32 score, then by frame position).
         lg16 = resp.logits[0].view(-1).float().cpu().half()
         s16 = torch.sigmoid(lg16.float()).half().float()[order].tolist()
-        return [int(sampled[i]) for i in order], [round(v, 2) for v in s16], 1
+        return [int(sampled[i]) for i in order], [round(v, 2) for v in s16], len(videos)
 
     def generate_until(self, requests) -> List[dict]:
         os.makedirs(self.output_dir, exist_ok=True)
@@ -155,9 +168,9 @@ class VideoITG(_Base):
         res = []
         for contexts, gen_kwargs, doc_to_visual, doc_id, task, split in [r.args for r in requests]:
             visuals = self.flatten([doc_to_visual(self.task_dict[task][split][doc_id])])
-            visual = visuals[-1]
-            index, logits, _ = self.score(contexts, visual)
-            out = {"index": index, "logits": logits, "num_frames": len(visuals), "contexts": contexts,
+            index, logits, n_vis = self.score(contexts, visuals)
+            visual = visuals[-1]                                         # videoitg.py:315: the loop variable after the loop
+            out = {"index": index, "logits": logits, "num_frames": n_vis, "contexts": contexts,
                    "video_path": visual if isinstance(visual, str) else None, "doc_id": doc_id}
             with open(path, "a", encoding="utf-8") as f:               # all ranks share one file: serialise the append
                 fcntl.flock(f, fcntl.LOCK_EX)

@@ -191,7 +191,8 @@ class EagleQwenG(nn.Module):
             images = list(images)
             single = len(images) == 1 and (input_ids.dim() == 1 or input_ids.shape[0] == 1) and \
                 (attention_mask is None or bool(attention_mask.all()))
-            if self.use_graphs and single and grounding_labels is None:
+            # (never in training mode: the captured forward pools with the eval rule and would not consume the reference's random-grid draws)
+            if self.use_graphs and single and grounding_labels is None and not self.training:
                 if self._graphs is None or self._graphs.eng is not eng:
                     from ..engine import GraphCache
                     self._graphs = GraphCache(eng)

@@ -79,7 +79,10 @@ class RowGatherer:
 
     def _ensure(self, c: int, dtype, device) -> None:
         p = self.plan
-        if self._recv is None or self._recv.shape[1] != c or self._recv.dtype != dtype or self._recv.device != torch.device(device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:           # an index-less "cuda" never equals a tensor's "cuda:0" (that
+            device = torch.device("cuda", torch.cuda.current_device())   # re-allocated the buffers and dropped the compaction index every layer)
+        if self._recv is None or self._recv.shape[1] != c or self._recv.dtype != dtype or self._recv.device != device:
             self._recv = torch.zeros((p.world * self.n_max, c), dtype=dtype, device=device)
             self._out = self._recv if self.even else torch.empty((p.total, c), dtype=dtype, device=device)
             self._idx = None
