@@ -119,7 +119,7 @@ def test_multi_visual_document_goes_through_as_the_reference_does_it(tmp_path):
 
     lm = VideoITG(pretrained="synthetic:tiny:0", device="cuda:0", num_frames=8, output_dir=str(tmp_path), video_loader=fake_loader)
     lm.task_dict = {"t": {"test": {0: {"v": ["a.mp4", "bb.mp4"]}}}}
-    res = lm.generate_until([types.SimpleNamespace(args=("which frame?", {}, lambda d: [d["v"]], 0, "t", "test"))])[0]
+    res = lm.generate_until([types.SimpleNamespace(args=("which frame?", {}, lambda d: d["v"], 0, "t", "test"))])[0]   # doc_to_visual -> list of visuals
     first_only = lm.score("which frame?", ["a.mp4"])
     ids_last = fake_loader("bb.mp4", 8, 1)[1]
     ids_first = fake_loader("a.mp4", 8, 1)[1]
