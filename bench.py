@@ -448,7 +448,9 @@ def main():
     ops.gemm = timer.wrap(ops.gemm)
     ops.gemm_splitk = timer.wrap(ops.gemm_splitk)       # (the o / down projections of a context-parallel rank; includes their reduce kernel)
     ops.gemm_streamk = timer.wrap(ops.gemm_streamk)     # (the same projections on the stream-K partition; includes the reduce kernel)
-    ops.gemm_res16 = timer.wrap(ops.gemm_res16)         # (patch embedding, out-proj and fc2 of the tower on its 16-bit residual stream)
+    ops.gemm_res16 = timer.wrap(ops.gemm_res16)         # (out-proj and fc2 of the tower on its 16-bit residual stream; the patch embedding when not fused)
+    t_pe = GemmTimer()                                  # the patch-embed GEMM with the im2col inside its operand loader: one of the step's GEMM launches
+    ops.patch_embed16 = t_pe.wrap(timer.wrap(ops.patch_embed16))     # (`timer` in the timed region, `t_pe` in the side pass)
     timer8 = GemmTimer()                                # --fp8: the layer GEMMs run here; patch-embed / projector stay on ops.gemm
     if args.fp8:
         ops.gemm_fp8 = timer8.wrap(ops.gemm_fp8)
@@ -472,7 +474,7 @@ def main():
     ops.bilinear_pool16 = t_pool.wrap(ops.bilinear_pool16)
     if hasattr(ops, "layernorm16"):
         ops.layernorm16 = t_ln.wrap(ops.layernorm16)          # (tower on the 16-bit residual stream)
-    side_timers = [t_attn[72], t_attn[128], t_ln, t_rms, t_patch, t_rope, t_pool]      # `roofline_other`: timed in ONE extra step after the timed region
+    side_timers = [t_attn[72], t_attn[128], t_ln, t_rms, t_patch, t_rope, t_pool, t_pe]      # `roofline_other`: timed in ONE extra step after the timed region
 
     graphed = None
     if args.graph and cp is None:
@@ -628,6 +630,19 @@ def main():
             kp = eng.w.patch_w.shape[1]
             other["patchify"] = hbm_row(t_patch, T * 3 * R * R * es + T * P_ * kp * es,
                                         f"algorithmic: pixel_values read once ({es} B/px, NCHW) + the im2col operand written once ([T*P, {kp}] 16-bit)")
+            n_pe, ms_pe = t_pe.summary()
+            if n_pe:
+                # north_star's "patchify": since round 4 there is no patchify kernel in the step - the patch-embed GEMM's A-tile loader reads the
+                # 14 x 14 x 3 patches straight out of pixel_values (vitg_patch_embed16).  Priced both ways: as the GEMM it is, and on the bytes
+                # it HAS to move (pixels read once + the embedded rows written once; the 671 MB im2col operand is neither written nor read)
+                pe_flops = 2.0 * T * P_ * (3 * v.patch_size ** 2) * v.hidden_size
+                pe_bytes = T * 3 * R * R * es + T * P_ * v.hidden_size * es
+                other["patch_embed_fused"] = {"bound": "mfma", "achieved": round(pe_flops / (ms_pe * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": round(pe_flops / (ms_pe * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "launches": n_pe,
+                                              "avg_launch_ms": round(ms_pe / n_pe, 4), "share_of_step": round(ms_pe / (dt_side * 1e3), 5),
+                                              "hbm_gbs_on_algorithmic_bytes": round(pe_bytes / (ms_pe * 1e-3) / 1e9, 1),
+                                              "what": "im2col inside the GEMM's operand loader: no patchify kernel, no im2col operand in HBM "
+                                                      f"(K = {3 * v.patch_size ** 2} as {(3 * v.patch_size + 3) // 4} K-tiles of 64); algorithmic FLOPs"}
             nqk = cfg.num_attention_heads + cfg.num_key_value_heads
             other["rope"] = hbm_row(t_rope, cfg.num_hidden_layers * 2 * fl["N"] * nqk * cfg.head_dim * es,
                                     "algorithmic: q|k heads read + written in place, 16-bit (SURVEY 8d: 211 MB per layer); cos/sin tables from L2")

@@ -100,6 +100,18 @@ int vitg_gemm_res16(const void* A, int lda, const void* W, int ldw, int M, int N
                     int ldo, const void* res16, int ldr16, const float* res32, int ldr32, int res_mod, void* stream);
 int vitg_layernorm16(const void* x, int ldx, const float* w, const float* b, void* out, int ldo, int dtype, long M, int D, float eps,
                      void* stream);
+
+/* Patch embedding with the im2col INSIDE the GEMM's operand loader (round 4; north_star "coalesced ... patchify"): replaces the
+ * stride-p convolution + position-embedding add of [3P] SiglipVisionEmbeddings (reached from
+ * /root/reference/eagle/model/multimodal_encoder/clip_encoder.py:146) in ONE launch - no vitg_patchify pass, no im2col operand in HBM:
+ *   out16[(t, py, px), n] = round16( sum_{c,ky,kx} pix[t, c, p py + ky, p px + kx] W[n, c, ky, kx] + bias[n] + pos[(py, px), n] )
+ * pix: [T, 3, R, R] 16-bit NCHW (what the reference hands the tower, infer.py:55); rows/columns past p * (R / p) are ignored like the VALID
+ * convolution ignores them.  Wf: the convolution weight re-laid ONCE at load to [N, ldw >= 64 ceil(3 p / 4)] in (c, ky)-pair order -
+ * k = 16 (c p + ky) + slot; slot 0..7 = kx 0..7, slot 8..15 = kx p-8..p-1 with the slots of the re-read kx (p-8..7) zero; K-padding rows zero -
+ * so that every 16-byte operand chunk is 8 consecutive pixels of one image row.  pos: fp32 [P, ldp] or null; bias fp32 [N] or null.
+ * p even in 8..16, R even, N >= 256, T * 3 * R * R * 2 < 2^32; otherwise VITG_ERR_SHAPE (callers then use vitg_patchify + vitg_gemm_res16). */
+int vitg_patch_embed16(const void* pix, int T, int R, int patch, const void* Wf, int ldw, int N, int dtype, const float* bias, void* out,
+                       int ldo, const float* pos, int ldp, void* stream);
 int vitg_bilinear_pool16(const void* x, int ldx, void* out, int ldo, int T, int G, int HW, int D, int dtype, const int* cmap, int Pc,
                          void* stream);
 

@@ -578,3 +578,84 @@ def test_gemm_epilogue_forms_agree(ops, dtype, cfg, M):
     finally:
         for k in ("gemm_flags", "gemm_tile", "gemm_cfg", "gemm_mi"):
             ops.set_option(k, 0)
+
+
+# ---- round 4: patch embedding with the im2col inside the GEMM's A-tile loader (vitg_patch_embed16) ---------------------------------------
+def pair_layout(w: torch.Tensor) -> torch.Tensor:
+    """[N, 3, p, p] -> [N, 64 ceil(3p/4)] in the (c, ky)-pair layout of vitg_patch_embed16 (restated here, independent of the engine's packer)"""
+    n, _, p, _ = w.shape
+    out = torch.zeros((n, (3 * p + 3) // 4 * 4, 16), dtype=w.dtype)
+    rows = w.reshape(n, 3 * p, p)
+    for kx in range(p):
+        if kx < 8:
+            out[:, :3 * p, kx] = rows[:, :, kx]
+        else:
+            out[:, :3 * p, 8 + kx - (p - 8)] = rows[:, :, kx]      # slot 8 + j holds kx = p - 8 + j; the re-read kx p-8..7 keep a zero weight
+    return out.reshape(n, -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,R,N", [(3, 448, 1152), (2, 384, 1152), (5, 224, 1152), (1, 70, 272), (7, 56, 256), (2, 62, 400)])
+def test_patch_embed16_fused_loader(ops, dtype, T, R, N):
+    """vitg_patch_embed16 against (a) the stride-14 convolution + bias + position table in fp32 (the reference's own formulation, [3P]
+    SiglipVisionEmbeddings) and (b) the unfused pair it replaces (vitg_patchify + vitg_gemm_res16): same products, a different fp32 summation
+    order -> at most one 16-bit ulp apart.  Image sides that are not a multiple of the patch (384 = 27*14 + 6, 70, 62), the last patch of a row
+    ending exactly on the row's end (448, 224, 56: the second chunk must not run past it), a single frame, ragged M and N tiles."""
+    ps = 14
+    G = R // ps
+    P = G * G
+    pix = rnd((T, 3, R, R), 90 + T, dtype=dtype)
+    w = rnd((N, 3, ps, ps), 91, 0.05, dtype)
+    b = rnd((N,), 92, 0.1, torch.float32)
+    pos = rnd((P, N), 93, 0.5, torch.float32)
+    want = F.conv2d(pix, w, stride=ps).flatten(2).transpose(1, 2).reshape(-1, N) + b
+    want = want + pos.repeat(T, 1)
+    assert ops.patch_embed_fusable(T, R, ps, N)
+    # NaN guards behind the last pixel (and in front of the first): a loader chunk that ran past the end of a pixel row of the last frame
+    # would multiply a NaN by its zero weight and poison the output
+    buf = torch.full((T * 3 * R * R + 128,), float("nan"), dtype=dtype, device="cuda")
+    dpix = buf[64:64 + T * 3 * R * R].view(T, 3, R, R)
+    dpix.copy_(pix.to(dtype))
+    out = torch.full((T * P, N), float("nan"), dtype=dtype, device="cuda")
+    ops.patch_embed16(dpix, pair_layout(w.to(dtype)).cuda(), out, patch=ps, bias=b.cuda(), pos=pos.cuda())
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    tol = EPS16[dtype] * want.abs().clamp(min=1.0) + 1e-3
+    assert ((got - want).abs() <= tol).all(), (got - want).abs().max().item()
+    a0 = ops.patchify(pix.to(dtype).cuda(), ps, 640, dtype)
+    w2 = torch.zeros((N, 640), dtype=dtype)
+    w2[:, :588] = w.reshape(N, -1).to(dtype)
+    ref = torch.empty((T * P, N), dtype=dtype, device="cuda")
+    ops.gemm_res16(a0, w2.cuda(), ref, bias=b.cuda(), res32=pos.cuda(), res_mod=P)
+    d = (got - ref.float().cpu()).abs()
+    assert (d <= 2 * EPS16[dtype] * ref.float().cpu().abs() + 1e-6).all(), d.max().item()
+    # no bias / no position table
+    out2 = torch.full((T * P, N), float("nan"), dtype=dtype, device="cuda")
+    ops.patch_embed16(dpix, pair_layout(w.to(dtype)).cuda(), out2, patch=ps)
+    want2 = F.conv2d(pix, w, stride=ps).flatten(2).transpose(1, 2).reshape(-1, N)
+    assert ((out2.float().cpu() - want2).abs() <= EPS16[dtype] * want2.abs().clamp(min=1.0) + 1e-3).all()
+
+
+def test_patch_embed16_rejects_what_the_loader_does_not_cover(ops):
+    from videoitg_amd._lib import VitgError
+    assert not ops.patch_embed_fusable(2, 56, 14, 144)                 # N < 256: the 128-tile kernel's territory
+    assert not ops.patch_embed_fusable(2, 57, 14, 1152)                # odd image side: chunk sources would not be 4-byte aligned
+    assert not ops.patch_embed_fusable(2, 56, 7, 1152)                 # patch < 8
+    assert not ops.patch_embed_fusable(4000, 448, 14, 1152)            # 32-bit source offsets
+    pix = torch.zeros((2, 3, 56, 56), dtype=torch.float16, device="cuda")
+    with pytest.raises(VitgError):
+        ops.patch_embed16(pix, torch.zeros((144, 704), dtype=torch.float16, device="cuda"), torch.empty((32, 144), dtype=torch.float16, device="cuda"),
+                          patch=14)
+
+
+def test_engine_packs_the_pair_layout_like_the_test_does():
+    """PackedWeights.patch_wf (the engine's packer) == pair_layout (this file's restatement) on the synthetic tower's weight"""
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig, VisionConfig
+    from videoitg_amd.engine import PackedWeights
+    cfg = ITGConfig(vocab_size=512, num_hidden_layers=1, vision=VisionConfig(image_size=56, num_hidden_layers=2))
+    vsd = synth.synth_vision_state_dict(cfg, 5)
+    pw = PackedWeights(cfg=cfg, dtype=torch.float16, device=torch.device("cuda:0"))
+    pw.pack_vision_embeddings(vsd)
+    want = pair_layout(vsd["vision_model.embeddings.patch_embedding.weight"].half())
+    assert torch.equal(pw.patch_wf.cpu(), want)

@@ -13,6 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GEMM variants and ablation switches of include/videoitg_hip_profiling.h
 PROFILING = os.environ.get("VITG_PROFILING_LIB", "0") not in ("", "0")
 LIB_PATH = os.path.join(_HERE, "libvideoitg_hip_prof.so" if PROFILING else "libvideoitg_hip.so")
+# A/B measurements of experiment builds (csrc/build.sh --exp NAME; tools/r04): an explicit path to another build of the SAME C ABI.  Still no
+# fallback - if the named file is missing, load() raises.
+if os.environ.get("VITG_LIB_PATH"):
+    LIB_PATH = os.path.abspath(os.environ["VITG_LIB_PATH"])
 
 BF16, F16, F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
@@ -30,6 +34,7 @@ SIGNATURES = {
     "vitg_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "vitg_gemm": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "vitg_gemm_res16": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _p],
+    "vitg_patch_embed16": [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p],
     "vitg_gemm_splitk_plan": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_long)],
     "vitg_gemm_splitk": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p],
     "vitg_gemm_streamk_plan": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_long)],

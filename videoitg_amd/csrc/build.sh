@@ -17,6 +17,14 @@ if [ "${1:-}" = "--profiling" ]; then
   OBJ="$HERE/build_prof"
   DEFS="-DVITG_PROFILING_BUILD=1"
 fi
+# build.sh --exp NAME [defs]: an EXPERIMENT flavour of the product library (libvideoitg_hip_exp_NAME.so, tools/r04 A/B calls load it through
+# VITG_LIB_PATH): the product sources with -DVITG_EXP=1 and the given -D switches; never built by __graft_entry__.build(), never loaded by default
+if [ "${1:-}" = "--exp" ]; then
+  NAME="$2"; shift 2
+  OUT="$HERE/../libvideoitg_hip_exp_${NAME}.so"
+  OBJ="$HERE/build_exp_${NAME}"
+  DEFS="-DVITG_EXP=1"
+fi
 # VITG_CLEAN=1: compile every source from scratch (the default reuses objects newer than their sources and shared headers)
 if [ "${VITG_CLEAN:-0}" != "0" ]; then rm -rf "$OBJ" "$OUT"; fi
 mkdir -p "$OBJ"

@@ -42,6 +42,10 @@ struct GemmArgs {
     int sk_units, sk_kt;      // stream-K (vitg_gemm_streamk, gemm_mi16.hip): K-tile units per block / K-tiles per output tile; 0 = off
     int split_k;              // MODE_F32 only: gridDim.y = split_k blocks share one output tile, block y accumulates its K range and
     long split_stride;        // writes the raw fp32 partial tile to out + y * split_stride floats (vitg_gemm_splitk reduces them)
+    // patch embedding with the im2col inside the A-tile loader (vitg_patch_embed16; gemm_mi16.hip PATCH instantiations): A = pixel_values
+    // [T, 3, R, R] (16-bit, NCHW), row m = (frame, py, px) reads its p x p x 3 patch straight from there
+    int pt_R, pt_G, pt_P;     // image side, patches per side (R / p), patches per frame (G * G); pt_R == 0: off
+    int pt_p, pt_pairs;       // patch side p (8..16), (channel, ky) pairs = 3 p
 };
 
 enum { MODE_STORE16 = 0, MODE_F32 = 1, MODE_SWIGLU = 2 };

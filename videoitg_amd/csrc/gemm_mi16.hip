@@ -44,9 +44,17 @@ constexpr int MODE_RES16 = 3;      // internal: MODE_STORE16 with a residual pre
 // (192 + 64) / (192 * 64) = 0.0208); as 4 x 2 it gives 96 x 128 (0.0182, the figure of the 256x384 tile's 128 x 96) - the wide tiles differ by
 // 4-5 % on shapes both fit, and that is their LDS read traffic (profiles/r03_gemm_mi16.md).  The phased schedule is unchanged: waves 4-7 run
 // one barrier behind waves 0-3 (wave w and w + 4 share a SIMD).
-template <typename T, int MODE, int BM, int BN, bool SK = false, int WM = 2>
+// PATCH (round 4, vitg_patch_embed16): the patch-embedding GEMM reads its A operand - the im2col matrix [T * P, 3 p^2] - straight out of
+// pixel_values [T, 3, R, R] (16-bit NCHW): no im2col kernel, no [T * P, 640] operand written and read back (671 MB at 512 x 448^2).  The K axis is
+// re-laid as (c, ky) PAIRS of 16 slots (the weight is re-laid to match once at load, PackedWeights.patch_wf): a K-tile of 64 = 4 pairs, one
+// 128-B LDS row = 4 x [kx 0..7 | kx p-8..p-1].  Each 16-B DMA chunk is then 8 CONSECUTIVE pixels of one image row - a legal (4-B aligned)
+// global_load_lds_dwordx4 source - and the second chunk of a pair re-reads kx p-8..7, whose weight slots are zero: no chunk ever crosses the
+// end of its pixel row, so nothing is read outside the tensor and no value depends on what lies behind a patch.  The per-lane source offset
+// is (row's pixel base) + (pair's row/channel offset, recomputed per K-tile: ~7 VALU per DMA instruction on a GEMM of 11 K-tiles).
+template <typename T, int MODE, int BM, int BN, bool SK = false, int WM = 2, bool PATCH = false>
 __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     static_assert(!SK || MODE == MODE_F32, "stream-K partials are fp32 tiles");
+    static_assert(!PATCH || !SK, "the patch loader is not combined with stream-K");
     typedef typename T16<T>::vec8 vec8;
     GemmArgs g = g_;
     constexpr bool RES16 = MODE == MODE_RES16;
@@ -110,10 +118,19 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     const char* const a_base = (const char*)g.A + (size_t)m0 * g.lda * 2 + (size_t)kfirst * 128;
     const char* const w_base = (const char*)g.W + (size_t)n0 * g.ldw * 2 + (size_t)kfirst * 128;
     unsigned a_cur[A_INSTR], w_cur[W_INSTR];
+    int a_pair[PATCH ? A_INSTR : 1];                     // PATCH: which of the K-tile's four (c, ky) pairs this lane's chunk belongs to
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
         const int R = (wave * A_INSTR + j) * 8 + drow;
-        a_cur[j] = ((unsigned)(min(R, g.M - 1 - m0) * g.lda) + (unsigned)((dslot ^ ((R >> 1) & 7)) << 3)) * 2u;
+        if constexpr (PATCH) {
+            const int m = m0 + min(R, g.M - 1 - m0);
+            const int t = m / g.pt_P, rem = m - t * g.pt_P, py = rem / g.pt_G, px = rem - py * g.pt_G;
+            const int sc = dslot ^ ((R >> 1) & 7);       // source chunk 0..7 of the 128-B row: pair sc >> 1, half sc & 1
+            a_cur[j] = (unsigned)(((t * 3 * g.pt_R + py * g.pt_p) * g.pt_R + px * g.pt_p + (sc & 1) * (g.pt_p - 8)) * 2);
+            a_pair[j] = sc >> 1;
+        } else {
+            a_cur[j] = ((unsigned)(min(R, g.M - 1 - m0) * g.lda) + (unsigned)((dslot ^ ((R >> 1) & 7)) << 3)) * 2u;
+        }
     }
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j) {
@@ -126,10 +143,23 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
         const char* ka = a_base + koff;
         const char* kw = w_base + koff;
         unsigned off = j < A_INSTR ? a_cur[j] : w_cur[j - A_INSTR];
+        if constexpr (PATCH) {
+            if (j < A_INSTR) {                           // (pairs past 3 p - 1 are K padding: zero weight rows, any finite pixels)
+                const int pair = min(kt * 4 + a_pair[j], g.pt_pairs - 1);
+                const int c = (pair >= g.pt_p ? 1 : 0) + (pair >= 2 * g.pt_p ? 1 : 0), ky = pair - c * g.pt_p;
+                off += (unsigned)((c * g.pt_R + ky) * g.pt_R * 2);
+                ka = (const char*)g.A;
+            }
+        }
         asm volatile("" : "+v"(off));                    // keeps base + offset in the saddr form (no per-lane 64-bit pointer)
+#ifdef VITG_EXP_NT_A      // experiment build: the activation operand streams through the L2 non-temporally (the weight panel is what should stay)
+        constexpr int A_AUX = 2;
+#else
+        constexpr int A_AUX = 0;
+#endif
         if (j < A_INSTR)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ka + off),
-                                             (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, A_AUX);
         else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kw + off),
                                              (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * W_INSTR + j - A_INSTR) * 1024), 16, 0, 0);
@@ -536,4 +566,46 @@ int launch_gemm_mi16(const GemmArgs& g, int dtype, int mode, int cfg, hipStream_
     return dtype == DT_BF16 ? launch16_t<bf16_t>(g, mode, cfg, s) : launch16_t<f16_t>(g, mode, cfg, s);
 }
 
+// patch embedding with the im2col inside the A-tile loader: the 256x384 tile with the 16-bit-output + fp32 position-table epilogue (MODE_RES16)
+template <typename T>
+static int launch16_patch(GemmArgs g, hipStream_t s) {
+    constexpr int BM = 256, BN = 384, lds = 2 * (BM + BN) * 128;
+    static std::atomic<unsigned> done_mask{0};
+    const int cur_dev = current_device();
+    if (!device_done(done_mask, cur_dev)) {
+        (void)hipFuncSetAttribute((const void*)gemm16_kernel<T, MODE_RES16, BM, BN, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        mark_device_done(done_mask, cur_dev);
+    }
+    g.tiles_m = ceil_div(g.M, BM);
+    g.tiles_n = ceil_div(g.N, BN);
+    g.group_m = 4;
+    const int cus = device_cu_count(cur_dev), nwg = g.tiles_m * g.tiles_n;
+    hipLaunchKernelGGL((gemm16_kernel<T, MODE_RES16, BM, BN, false, 2, true>), dim3(nwg >= 2 * cus ? cus : nwg), dim3(G16_THREADS), lds, s, g);
+    return (int)hipGetLastError();
+}
+
 }  // namespace vitg
+
+// x[T * P, N] (16-bit) = im2col(pixel_values) @ Wf^T + bias + pos[(m % P), :]   - SigLIP's patch_embedding + position table
+// ([3P] SiglipVisionEmbeddings, reached from /root/reference/eagle/model/multimodal_encoder/clip_encoder.py:146) with the im2col done by the
+// GEMM's own operand loader (PATCH above).  Wf: [N, ldw >= 64 ceil(3 p / 4)] in the PAIR layout - k = 16 (c p + ky) + slot, slot 0..7 = kx 0..7,
+// slot 8..15 = kx p-8..p-1 with the slots of the re-read kx (p-8..7) ZERO, rows of K padding zero (videoitg_amd.engine.PackedWeights.patch_wf).
+// Returns VITG_ERR_SHAPE for geometries the loader does not cover (the caller then runs vitg_patchify + vitg_gemm_res16).
+extern "C" int vitg_patch_embed16(const void* pix, int T, int R, int patch, const void* Wf, int ldw, int N, int dtype, const float* bias,
+                                  void* out, int ldo, const float* pos, int ldp, void* stream) {
+    using namespace vitg;
+    if (T <= 0) return 0;
+    if (!pix || !Wf || !out) return VITG_ERR_ARG;
+    if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
+    if (patch < 8 || patch > 16 || (patch & 1) || R < patch || (R & 1)) return VITG_ERR_SHAPE;     // 4-B aligned chunk sources need even p and R
+    const int G = R / patch, P = G * G, pairs = 3 * patch, K = (pairs + 3) / 4 * 64;
+    if (N < 256 || (long)T * 3 * R * R * 2 >= (1l << 32) || (long)T * P >= (1l << 31)) return VITG_ERR_SHAPE;
+    if (ldw < K || (ldw % 8) || (ldo % 4) || (N % 4) || (pos && (ldp % 4))) return VITG_ERR_ALIGN;
+    GemmArgs g = {};
+    g.A = pix; g.lda = 0; g.W = Wf; g.ldw = ldw; g.M = T * P; g.N = N; g.K = K;
+    g.bias = bias; g.act = VITG_ACT_NONE; g.out = out; g.ldo = ldo; g.res = pos; g.ldr = ldp; g.res_mod = pos ? P : 0;
+    g.split_k = 1;
+    g.pt_R = R; g.pt_G = G; g.pt_P = P; g.pt_p = patch; g.pt_pairs = pairs;
+    const int rc = dtype == DT_BF16 ? launch16_patch<bf16_t>(g, (hipStream_t)stream) : launch16_patch<f16_t>(g, (hipStream_t)stream);
+    return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+}

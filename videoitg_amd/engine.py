@@ -127,6 +127,7 @@ class PackedWeights:
     fp8: object = False                             # BASELINE.json configs[4]: tower / decoder GEMM weights as e4m3fn + per-channel scales;
                                                     # True = both parts, "vit" / "llm" = that part only (the other stays 16-bit)
     patch_w: torch.Tensor = None; patch_b: torch.Tensor = None
+    patch_wf: torch.Tensor = None                  # the same weight in the (c, ky)-pair layout of vitg_patch_embed16 (im2col inside the GEMM's loader)
     pos_native: torch.Tensor = None                # fp32 [P0, Dv]
     pos_cache: Dict[int, torch.Tensor] = field(default_factory=dict)
     vit: List[VitLayerW] = field(default_factory=list)
@@ -180,6 +181,15 @@ class PackedWeights:
         w = vsd[e + "patch_embedding.weight"]
         self._packing = self.vit_dtype
         self.patch_w = self._w16(w.reshape(w.shape[0], -1))
+        # (c, ky)-pair layout for the fused loader (csrc/gemm_mi16.hip PATCH): k = 16 (c p + ky) + slot; slots 0..7 = kx 0..7, slots 8..15 =
+        # kx p-8..p-1 where the slots of the kx that chunk RE-READS (p-8..7) are zero; rows of K padding zero.  Same 16-bit values as patch_w.
+        p_ = w.shape[-1]
+        if w.dim() == 4 and w.shape[1] == 3 and w.shape[2] == p_ and 8 <= p_ <= 16 and p_ % 2 == 0:
+            rows = w.reshape(w.shape[0], 3 * p_, p_).to(self.device)
+            wf = torch.zeros((w.shape[0], (3 * p_ + 3) // 4 * 4, 16), dtype=rows.dtype, device=self.device)
+            wf[:, :3 * p_, :8] = rows[:, :, :8]
+            wf[:, :3 * p_, 16 - (p_ - 8):] = rows[:, :, 8:]
+            self.patch_wf = wf.reshape(w.shape[0], -1).to(self._packing).contiguous()
         self._packing = self.dtype
         self.patch_b = self._f32(vsd[e + "patch_embedding.bias"])
         self.pos_native = self._f32(vsd[e + "position_embedding.weight"])
@@ -287,6 +297,8 @@ class SelectorEngine:
         # Default since the gate held on every complete-pass fixture (max |dscore| 3.1e-4 against 1.5e-4 on the fp32 stream, Top-K sets
         # identical, step -2.8 %: profiles/r03_residual16.md); VITG_RES16=0 / engine.residual16 = False restores the fp32 stream.
         self.residual16 = os.environ.get("VITG_RES16", "1") not in ("", "0")
+        # patch embedding: im2col inside the GEMM's A-tile loader (round 4, vitg_patch_embed16); VITG_FUSE_PATCHIFY=0 = patchify kernel + GEMM (A/B, cross-check)
+        self.fuse_patchify = os.environ.get("VITG_FUSE_PATCHIFY", "1") not in ("", "0")
         self.vit_stream_bytes = 4                        # element size of the tower's residual stream in the LAST vit_forward (2 when the 16-bit stream ran)
         # LayerNorm / RMSNorm folded into the GEMMs around them (vitg_gemm_norm_*).  Measured 4 % SLOWER on the step than the stand-alone
         # norm kernels (profiles/r02_fused_norm.md), so the kernels live in the profiling library and this switch only exists there.
@@ -444,7 +456,6 @@ class SelectorEngine:
         M = T * P
         Dv, Dvp, Fvp = v.hidden_size, pad64(v.hidden_size), pad64(v.intermediate_size)
         H, hd = v.num_attention_heads, v.head_dim
-        a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.vdtype)
         eps, vdt = v.layer_norm_eps, self.vdtype
         # (fp16 only: a bf16 stream would carry 8 mantissa bits through 26 layers; never together with fp8 tower GEMMs or the fused norm)
         # (and only when the projector runs in the same type: vitg_bilinear_pool16 writes the pooled rows in the tower's type - ADVICE r3)
@@ -469,13 +480,22 @@ class SelectorEngine:
                 self._gemm(a, wt, xs, mode=K.GEMM_F32, bias=bias, res=xs)
 
         # `pend` = (xh, stats) when the GEMM that produced x also emitted the operand / statistics of the next LayerNorm (fuse_norm)
-        if r16:
-            K.gemm_res16(a0, w.patch_w, x, bias=w.patch_b, res32=w.pos_table(G), res_mod=P)
+        # patch embedding (+ bias + position table).  On the 16-bit stream the im2col happens inside the GEMM's operand loader
+        # (vitg_patch_embed16: no patchify pass, no [T*P, 640] operand in HBM); other streams / geometries: vitg_patchify + GEMM
+        fused_pe = (self.fuse_patchify and r16 and w.patch_wf is not None and pix.dtype == vdt and pix.is_contiguous()
+                    and K.patch_embed_fusable(T, R, v.patch_size, Dv))
+        if fused_pe:
+            K.patch_embed16(pix, w.patch_wf, x, patch=v.patch_size, bias=w.patch_b, pos=w.pos_table(G))
             pend = None
         else:
-            pend = self._producer(a0, w.patch_w, x, bias=w.patch_b, res=w.pos_table(G), res_mod=P, gamma=w.vit[0].ln1_w if w.vit else None,
-                                  name="vit", eps=eps, rms=False, dt=vdt)
-        del a0
+            a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], self.vdtype)
+            if r16:
+                K.gemm_res16(a0, w.patch_w, x, bias=w.patch_b, res32=w.pos_table(G), res_mod=P)
+                pend = None
+            else:
+                pend = self._producer(a0, w.patch_w, x, bias=w.patch_b, res=w.pos_table(G), res_mod=P, gamma=w.vit[0].ln1_w if w.vit else None,
+                                      name="vit", eps=eps, rms=False, dt=vdt)
+            del a0
         qkv = self._buf("vit_qkv", (M, 3 * Dv), vdt)
         o = self._buf("vit_o", (M, Dvp), vdt, zero=True)
         mx_mlp = self.fp8_mx and all(isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight) for lw in w.vit)

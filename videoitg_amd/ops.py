@@ -105,6 +105,27 @@ def gemm_res16(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
     return out
 
 
+def patch_embed_fusable(T: int, R: int, patch: int, n: int) -> bool:
+    """the geometries vitg_patch_embed16 covers (same tests as the C entry): otherwise vitg_patchify + vitg_gemm_res16"""
+    return (8 <= patch <= 16 and patch % 2 == 0 and R >= patch and R % 2 == 0 and n >= 256 and n % 4 == 0
+            and T * 3 * R * R * 2 < (1 << 32) and T * (R // patch) ** 2 < (1 << 31))
+
+
+def patch_embed16(pix: torch.Tensor, wf: torch.Tensor, out: torch.Tensor, *, patch: int, bias: Optional[torch.Tensor] = None,
+                  pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out16[T*P, N] = im2col(pix) @ W^T + bias + pos[m % P]: SigLIP's patch embedding with the im2col inside the GEMM's operand loader
+    (vitg_patch_embed16); wf = the convolution weight in the (c, ky)-pair layout (PackedWeights.patch_wf)"""
+    _req(pix); _req(wf, pix.dtype); _req(out, pix.dtype)
+    T, C3, R, R2 = pix.shape
+    if C3 != 3 or R != R2 or not pix.is_contiguous():
+        raise ValueError("pixel_values must be a contiguous [T, 3, R, R] tensor")
+    if pos is not None:
+        _req(pos, torch.float32)
+    _lib.call("vitg_patch_embed16", _ptr(pix), T, R, patch, _ptr(wf), wf.stride(0), wf.shape[0], dt_code(pix.dtype), _ptr(bias), _ptr(out),
+              out.stride(0), _ptr(pos), pos.stride(0) if pos is not None else 0, _stream())
+    return out
+
+
 def gemm_norm_plan(M: int, N: int, K: int) -> int:
     """output columns per partial of the fused-norm producer for this shape; 0 = not covered (use the stand-alone norm)"""
     c = C.c_int(0)

@@ -58,6 +58,10 @@ _def("gemm_res16(Tensor a, Tensor w, Tensor(a!) out, Tensor? bias=None, Tensor? 
          (_raw.gemm_res16(a, w, out, bias=bias, res16=res16, res32=res32, res_mod=res_mod), None)[1],
      lambda *a, **k: None)
 
+_def("patch_embed16(Tensor pix, Tensor wf, Tensor(a!) out, int patch, Tensor? bias=None, Tensor? pos=None) -> ()",
+     lambda pix, wf, out, patch, bias=None, pos=None: (_raw.patch_embed16(pix, wf, out, patch=patch, bias=bias, pos=pos), None)[1],
+     lambda *a, **k: None)
+
 _def("gemm_splitk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int splits, Tensor? bias=None, Tensor? res=None) -> ()",
      lambda a, w, out, workspace, splits, bias=None, res=None: (_raw.gemm_splitk(a, w, out, workspace, splits, bias=bias, res=res), None)[1],
      lambda *a, **k: None)
@@ -237,6 +241,13 @@ class _Namespace:
         return out
 
     @staticmethod
+    def patch_embed16(pix, wf, out, *, patch, bias=None, pos=None):
+        _ops.patch_embed16(pix, wf, out, patch, bias, pos)
+        return out
+
+    patch_embed_fusable = staticmethod(_raw.patch_embed_fusable)
+
+    @staticmethod
     def layernorm16(x, w, b, out, d, eps):
         _ops.layernorm16(x, w, b, out, d, eps)
         return out
@@ -294,4 +305,4 @@ class _Namespace:
 K = _Namespace()
 OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
                        "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx",
-                       "gemm_res16", "layernorm16", "bilinear_pool16", "gemm_streamk"]
+                       "gemm_res16", "layernorm16", "bilinear_pool16", "gemm_streamk", "patch_embed16"]
