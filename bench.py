@@ -447,7 +447,6 @@ def main():
     timer = GemmTimer()
     ops.gemm = timer.wrap(ops.gemm)
     ops.gemm_splitk = timer.wrap(ops.gemm_splitk)       # (the o / down projections of a context-parallel rank; includes their reduce kernel)
-    ops.gemm_streamk = timer.wrap(ops.gemm_streamk)     # (the same projections on the stream-K partition; includes the reduce kernel)
     ops.gemm_res16 = timer.wrap(ops.gemm_res16)         # (out-proj and fc2 of the tower on its 16-bit residual stream; the patch embedding when not fused)
     t_pe = GemmTimer()                                  # the patch-embed GEMM with the im2col inside its operand loader: one of the step's GEMM launches
     ops.patch_embed16 = t_pe.wrap(timer.wrap(ops.patch_embed16))     # (`timer` in the timed region, `t_pe` in the side pass)

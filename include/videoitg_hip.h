@@ -42,28 +42,20 @@ int vitg_version(void);
  * compute-unit count, or a negative error when no HIP device is usable. */
 int vitg_device_info(char* name, int name_len);
 
-/* Kernel-selection knobs for A/B measurements and tests; 0 = the measured default everywhere.  Defaults can also come from
- * the environment (VITG_<KEY IN CAPS>).  Host-only, no GPU needed.  Keys of the PRODUCT library:
- *   gemm_tile   128 | 256      force the 128x128 register-staged or the 256-wide LDS-DMA kernels
- *   gemm_cfg    2 256x128x32 (2 blocks/CU; small-M shapes) | 6 256x256x64 phased | 9 256x384 (fp32-residual shapes) |
- *               10 384x256 (SwiGLU, 16-bit outputs); anything else = 6.  Auto mode picks per shape (gemm256.hip: choose_cfg)
- *   gemm_group  M-tiles per group of the XCD-aware tile order (default 4)
- *   gemm_mi     MFMA shape of the 256x256 / 256x384 / 384x256 tiles: 16 v_mfma_f32_16x16x32 (gemm_mi16.hip, the default) | 32 v_mfma_f32_32x32x16
- *               (gemm256.hip);  gemm_mi_modes  bit mask of epilogue modes on the 16x16x32 kernels (A/B);  gemm_pref  forced tile shape per mode (A/B)
- *   gemm_wm4    wave grid of the 384x256 tile on the 16x16x32 kernels: bit mask of epilogue modes (1 16-bit output, 2 fp32 residual, 4 SwiGLU, 8 16-bit
- *               residual) that run 4 x 2 waves (96 x 128 wave tiles) instead of 2 x 4 (192 x 64); -1 none; 0 the library default
- *   gemm_flags  bits 26-30: epilogue-form A/B switches of the 16x16x32 kernels (26 residual-form bias per quad, 27 bias in the epilogue instead of as the
- *               accumulators' start value, 28 activation tested per quad + scalar GELU / SiLU, 29 no interior-tile forms, 30 bias tested per quad:
- *               same results, profiles/r03_gemm_epilogue.md);  bit8 wide tiles off, bits 11-14 cost-model A/B switches, bit24 one hardware block per tile instead of one block per CU walking the tile list (the default for long tile lists)
- *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
- *   attn_ab     1 | 2  half-tile-out-of-phase hd-72 kernel on / off (default on; PV on v_mfma_f32_16x16x32, five 16-row d-tiles);  3 = 16 waves per block;
- *               4 = its round-2 form with PV on v_mfma_f32_32x32x16 (head dim padded to 96; A/B and cross-check);  5 = PV on 16x16x32 with the softmax row
- *               sums on the VALU (the default forms them on the matrix pipe: a constant [1, 0, ..] pad chunk in every V row);  6 = with pre-scaled Q
- *               (vitg_attention variant bit 1) keep the multiply and the max subtraction on the VALU instead of taking the scores from the matrix pipe
- *   attn_sp     1 | 2  software-pipelined kernel on (both head sizes) / off (default: on for hd 128);  3 = hd 128 with PV on v_mfma_f32_16x16x32
- *               (measured 3-4 % slower than the default form; A/B and cross-check)
- * The research configurations of round 1 (gemm_cfg 1/3/4/5/7/8/11/13, fragment-packed weights, the ablation switches that produce
- * WRONG results by design) are NOT in this library: they live in libvideoitg_hip_prof.so (build.sh --profiling,
+/* Kernel-set selection for cross-check tests; 0 = the measured default everywhere.  FOUR keys, each a choice between the default and one
+ * cross-check kernel set; the same values can come from the environment (VITG_<KEY IN CAPS>, read once).  Host-only, no GPU needed.
+ *   gemm_tile   128  every GEMM on the 128x128 register-staged kernels (csrc/gemm.hip) | 256  never the 128-tile kernel where a 256-wide one applies
+ *   gemm_cfg    2 | 6 | 9 | 10  force ONE shipped 256-wide tile shape (256x128x32 | 256x256x64 | 256x384x64 | 384x256x64) instead of the per-shape
+ *               choice (csrc/gemm256.hip: choose_cfg) - lets a test reach every shipped kernel on a small shape
+ *   attn_ab     2  head dim 72 on the per-tile kernel (csrc/attention.hip) instead of the half-tile-out-of-phase one (csrc/attention_ab.hip)
+ *   attn_sp     2  head dim 128 on the per-tile kernel instead of the software-pipelined one (csrc/attention_sp.hip)
+ * Any other key or value returns VITG_ERR_ARG.  These are process-global test hooks: set them before the forward they should apply to, not from a
+ * second thread while one runs.  tests/test_gpu_e2e.py::test_full_size_invariants runs the same video through (gemm_tile 128, attn_ab 2, attn_sp 2)
+ * and through the defaults.
+ * Everything that was an A/B switch in rounds 1-3 (gemm_flags, gemm_group, gemm_mi, gemm_mi_modes, gemm_pref, gemm_wm4, gemm_stagger, attn_waves,
+ * attn_dma, attn_pipe, the other values of the four keys above) and every kernel variant that lost its A/B (32x32x16 wide tiles, 4 x 2 wave grid,
+ * stream-K, hd-72 cross-tile / software-pipelined loops, 16-wave blocks, PV on 32x32x16, VALU row sums, hd-128 PV on 16x16x32, the round-1 research
+ * configurations, the ablation switches that produce WRONG results by design) lives in libvideoitg_hip_prof.so only (build.sh --profiling,
  * include/videoitg_hip_profiling.h), which tools/ load and the product never does. */
 int vitg_set_option(const char* key, int value);
 
@@ -124,16 +116,6 @@ int vitg_bilinear_pool16(const void* x, int ldx, void* out, int ldo, int T, int 
 int vitg_gemm_splitk_plan(int M, int N, int K, int* splits, long* workspace_bytes);
 int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
                      int ldo, const float* res, int ldr, float* workspace, int splits, void* stream);
-
-/* Stream-K form of the same GEMM (round 3) for FEWER output tiles than CUs and a long K - the same shapes one rank of an 8-GPU run has
- * (o: 98 tiles x 56 K-tiles, down: 98 x 296 on 256 CUs), where split-K x2 leaves 60 CUs idle: the K-tiles of all output tiles are laid end to end
- * and cut into equal runs, one per block (a block covers the tail of one tile and the head of the next); each segment's raw fp32 partial tile goes
- * to its own workspace slot and a second kernel adds a tile's segments in block order, the bias and the residual (no atomics: bit-reproducible).
- * vitg_gemm_streamk_plan: blocks == 0 means "does not apply" (use vitg_gemm_splitk_plan / vitg_gemm); otherwise pass blocks and a workspace of
- * workspace_bytes to vitg_gemm_streamk.  out = A W^T + bias + res (fp32). */
-int vitg_gemm_streamk_plan(int M, int N, int K, int* blocks, long* workspace_bytes);
-int vitg_gemm_streamk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
-                      int ldo, const float* res, int ldr, float* workspace, int blocks, void* stream);
 
 /* ---- FP8 weight path (BASELINE.json configs[4]; videoitg_amd/csrc/gemm_fp8.hip) ------------------------------------------------
  * The reference runs fp16 everywhere (/root/reference/eagle/model/builder.py:59), so this is an additional precision tier of the

@@ -3,12 +3,25 @@
  * measurements in profiles/r01_gemm_shapes.md; the product library (include/videoitg_hip.h) does not contain them and the
  * product path never loads this library.
  *
- * Additional vitg_set_option keys in the profiling library:
+ * Additional vitg_set_option keys / values in the profiling library (environment: VITG_<KEY IN CAPS>):
  *   gemm_cfg    1 256x256x32 ring-4 | 3 256x256x64 ring-2 | 4 persistent | 5 asm LDS reads | 7 phased, 2 k-steps per interval |
  *               8 four waves x 128x128 (AGPR accumulators) | 11 register-staged operands | 13 persistent blocks, deferred epilogue
  *   gemm_flags  bit0 non-temporal stores, bit5 N-split launch, bit7 5-stage ring for cfg 8, bit20/21 auto mode uses cfg 13;
- *               bits 1-4, 6, 9, 15-19, 22-23: ablations that produce WRONG results (additionally need VITG_PROFILING=1)
- *   gemm_stagger  persistent kernel (cfg 4): de-phase the XCDs
+ *               bits 1-4, 6, 9, 15-19, 22-23: ablations that produce WRONG results (additionally need VITG_PROFILING=1);
+ *               bit8 wide tiles off, bits 11-14 cost-model A/B switches, bit24 one hardware block per tile instead of one block per CU walking the
+ *               tile list, bit26 XCD rendezvous (gemm256.hip) / residual-form bias per quad (gemm_mi16.hip), bits 27-30 epilogue-form A/B switches of the
+ *               16x16x32 kernels (27 bias in the epilogue instead of as the accumulators' start value, 28 activation tested per quad + scalar GELU / SiLU,
+ *               29 no interior-tile forms, 30 bias tested per quad: same results, profiles/r03_gemm_epilogue.md)
+ *   gemm_stagger  persistent kernel (cfg 4) / tile loop of the fp32-residual shapes: de-phase the XCDs / tile groups
+ *   gemm_group  M-tiles per group of the XCD-aware tile order (default 4)
+ *   gemm_mi     32 = the 256x256 / 256x384 / 384x256 tiles on v_mfma_f32_32x32x16 (gemm256.hip; the product runs them on 16x16x32, gemm_mi16.hip);
+ *               gemm_mi_modes bit mask of epilogue modes on the 16x16x32 kernels;  gemm_pref forced tile shape per mode
+ *   gemm_wm4    wave grid of the 384x256 tile on the 16x16x32 kernels: bit mask of epilogue modes (1 16-bit output, 2 fp32 residual, 4 SwiGLU, 8 16-bit
+ *               residual) that run 4 x 2 waves (96 x 128 wave tiles) instead of 2 x 4 (192 x 64); -1 none
+ *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
+ *   attn_ab     1 forced on | 3 16 waves per block | 4 PV on v_mfma_f32_32x32x16 (head dim padded to 96) | 5 PV on 16x16x32 with the softmax row sums on
+ *               the VALU | 6 pre-scaled Q with the multiply and the max subtraction kept on the VALU
+ *   attn_sp     1 software-pipelined kernel for both head sizes | 3 hd 128 with PV on v_mfma_f32_16x16x32 (3-4 % slower than the default form)
  */
 #ifndef VIDEOITG_HIP_PROFILING_H
 #define VIDEOITG_HIP_PROFILING_H
@@ -16,6 +29,17 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* (round 3; LOST its A/B against split-K x2 on the per-rank shapes - 447 / 694 against 682 / 911 TF/s, profiles/r03_context_parallel.md - and
+ * therefore not in the product library since round 4)  Stream-K form of vitg_gemm_splitk's GEMM for FEWER output tiles than CUs and a long K - the same shapes one rank of an 8-GPU run has
+ * (o: 98 tiles x 56 K-tiles, down: 98 x 296 on 256 CUs), where split-K x2 leaves 60 CUs idle: the K-tiles of all output tiles are laid end to end
+ * and cut into equal runs, one per block (a block covers the tail of one tile and the head of the next); each segment's raw fp32 partial tile goes
+ * to its own workspace slot and a second kernel adds a tile's segments in block order, the bias and the residual (no atomics: bit-reproducible).
+ * vitg_gemm_streamk_plan: blocks == 0 means "does not apply" (use vitg_gemm_splitk_plan / vitg_gemm); otherwise pass blocks and a workspace of
+ * workspace_bytes to vitg_gemm_streamk.  out = A W^T + bias + res (fp32). */
+int vitg_gemm_streamk_plan(int M, int N, int K, int* blocks, long* workspace_bytes);
+int vitg_gemm_streamk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
+                      int ldo, const float* res, int ldr, float* workspace, int blocks, void* stream);
 
 /* Static-weight fast path of vitg_gemm.  Weights never change between forwards, so they can be stored a second time in the order
  * the MFMA consumes them: vitg_pack_weight_fragments writes, for every (32-row weight tile, 16-deep k-step), one contiguous 1-KiB

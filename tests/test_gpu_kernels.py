@@ -11,6 +11,18 @@ pytestmark = pytest.mark.gpu
 DTYPES = [torch.bfloat16, torch.float16]
 EPS16 = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 
+# The PRODUCT library takes four option keys (gemm_tile, gemm_cfg, attn_ab, attn_sp: the defaults and one cross-check kernel set each,
+# include/videoitg_hip.h).  The A/B switches and the kernel variants that lost their A/B live in libvideoitg_hip_prof.so; the cases that need them
+# run when the suite is pointed at that library (VITG_PROFILING_LIB=1 python -m pytest tests -m gpu) and are skipped otherwise.
+from videoitg_amd import _lib as _L   # noqa: E402
+PROF = _L.PROFILING
+research_only = pytest.mark.skipif(not PROF, reason="research knob / variant: profiling library only (VITG_PROFILING_LIB=1)")
+
+
+def R(*values, id=None):
+    """a parametrize / fixture case that needs the profiling library"""
+    return pytest.param(*values, marks=research_only, id=id)
+
 
 @pytest.fixture(scope="module")
 def ops():
@@ -22,8 +34,8 @@ def ops():
 
 
 @pytest.fixture(params=["auto", "tile128", "cfg2_256x128x32", "cfg6_phased", "cfg9_256x384", "cfg10_384x256",
-                        "cfg6_mi16", "cfg9_256x384_mi16", "cfg10_384x256_mi16", "cfg6_mi32", "cfg9_256x384_mi32", "cfg10_384x256_mi32",
-                        "cfg10_384x256_mi16_wm4", "cfg10_384x256_mi16_wm2"])
+                        R("cfg6_mi16"), R("cfg9_256x384_mi16"), R("cfg10_384x256_mi16"), R("cfg6_mi32"), R("cfg9_256x384_mi32"), R("cfg10_384x256_mi32"),
+                        R("cfg10_384x256_mi16_wm4"), R("cfg10_384x256_mi16_wm2")])
 def gemm_cfg(request, ops):
     """Every SHIPPED GEMM kernel configuration is forced in turn (vitg_set_option), so the 256-tile kernels are covered at test
     sizes too (auto mode would pick the 128 tile for them); tile128 doubles as the cross-check set.  The research
@@ -38,26 +50,34 @@ def gemm_cfg(request, ops):
                      "cfg6_mi32": (256, 6, 32), "cfg9_256x384_mi32": (256, 9, 32), "cfg10_384x256_mi32": (256, 10, 32)}[name_]
     ops.set_option("gemm_tile", tile)
     ops.set_option("gemm_cfg", cfg)
-    ops.set_option("gemm_mi", mi)
-    ops.set_option("gemm_wm4", wm4)
+    if PROF:
+        ops.set_option("gemm_mi", mi)
+        ops.set_option("gemm_wm4", wm4)
     yield name
     ops.set_option("gemm_tile", 0)
     ops.set_option("gemm_cfg", 0)
-    ops.set_option("gemm_mi", 0)
-    ops.set_option("gemm_wm4", 0)
+    if PROF:
+        ops.set_option("gemm_mi", 0)
+        ops.set_option("gemm_wm4", 0)
 
 
-@pytest.fixture(params=[(0, 0, 0, 0, 0), (4, 0, 2, 2, 2), (8, 0, 2, 2, 2), (4, 1, 2, 2, 2), (4, 0, 1, 2, 2), (8, 0, 1, 2, 2), (4, 0, 0, 1, 2), (8, 0, 0, 1, 2),
-                        (0, 0, 0, 2, 1), (0, 0, 0, 2, 3), (0, 0, 0, 2, 4), (8, 0, 0, 3, 0), (0, 0, 0, 2, 5)],
-                ids=["auto", "waves4_reg", "waves8_reg", "waves4_pipelined", "waves4_dma", "waves8_dma", "waves4_swpipe", "waves8_swpipe",
-                     "half_tile_out_of_phase", "half_tile_out_of_phase_16_waves", "half_tile_out_of_phase_pv32", "waves8_swpipe_hd128_pv16", "half_tile_out_of_phase_valu_rowsum"])
+# (attn_waves, attn_pipe, attn_dma, attn_sp, attn_ab).  Product: the defaults (hd 72: half-tile-out-of-phase kernel when 256-query blocks fill the
+# chip, else the per-tile loop with LDS-DMA staging; hd 128: software-pipelined loop) and the cross-check set (per-tile kernels for both head sizes).
+@pytest.fixture(params=[pytest.param((0, 0, 0, 0, 0), id="auto"), pytest.param((0, 0, 0, 2, 2), id="per_tile_kernels"),
+                        R((4, 0, 2, 2, 2), id="waves4_reg"), R((8, 0, 2, 2, 2), id="waves8_reg"), R((4, 1, 2, 2, 2), id="waves4_pipelined"),
+                        R((4, 0, 1, 2, 2), id="waves4_dma"), R((8, 0, 1, 2, 2), id="waves8_dma"), R((4, 0, 0, 1, 2), id="waves4_swpipe"),
+                        R((8, 0, 0, 1, 2), id="waves8_swpipe"), R((0, 0, 0, 2, 1), id="half_tile_out_of_phase"),
+                        R((0, 0, 0, 2, 3), id="half_tile_out_of_phase_16_waves"), R((0, 0, 0, 2, 4), id="half_tile_out_of_phase_pv32"),
+                        R((8, 0, 0, 3, 0), id="waves8_swpipe_hd128_pv16"), R((0, 0, 0, 2, 5), id="half_tile_out_of_phase_valu_rowsum")])
 def attn_waves(request, ops):
     keys = ("attn_waves", "attn_pipe", "attn_dma", "attn_sp", "attn_ab")
     for key, val in zip(keys, request.param):
-        ops.set_option(key, val)
+        if PROF or key in ("attn_sp", "attn_ab"):
+            ops.set_option(key, val)
     yield request.param
     for key in keys:
-        ops.set_option(key, 0)
+        if PROF or key in ("attn_sp", "attn_ab"):
+            ops.set_option(key, 0)
 
 
 def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
@@ -161,7 +181,7 @@ def test_attention(ops, attn_waves, dtype, variant, B, H, HKV, S, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("ab", [0, 6, 4, 2], ids=["scores_from_matrix_pipe", "valu_scale", "pv32", "per_tile_kernel"])
+@pytest.mark.parametrize("ab", [pytest.param(0, id="scores_from_matrix_pipe"), R(6, id="valu_scale"), R(4, id="pv32"), pytest.param(2, id="per_tile_kernel")])
 @pytest.mark.parametrize("B,H,HKV,S,Sk,D", [(3, 2, 2, 729, 729, 72), (2, 16, 16, 1024, 1024, 72), (2, 3, 3, 100, 1024, 72), (1, 3, 3, 25, 25, 72), (1, 2, 2, 4, 4, 72),
                                             (1, 2, 2, 300, 1000, 72), (1, 4, 2, 523, 523, 128)])
 def test_attention_with_prescaled_q(ops, dtype, ab, B, H, HKV, S, Sk, D):
@@ -309,8 +329,31 @@ def test_rank_stable_descending(ops, n):
         assert torch.equal(order.cpu().long(), want)
 
 
+def test_product_library_takes_four_option_keys_and_nothing_else(ops):
+    """include/videoitg_hip.h documents FOUR keys with one cross-check value each; every research knob of rounds 1-3 and every research value of
+    the four keys is refused by the product library (a stray option cannot select a kernel variant the product does not ship)."""
+    from videoitg_amd._lib import VitgError
+    if PROF:
+        pytest.skip("the profiling library accepts the research knobs by design")
+    for key, val in (("gemm_tile", 128), ("gemm_tile", 256), ("gemm_cfg", 2), ("gemm_cfg", 6), ("gemm_cfg", 9), ("gemm_cfg", 10), ("attn_ab", 2), ("attn_sp", 2)):
+        ops.set_option(key, val)
+        ops.set_option(key, 0)
+    for key, val in (("gemm_flags", 1 << 27), ("gemm_group", 8), ("gemm_mi", 32), ("gemm_mi_modes", 1), ("gemm_pref", 111), ("gemm_wm4", 15), ("gemm_stagger", 1),
+                     ("attn_waves", 4), ("attn_dma", 1), ("attn_pipe", 1), ("gemm_cfg", 13), ("gemm_cfg", 3), ("gemm_tile", 64), ("attn_ab", 4), ("attn_ab", 1),
+                     ("attn_sp", 3), ("attn_sp", 1), ("no_such_key", 1)):
+        with pytest.raises(VitgError):
+            ops.set_option(key, val)
+    # the ablation bits of the attention entry (variant >> 4) are refused as before
+    qkv = torch.randn((64, 3 * 128), device="cuda").half()
+    o = torch.empty((64, 128), dtype=torch.float16, device="cuda")
+    with pytest.raises(VitgError):
+        ops.attention(qkv, qkv[:, 128:], qkv[:, 256:], o, batch=1, heads=1, kv_heads=1, seq=64, head_dim=128, q_strides=(0, 384, 128),
+                      k_strides=(0, 384, 128), v_strides=(0, 384, 128), o_strides=(0, 128, 128), scale=128 ** -0.5, variant=8 << 4)
+
+
+@research_only
 def test_profiling_ablations_are_inert_in_a_product_process(ops):
-    """The library carries profiling switches that skip work on purpose (wrong results).  Without VITG_PROFILING=1 in the
+    """The profiling library carries switches that skip work on purpose (wrong results).  Without VITG_PROFILING=1 in the
     environment of the process they must do nothing (GEMM) or be refused (attention)."""
     import os
     from videoitg_amd._lib import VitgError
@@ -340,6 +383,7 @@ def test_mfma_probe_runs_and_zero_operands_are_not_slower(ops):
     assert 500.0 < r <= z * 1.05 and z < 2700.0, (z, r)
 
 
+@research_only
 @pytest.mark.parametrize("mi", [16, 32])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [6, 9, 10])
@@ -492,6 +536,7 @@ def test_dispatcher_ops_with_residual_aliasing_output(ops, dtype):
         torch.ops.videoitg.gemm(a.cpu(), w.cpu(), sep.cpu(), ops.GEMM_F32, None, b.cpu(), 0, None, 0, None)
 
 
+@research_only
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(1660, 3584, 3584), (1660, 3584, 18944), (700, 1024, 4096), (300, 520, 2048), (1660, 1152, 2048)])
 def test_gemm_streamk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K):
@@ -516,6 +561,7 @@ def test_gemm_streamk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, 
     assert (outs[0] - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
 
 
+@research_only
 def test_gemm_streamk_plan_covers_the_per_rank_shapes(ops):
     name, cus = ops.device_info()
     b_o, _ = ops.gemm_streamk_plan(1660, 3584, 3584)
@@ -526,6 +572,7 @@ def test_gemm_streamk_plan_covers_the_per_rank_shapes(ops):
 
 
 # ---- round 3, late: the epilogue forms of gemm_mi16.hip are selected once per tile; every form must give the same result ----------------
+@research_only
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [6, 9, 10], ids=["256x256", "256x384", "384x256"])
 @pytest.mark.parametrize("M", [66000, 1700], ids=["tile_loop", "one_tile_per_block"])

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 4: VITG_GEMM_FLAGS / VITG_GEMM_GROUP / VITG_GEMM_STAGGER are research knobs of the profiling library - the product library ignores them;
+#  this script is the record of the round-1..3 A/Bs and needs VITG_PROFILING_LIB=1 to repeat them)
 # in-step A/B of the tile-shape cost-model switches (VITG_GEMM_FLAGS) and tile-order group (VITG_GEMM_GROUP), fp16 headline workload
 for rep in 1 2; do
 for f in 0 4096 2048 256 8192 16384 16777216; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 4: VITG_GEMM_FLAGS / VITG_GEMM_GROUP / VITG_GEMM_STAGGER are research knobs of the profiling library - the product library ignores them;
+#  this script is the record of the round-1..3 A/Bs and needs VITG_PROFILING_LIB=1 to repeat them)
 # same-box A/B of the tile-group de-phasing for the fp32-residual GEMMs (gemm_stagger): per shape, then in the step
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 for r in 1 2; do

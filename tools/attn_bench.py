@@ -5,6 +5,8 @@ import os
 import sys
 import torch
 
+if any("=" in a and not a.startswith("variant=") for a in sys.argv[1:]):       # option knobs other than the product's four live in the profiling library
+    os.environ.setdefault("VITG_PROFILING_LIB", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops  # noqa: E402
 

@@ -2,6 +2,7 @@
 """hd-128 attention on the shapes ONE rank of the context-parallel LLM sees (S local queries x all 12860 keys, GQA 28:4) for the block
 sizes attn_waves = 3 / 4 / 8 (96 / 128 / 256 queries per block): which one balances 256 CUs best at each rank count."""
 import os, sys, torch
+os.environ.setdefault("VITG_PROFILING_LIB", "1")   # research knobs (round 4: the product library takes four option keys only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops
 dt = torch.float16

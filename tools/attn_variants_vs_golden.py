@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Error of each attention loop structure against the committed golden logits (tests/golden/*.npz), fp16."""
 import os, sys
+os.environ.setdefault("VITG_PROFILING_LIB", "1")   # research knobs (round 4: the product library takes four option keys only)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -2,6 +2,7 @@
 """Tile-shape sweep of the shipped 256-tile GEMM on the step's shapes WITH their real epilogues (gemm_cfg 0 = auto, 6 = 256x256,
 9 = 256x384, 10 = 384x256), same call: checks that auto mode still picks the fastest shape.   python tools/gemm_cfg_sweep.py [fp16|bf16]"""
 import os, sys, torch
+os.environ.setdefault("VITG_PROFILING_LIB", "1")   # research knobs (round 4: the product library takes four option keys only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops
 dt = torch.bfloat16 if "bf16" in sys.argv[1:] else torch.float16

@@ -4,6 +4,7 @@ with their real epilogues, interleaved in one process (median of rounds), produc
 results (different accumulation order inside the MFMA: fp32 rounding only).
     python tools/gemm_mi_ab.py [fp16|bf16] [rounds]"""
 import os, sys, statistics
+os.environ.setdefault("VITG_PROFILING_LIB", "1")   # research knobs (round 4: the product library takes four option keys only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videoitg_amd import ops

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GEMM throughput at the per-rank row counts of the context-parallel LLM (M = N_tokens / world)."""
 import os, sys, torch
+os.environ.setdefault("VITG_PROFILING_LIB", "1")   # research knobs (round 4: the product library takes four option keys only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videoitg_amd import ops
 dt = torch.bfloat16 if "bf16" in sys.argv[1:] else torch.float16

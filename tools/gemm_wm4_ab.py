@@ -4,6 +4,7 @@ fewer fragment bytes per flop), the step's shapes with their real epilogues, int
 two grids give bit-identical results (same k order per output element) and shows the 256x384 tile (128 x 96 wave tiles) where the mode has it.
     python tools/gemm_wm4_ab.py [fp16|bf16] [rounds]"""
 import os, sys, statistics
+os.environ.setdefault("VITG_PROFILING_LIB", "1")   # research knobs (round 4: the product library takes four option keys only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videoitg_amd import ops

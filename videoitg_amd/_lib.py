@@ -37,8 +37,6 @@ SIGNATURES = {
     "vitg_patch_embed16": [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p],
     "vitg_gemm_splitk_plan": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_long)],
     "vitg_gemm_splitk": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p],
-    "vitg_gemm_streamk_plan": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_long)],
-    "vitg_gemm_streamk": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p],
     "vitg_quant_rows_fp8": [_p, _l, _i, _p, _l, _p, _l, _i, _p],
     "vitg_norm_quant_fp8": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _f, _p],
     "vitg_gemm_fp8": [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
@@ -63,6 +61,8 @@ SIGNATURES = {
 
 # include/videoitg_hip_profiling.h: only in libvideoitg_hip_prof.so
 PROFILING_SIGNATURES = {
+    "vitg_gemm_streamk_plan": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_long)],
+    "vitg_gemm_streamk": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p],
     "vitg_gemm_wf": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
     "vitg_weight_fragments_bytes": [_i, _i, C.POINTER(C.c_long)],
     "vitg_pack_weight_fragments": [_p, _i, _i, _i, _p, _p],

@@ -497,7 +497,7 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     // Defaults from same-call A/B (profiles/r01_attention.md): 8 waves / 256 queries per block when that still yields enough
     // blocks to fill the chip, else 4; K/V staging by LDS-DMA for hd 72 (+16 %: no staging registers -> 3-4 waves/SIMD) and
     // through registers for hd 128 (DMA measured 3-6 % slower there).  attn_waves / attn_dma (1 = DMA, 2 = registers) pin them.
-    const int nw_env = tuning().attn_waves;
+    const int nw_env = RESEARCH(attn_waves);
     int nw = nw_env ? nw_env : 8;
     if (!nw_env) {
         // 256-query blocks run one per CU, 128-query blocks two per CU: with r = blocks / slots rounds of work the chip is r / ceil(r)
@@ -518,6 +518,27 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     }
 #endif
 #define GO(T, D) (!tr ? launch_attn<T, D, false, 4>(a, batch, heads, s) : nw == 4 ? launch_attn<T, D, true, 4>(a, batch, heads, s) : launch_attn<T, D, true, 8>(a, batch, heads, s))
+#if !VITG_PROFILING_BUILD
+    // PRODUCT library: the measured defaults plus ONE cross-check set (attn_sp = 2 / attn_ab = 2: the per-tile kernels of this file).
+    //   hd 128 -> software-pipelined loop (attention_sp.hip; 1023 vs 916 TF/s on the LLM shape);
+    //   hd 72  -> half-tile-out-of-phase kernel (attention_ab.hip) when 256-query blocks fill the chip, else the per-tile loop with LDS-DMA staging.
+    // The variants that lost their A/B (hd-72 cross-tile pipelined loop, hd-72 software-pipelined loop, DMA staging at hd 128, 16-wave blocks, PV on
+    // 32x32x16, VALU row sums, hd-128 PV on 16x16x32) are instantiated in the profiling library only.
+    if (tr && head_dim == 128 && tuning().attn_sp == 0) {
+        rc = attention_sp_dispatch(a, batch, heads, head_dim, dtype, nw, false, s);
+        return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+    }
+    if (tr && head_dim == 72 && tuning().attn_ab == 0 && nw == 8) {
+        rc = attention_ab_dispatch(a, batch, heads, dtype, 8, 0, q_prescaled, s);
+        return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+    }
+    if (tr && head_dim == 72)
+        rc = dtype == DT_BF16 ? (nw == 4 ? launch_attn<bf16_t, 72, true, 4, false, false, true>(a, batch, heads, s) : launch_attn<bf16_t, 72, true, 8, false, false, true>(a, batch, heads, s))
+                              : (nw == 4 ? launch_attn<f16_t, 72, true, 4, false, false, true>(a, batch, heads, s) : launch_attn<f16_t, 72, true, 8, false, false, true>(a, batch, heads, s));
+    else if (dtype == DT_BF16) rc = head_dim == 72 ? GO(bf16_t, 72) : GO(bf16_t, 128);
+    else rc = head_dim == 72 ? GO(f16_t, 72) : GO(f16_t, 128);
+    return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+#else
     // hd 72: optional cross-tile software-pipelined variant (QK^T of tile t+1 issued before the softmax of tile t).  Measured
     // equal to the plain loop (549 vs 555 TF/s, profiles/r01_attention.md), so it is opt-in: attn_pipe = 1
     // Software-pipelined loop (attention_sp.hip): default for hd 128 (LLM shape 1023 vs 916 TF/s); for hd 72 the per-tile
@@ -528,13 +549,13 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     }
     // hd 72 default: the half-tile-out-of-phase kernel (attention_ab.hip, +5 % over the per-tile loop in same-call A/B) whenever
     // 256-query blocks fill the chip and no other variant is pinned; attn_ab = 1 / 2 forces it on / off
-    const bool ab_auto = tuning().attn_ab == 0 && !nw_env && nw == 8 && !tuning().attn_pipe && !tuning().attn_dma && tuning().attn_sp != 1;
+    const bool ab_auto = tuning().attn_ab == 0 && !nw_env && nw == 8 && !RESEARCH(attn_pipe) && !RESEARCH(attn_dma) && tuning().attn_sp != 1;
     if (tr && head_dim == 72 && !a.ablate && (tuning().attn_ab == 1 || tuning().attn_ab >= 3 || ab_auto) && tuning().attn_sp != 1) {
         rc = attention_ab_dispatch(a, batch, heads, dtype, tuning().attn_ab == 3 ? 16 : 8, tuning().attn_ab >= 4 ? tuning().attn_ab : 0, q_prescaled, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
-    const bool pipe72 = tr && head_dim == 72 && nw == 4 && tuning().attn_pipe == 1;
-    const bool dma = tr && !pipe72 && (tuning().attn_dma == 1 || (tuning().attn_dma == 0 && head_dim == 72));
+    const bool pipe72 = tr && head_dim == 72 && nw == 4 && RESEARCH(attn_pipe) == 1;
+    const bool dma = tr && !pipe72 && (RESEARCH(attn_dma) == 1 || (RESEARCH(attn_dma) == 0 && head_dim == 72));
     if (pipe72) rc = dtype == DT_BF16 ? launch_attn<bf16_t, 72, true, 4, false, true>(a, batch, heads, s)
                                       : launch_attn<f16_t, 72, true, 4, false, true>(a, batch, heads, s);
     else if (dma) {
@@ -544,8 +565,9 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
 #undef GD
     } else if (dtype == DT_BF16) rc = head_dim == 72 ? GO(bf16_t, 72) : GO(bf16_t, 128);
     else rc = head_dim == 72 ? GO(f16_t, 72) : GO(f16_t, 128);
-#undef GO
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+#endif
+#undef GO
 }
 
 extern "C" int vitg_attention(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads,

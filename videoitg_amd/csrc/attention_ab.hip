@@ -464,9 +464,13 @@ int attention_ab_dispatch(const AttnArgs& a_, int batch, int heads, int dtype, i
     const bool pv32 = form == 4;
     if (qs && form == 0 && waves == 8)
         return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, true, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, true, true>(a, batch, heads, s);
+#if VITG_PROFILING_BUILD   // the forms that lost their A/B (profiles/r03_attention.md): profiling library only
     if (form == 5) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, false>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, false>(a, batch, heads, s);
     if (pv32) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, false>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, false>(a, batch, heads, s);
     if (waves == 16) return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 16, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 16, true>(a, batch, heads, s);
+#else
+    (void)pv32; (void)waves;
+#endif
     return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true>(a, batch, heads, s);
 }
 

@@ -452,12 +452,20 @@ int attention_sp_dispatch(const AttnArgs& a_, int batch, int heads, int head_dim
     static const int exp_bits = [] { const char* e = getenv("VITG_EXP_ATTN"); return e ? atoi(e) : 0; }();
     a.ablate = exp_bits & 0x300;           // (bits 0-4 of `ablate` are this file's profiling ablations)
 #endif
+#if !VITG_PROFILING_BUILD
+    // PRODUCT library: head dim 128 only (the hd-72 form and PV on 16x16x32 lost their A/Bs: profiling library)
+    (void)pv16;
+    if (head_dim != 128) return -1;
+    if (dtype == DT_BF16) return nw == 4 ? launch_sp<bf16_t, 128, 4>(a, batch, heads, s) : launch_sp<bf16_t, 128, 8>(a, batch, heads, s);
+    return nw == 4 ? launch_sp<f16_t, 128, 4>(a, batch, heads, s) : launch_sp<f16_t, 128, 8>(a, batch, heads, s);
+#else
     if (head_dim == 128 && nw == 8 && pv16)
         return dtype == DT_BF16 ? launch_sp<bf16_t, 128, 8, true>(a, batch, heads, s) : launch_sp<f16_t, 128, 8, true>(a, batch, heads, s);
 #define SP(T, D) (nw == 3 ? launch_sp<T, D, 3>(a, batch, heads, s) : nw == 4 ? launch_sp<T, D, 4>(a, batch, heads, s) : launch_sp<T, D, 8>(a, batch, heads, s))
     if (dtype == DT_BF16) return head_dim == 72 ? SP(bf16_t, 72) : SP(bf16_t, 128);
     return head_dim == 72 ? SP(f16_t, 72) : SP(f16_t, 128);
 #undef SP
+#endif
 }
 
 }  // namespace vitg

@@ -116,24 +116,38 @@ inline int device_cu_count(int dev) {
     return c;
 }
 
-// Host-side tuning knobs (vitg_set_option / environment VITG_*): kernel selection for A/B measurements and tests.
+// Host-side kernel-selection knobs (vitg_set_option / environment VITG_*).
+// PRODUCT library: FOUR keys, each a choice between the measured default and one cross-check kernel set (what tests/test_gpu_e2e.py's
+// test_full_size_invariants runs the same video through); everything that was an A/B switch of rounds 1-3 - and every kernel variant that lost
+// its A/B - lives in the profiling library only (RESEARCH(field) below is the constant 0 in the product, so the host code folds and a stray
+// option or environment variable cannot select a variant the product does not ship).
 struct Tuning {
-    int gemm_tile;     // 0 auto | 128 | 256
-    int gemm_cfg;      // 0 auto | 1 256x256x32 ring-4 | 2 256x128x32 ring-3 | 3 256x256x64 ring-2 | 4 persistent 256x256x64
-    int gemm_flags;    // bit0 non-temporal stores; bits 1-3 profiling ablations (wrong results)
+    // ---- product keys (include/videoitg_hip.h) -------------------------------------------------------------------------------
+    int gemm_tile;     // 0 auto | 128 the 128x128 register-staged kernels everywhere (cross-check set) | 256 never the 128-tile kernel where a 256-wide one applies
+    int gemm_cfg;      // 0 auto (choose_cfg per shape) | 2 256x128x32 | 6 256x256x64 | 9 256x384x64 | 10 384x256x64 : forces ONE shipped tile shape (tests reach every shipped kernel on small shapes)
+    int attn_ab;       // hd 72: 0 auto (half-tile-out-of-phase kernel when 256-query blocks fill the chip) | 2 off (per-tile kernel: cross-check)
+    int attn_sp;       // hd 128: 0 auto (software-pipelined kernel) | 2 off (per-tile kernel: cross-check)
+    // ---- research knobs: libvideoitg_hip_prof.so only (include/videoitg_hip_profiling.h) -------------------------------------
+    int gemm_flags;    // A/B and ablation bits (see the kernels)
     int gemm_stagger;  // fp32-residual GEMMs in the tile loop: start the tile groups a third of a tile period apart (0 off, 1 = estimated period, > 1 = ns);
-                       // +6 % on the out-proj shape alone, nothing measurable in the step (profiles/r02_gemm_timeline.md): default off
-    int gemm_group;    // gemm256: M-tiles per tile-order group (0 = default 4)
-    int gemm_pref;     // A/B: forced tile shape per epilogue mode as three decimal digits <16-bit out><fp32 residual><SwiGLU>, digit 0 auto | 1 256x256 | 2 256x384 | 3 384x256
-    int gemm_mi;       // MFMA shape of the 256-tile GEMMs: 0 auto (= 16) | 16 v_mfma_f32_16x16x32 (gemm_mi16.hip) | 32 v_mfma_f32_32x32x16 (gemm256.hip)
-    int gemm_mi_modes; // A/B: epilogue modes that take the 16x16x32 kernels when gemm_mi selects them, bit0 16-bit output, bit1 fp32 residual, bit2 SwiGLU (0 = all)
+                       // +6 % on the out-proj shape alone, nothing measurable in the step (profiles/r02_gemm_timeline.md)
+    int gemm_group;    // M-tiles per tile-order group (0 = 4)
+    int gemm_pref;     // forced tile shape per epilogue mode as three decimal digits <16-bit out><fp32 residual><SwiGLU>, digit 0 auto | 1 256x256 | 2 256x384 | 3 384x256
+    int gemm_mi;       // MFMA shape of the 256-wide tiles: 0 / 16 v_mfma_f32_16x16x32 (gemm_mi16.hip) | 32 v_mfma_f32_32x32x16 (gemm256.hip; lost by 4-14 %, profiles/r03_gemm_mi16.md)
+    int gemm_mi_modes; // epilogue modes that take the 16x16x32 kernels when gemm_mi selects them, bit0 16-bit output, bit1 fp32 residual, bit2 SwiGLU (0 = all)
     int attn_waves;    // 0 auto | 4 | 8
-    int attn_pipe;     // 0 off (default) | 1 cross-tile pipelined hd-72 variant
+    int attn_pipe;     // 1 cross-tile pipelined hd-72 variant (measured equal to the plain loop)
     int attn_dma;      // 0 auto (DMA for hd 72, registers for hd 128) | 1 LDS-DMA K/V staging | 2 register staging
-    int attn_ab;       // hd 72: 0 auto | 1 half-tile-out-of-phase kernel (attention_ab.hip) | 2 off | 3 the same kernel with 16 waves / 512 queries per block | 4 its PV-on-32x32x16 form | 5 PV on 16x16x32 with VALU row sums | 6 pre-scaled Q without the shift column (A/B)
-    int attn_sp;       // 0 auto | 1 software-pipelined kernel (attention_sp.hip) | 2 per-tile kernel (attention.hip) | 3 hd 128: software-pipelined with PV on 16x16x32 (opt-in, slower)
-    int gemm_wm4;      // 384x256 tile of gemm_mi16.hip as a 4 x 2 wave grid (96 x 128 wave tiles): 0 library default | -1 never | bit mask of epilogue modes (1 16-bit output, 2 fp32 residual, 4 SwiGLU, 8 16-bit residual)
+    int gemm_wm4;      // 384x256 tile of gemm_mi16.hip as a 4 x 2 wave grid (96 x 128 wave tiles): 0 library default | -1 never | bit mask of epilogue modes
+                       // (+3.7 % at long K, -1.7 % at K = 1152, nothing in the step)
+    // research VALUES of the product keys (profiling library only): gemm_cfg 1/3/4/5/7/8/11/13; attn_ab 1 forced on | 3 16 waves per block | 4 PV on 32x32x16 |
+    // 5 VALU row sums | 6 pre-scaled Q without the shift column; attn_sp 1 forced on for both head sizes | 3 hd 128 with PV on 16x16x32 (3-4 % slower)
 };
 Tuning& tuning();
+#if VITG_PROFILING_BUILD
+#define RESEARCH(field) (::vitg::tuning().field)
+#else
+#define RESEARCH(field) 0
+#endif
 
 }  // namespace vitg

@@ -21,9 +21,27 @@ extern "C" int vitg_device_info(char* name, int name_len) {
 
 namespace vitg {
 static int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e) : 0; }
+// values a PRODUCT key may take (the research values of these keys select variants only the profiling library instantiates)
+static bool product_value_ok(const char* key, int v) {
+    if (!strcmp(key, "gemm_tile")) return v == 0 || v == 128 || v == 256;
+    if (!strcmp(key, "gemm_cfg")) return v == 0 || v == 2 || v == 6 || v == 9 || v == 10;
+    if (!strcmp(key, "attn_ab") || !strcmp(key, "attn_sp")) return v == 0 || v == 2;
+    return false;
+}
+static int env_product(const char* env, const char* key) { const int v = env_int(env); return (VITG_PROFILING_BUILD || product_value_ok(key, v)) ? v : 0; }
 Tuning& tuning() {
-    static Tuning t = {env_int("VITG_GEMM_TILE"), env_int("VITG_GEMM_CFG"), env_int("VITG_GEMM_FLAGS"), env_int("VITG_GEMM_STAGGER"), env_int("VITG_GEMM_GROUP"), env_int("VITG_GEMM_PREF"), env_int("VITG_GEMM_MI"), env_int("VITG_GEMM_MI_MODES"),
-                       env_int("VITG_ATTN_WAVES"), env_int("VITG_ATTN_PIPE"), env_int("VITG_ATTN_DMA"), env_int("VITG_ATTN_AB"), env_int("VITG_ATTN_SP"), env_int("VITG_GEMM_WM4")};
+    static Tuning t = [] {
+        Tuning x = {};
+        x.gemm_tile = env_product("VITG_GEMM_TILE", "gemm_tile"); x.gemm_cfg = env_product("VITG_GEMM_CFG", "gemm_cfg");
+        x.attn_ab = env_product("VITG_ATTN_AB", "attn_ab"); x.attn_sp = env_product("VITG_ATTN_SP", "attn_sp");
+#if VITG_PROFILING_BUILD
+        x.gemm_flags = env_int("VITG_GEMM_FLAGS"); x.gemm_stagger = env_int("VITG_GEMM_STAGGER"); x.gemm_group = env_int("VITG_GEMM_GROUP");
+        x.gemm_pref = env_int("VITG_GEMM_PREF"); x.gemm_mi = env_int("VITG_GEMM_MI"); x.gemm_mi_modes = env_int("VITG_GEMM_MI_MODES");
+        x.attn_waves = env_int("VITG_ATTN_WAVES"); x.attn_pipe = env_int("VITG_ATTN_PIPE"); x.attn_dma = env_int("VITG_ATTN_DMA");
+        x.gemm_wm4 = env_int("VITG_GEMM_WM4");
+#endif
+        return x;
+    }();
     return t;
 }
 }  // namespace vitg
@@ -31,8 +49,14 @@ Tuning& tuning() {
 extern "C" int vitg_set_option(const char* key, int value) {
     if (!key) return VITG_ERR_ARG;
     vitg::Tuning& t = vitg::tuning();
+#if !VITG_PROFILING_BUILD
+    if (!vitg::product_value_ok(key, value)) return VITG_ERR_ARG;      // not a product key, or a research value of one
+#endif
     if (!strcmp(key, "gemm_tile")) t.gemm_tile = value;
     else if (!strcmp(key, "gemm_cfg")) t.gemm_cfg = value;
+    else if (!strcmp(key, "attn_sp")) t.attn_sp = value;
+    else if (!strcmp(key, "attn_ab")) t.attn_ab = value;
+#if VITG_PROFILING_BUILD
     else if (!strcmp(key, "gemm_flags")) t.gemm_flags = value;
     else if (!strcmp(key, "gemm_stagger")) t.gemm_stagger = value;
     else if (!strcmp(key, "gemm_group")) t.gemm_group = value;
@@ -43,8 +67,7 @@ extern "C" int vitg_set_option(const char* key, int value) {
     else if (!strcmp(key, "attn_waves")) t.attn_waves = value;
     else if (!strcmp(key, "attn_pipe")) t.attn_pipe = value;
     else if (!strcmp(key, "attn_dma")) t.attn_dma = value;
-    else if (!strcmp(key, "attn_sp")) t.attn_sp = value;
-    else if (!strcmp(key, "attn_ab")) t.attn_ab = value;
+#endif
     else return VITG_ERR_ARG;
     return 0;
 }

@@ -245,10 +245,14 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     // bits 1-4 and 6 of gemm_flags are profiling ablations that produce WRONG results; they only take effect in a process that
     // opted in with VITG_PROFILING=1 (tools/ set it), so a stray option or environment variable cannot corrupt a product run
     static const bool profiling = [] { const char* e = getenv("VITG_PROFILING"); return e && atoi(e) != 0; }();
-    g.flags = profiling ? tuning().gemm_flags : (tuning().gemm_flags & ~(2 | 4 | 8 | 16 | 64 | 0xF0000));
+    g.flags = profiling ? RESEARCH(gemm_flags) : (RESEARCH(gemm_flags) & ~(2 | 4 | 8 | 16 | 64 | 0xF0000));
     hipStream_t s = (hipStream_t)stream;
     const int force = tuning().gemm_tile;          // 0 auto | 128 | 256 (vitg_set_option / VITG_GEMM_TILE)
     int rc;
+    // (ADVICE r3: only the three tile configurations that exist in gemm_mi16.hip - 6 / 9 / 10, with the shape conditions launch256_m puts on
+    // 9 and 10 - carry the 16-bit-output residual forms; any other forced gemm_cfg must NOT reach gemm256.hip's own epilogue, which would drop the residual)
+    const int cfg16 = (mode == VITG_GEMM_STORE16 && (res || res16) && force != 128 && gemm256_applicable(g, mode)) ? gemm256_pick_cfg(g, mode) : 0;
+    const bool res16_on_mi16 = (cfg16 == 6 || (cfg16 == 9 && N >= 384) || (cfg16 == 10 && M >= 384)) && (ldr16 % 4 == 0) && N >= 256;
     // Kernel choice by tile count (measured on the per-rank shapes of the context-parallel LLM, tools/gemm_small_m.py):
     // >= 160 tiles of 256x256 -> 256x256x64 ring-2 (1 block/CU); fewer -> 256x128x32 ring-3 at 2 blocks/CU (twice the tiles,
     // 512 slots) which beat both the 256x256 and the 128x128 kernel there; M < 256 / unaligned cases -> 128x128.
@@ -260,18 +264,14 @@ static int gemm_entry(const void* A, int lda, const void* W, int ldw, const void
     // switches inside an interval - was ported to gemm256.hip; since then the 384x256 tile wins again (721.6 vs 713.9 frames/s,
     // alternating runs; profiles/r01_gemm_shapes.md section 16).
     else if ((tuning().gemm_cfg == 13 ||
-              (tuning().gemm_cfg == 0 && (tuning().gemm_flags & 0x100000) && act != VITG_ACT_GELU_ERF &&
-               (mode != VITG_GEMM_SWIGLU || (tuning().gemm_flags & 0x200000)) && ceil_div(M, 256) * ceil_div(N, 256) >= 512)) &&
+              (tuning().gemm_cfg == 0 && (RESEARCH(gemm_flags) & 0x100000) && act != VITG_ACT_GELU_ERF &&
+               (mode != VITG_GEMM_SWIGLU || (RESEARCH(gemm_flags) & 0x200000)) && ceil_div(M, 256) * ceil_div(N, 256) >= 512)) &&
              force != 128 && gemm_pe_applicable(g, mode))
         rc = launch_gemm_pe(g, dtype, mode, s);
     else
 #endif
     // 16-bit output + residual (vitg_gemm_res16): the 256-wide tiles of gemm_mi16.hip, or - where auto mode would take the 256x128
     // tile or the shape is small / unaligned - the 128-tile kernel; gemm256.hip's own epilogues do not carry these forms
-    // (ADVICE r3: only the three tile configurations that exist in gemm_mi16.hip - 6 / 9 / 10, with the shape conditions launch256_m puts on
-    // 9 and 10 - carry the residual forms; any other forced gemm_cfg must NOT reach gemm256.hip's own epilogue, which would drop the residual)
-    const int cfg16 = (mode == VITG_GEMM_STORE16 && (res || res16) && force != 128 && gemm256_applicable(g, mode)) ? gemm256_pick_cfg(g, mode) : 0;
-    const bool res16_on_mi16 = (cfg16 == 6 || (cfg16 == 9 && N >= 384) || (cfg16 == 10 && M >= 384)) && (ldr16 % 4 == 0) && N >= 256;
     if (mode == VITG_GEMM_STORE16 && (res || res16) && !res16_on_mi16)
         rc = dtype == DT_BF16 ? launch<bf16_t>(g, mode, s) : launch<f16_t>(g, mode, s);
     else
@@ -365,6 +365,7 @@ extern "C" int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, 
     return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
 }
 
+#if VITG_PROFILING_BUILD   // (lost its A/B against split-K x2: profiling library only since round 4)
 // ---- stream-K for fp32-residual GEMMs with fewer output tiles than CUs (round 3; kernel side: gemm_mi16.hip, SK) -----------------------------
 namespace vitg {
 // out[m, n] = sum over the segments of tile (m / 256, n / 256), in block order, + bias[n] + res[m, n].  Tile t owns K-tile units [t KT, (t+1) KT) of the
@@ -438,6 +439,7 @@ extern "C" int vitg_gemm_streamk(const void* A, int lda, const void* W, int ldw,
                        out, ldo, M, N);
     return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
 }
+#endif   // stream-K
 
 #if VITG_PROFILING_BUILD
 // ---- LayerNorm / RMSNorm folded into the GEMMs on either side of it (round 2; measured slower than the stand-alone norm pass, kept

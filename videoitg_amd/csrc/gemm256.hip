@@ -812,7 +812,7 @@ static int launch256p(GemmArgs g, hipStream_t s) {
     const int ntiles = g.tiles_m * g.tiles_n;
     const int grid = ntiles >= cus ? cus : ((ntiles + 7) & ~7);
     // one tile period ~ 1.15 us per 64-deep K-tile (measured main-loop rate) + epilogue; only worth it with several rounds
-    const int stag = tuning().gemm_stagger;            // default off: measured no gain
+    const int stag = RESEARCH(gemm_stagger);            // default off: measured no gain
     g.stagger_ns = (stag && ntiles >= 4 * cus) ? (g.K / 64) * 1150 + 4000 : 0;
     hipLaunchKernelGGL((gemm256p_kernel<T, MODE>), dim3(grid), dim3(G2_THREADS), lds, s, g);
     return (int)hipGetLastError();
@@ -833,17 +833,17 @@ static int launch256(GemmArgs g, hipStream_t s) {
     g.tiles_n = ceil_div(g.N, BN);
     // M-tiles per group of the tile order (the 32 blocks resident on an XCD then cover group_m x 32/group_m tiles sharing operand
     // panels in its L2): 4 measured best (+0.5 % on the step over 8; 16 and 32 lose 10-20 %, profiles/r01_gemm_shapes.md section 7)
-    g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
+    g.group_m = RESEARCH(gemm_group) > 0 ? RESEARCH(gemm_group) : 4;
     // one block per CU walking the tile list ("software relaunch") when there are at least two tiles per CU and one block fills a CU
     const int cus = device_cu_count(cur_dev);
     const int nwg = g.tiles_m * g.tiles_n;
     // default since round 2: in-step A/B in fp16, two alternations: 734.8 -> 732.7 ms, GEMM 1073 -> 1079 TF/s (gpurun_out/r02_ab_flags.log);
     // gemm_flags bit24 switches back to one hardware block per tile (A/B and the bit-identity test)
-    const bool loop = BN >= 256 && nwg >= 2 * cus && !(tuning().gemm_flags & 0x1000000);
+    const bool loop = BN >= 256 && nwg >= 2 * cus && !(RESEARCH(gemm_flags) & 0x1000000);
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
     // gemm_stagger (default off: +6 % on the out-proj shape timed alone, 725.8 / 731.8 vs 734.7 / 732.6 ms in the step, tools/ab_stagger.sh;
     // 1 = estimate the tile period, > 1 = tile period in ns): de-phase the tile groups of the fp32-residual shapes
-    const int stag = tuning().gemm_stagger;
+    const int stag = RESEARCH(gemm_stagger);
     g.stagger_ns = (MODE == MODE_F32 && loop && splits == 1 && stag > 0) ? (stag > 1 ? stag : (g.K / 64) * 2400 + 40000) : 0;
 #if VITG_PROFILING_BUILD
     g.xcd_sync = nullptr;
@@ -880,8 +880,8 @@ bool gemm256_applicable(const GemmArgs& g, int mode) {
 // MFMA shape of the three wide tiles: v_mfma_f32_16x16x32 (gemm_mi16.hip) unless gemm_mi = 32 asks for the 32x32x16 kernels of this file
 // (A/B, tests); gemm_mi_modes restricts it per epilogue mode (A/B)
 static bool gemm_mi16_selected(int mode) {
-    if (tuning().gemm_mi == 32) return false;
-    const int mm = tuning().gemm_mi_modes;
+    if (RESEARCH(gemm_mi) == 32) return false;
+    const int mm = RESEARCH(gemm_mi_modes);
     return mm == 0 || ((mm >> mode) & 1);
 }
 static int choose_cfg(const GemmArgs& g, int mode) {
@@ -891,12 +891,12 @@ static int choose_cfg(const GemmArgs& g, int mode) {
         const long rounds = (tiles + (long)cus * blocks_per_cu - 1) / ((long)cus * blocks_per_cu);
         return (double)rounds * blocks_per_cu * bm * bn / eff;
     };
-    const bool wide_ok = !(tuning().gemm_flags & 256);               // flags bit8: A/B switch (wide tiles off)
+    const bool wide_ok = !(RESEARCH(gemm_flags) & 256);               // flags bit8: A/B switch (wide tiles off)
     double best = cost(256, 256, 1.00, 1);
     int cfg = 6;
     if (g.N < 256) return 2;
     {   // gemm_pref (A/B): force a tile shape per epilogue mode when the shape admits it
-        const int pref = tuning().gemm_pref, d = mode == MODE_STORE16 ? pref / 100 % 10 : mode == MODE_F32 ? pref / 10 % 10 : pref % 10;
+        const int pref = RESEARCH(gemm_pref), d = mode == MODE_STORE16 ? pref / 100 % 10 : mode == MODE_F32 ? pref / 10 % 10 : pref % 10;
         if (d == 1) return 6;
         if (d == 2 && mode != MODE_SWIGLU && g.N >= 384) return 9;
         if (d == 3 && g.M >= 384) return 10;
@@ -908,17 +908,17 @@ static int choose_cfg(const GemmArgs& g, int mode) {
         const bool resid = mode == MODE_F32 || (mode == MODE_STORE16 && (g.res || g.res16));
         // 16-bit outputs on the 16x16x32 kernels: the 128x96 wave tile leads on the tower's qkv / fc1 (1142 / 1024 against 1096 / 1041 for
         // 384x256 and 1042 / 994 for 256x256 TF/s, +0.7 % on the step over 384x256: profiles/r03_gemm_mi16.md)
-        const double e = resid ? ((g.K >= 4096 || (tuning().gemm_flags & 8192)) ? 1.07 : 1.00)
-                               : (gemm_mi16_selected(mode) ? 1.10 : ((tuning().gemm_flags & 2048) ? 0.90 : 1.00));   // flags bit11: A/B (16-bit outputs off the wide tile)
+        const double e = resid ? ((g.K >= 4096 || (RESEARCH(gemm_flags) & 8192)) ? 1.07 : 1.00)
+                               : (gemm_mi16_selected(mode) ? 1.10 : ((RESEARCH(gemm_flags) & 2048) ? 0.90 : 1.00));   // flags bit11: A/B (16-bit outputs off the wide tile)
         const double c9 = cost(256, 384, e, 1);
         if (c9 < 0.97 * best) { best = c9; cfg = 9; }
     }
-    if (wide_ok && g.M >= 384 && !(mode == MODE_F32 && (tuning().gemm_flags & 16384))) {
+    if (wide_ok && g.M >= 384 && !(mode == MODE_F32 && (RESEARCH(gemm_flags) & 16384))) {
         // fp32-residual GEMMs on the tall tile since the saddr addressing freed its registers (it used to spill): o-proj at M = 12860
         // +6 %, and at M = 6460 (two context-parallel ranks) o / down fit ONE round of 384x256 tiles: +24 % / +48 % (tools/gemm_small_m.py).
         // flags bit12: A/B (16-bit outputs off the tall tile); bit14: A/B (fp32-residual GEMMs off it)
         const bool resid10 = mode == MODE_F32 || (mode == MODE_STORE16 && (g.res || g.res16));
-        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : resid10 ? 1.05 : (gemm_mi16_selected(mode) ? 1.05 : ((tuning().gemm_flags & 4096) ? 0.96 : 1.08)), 1);
+        const double c10 = cost(384, 256, mode == MODE_SWIGLU ? 1.07 : resid10 ? 1.05 : (gemm_mi16_selected(mode) ? 1.05 : ((RESEARCH(gemm_flags) & 4096) ? 0.96 : 1.08)), 1);
         // the 3 % hysteresis protects the 256x256 default; between the two wide tiles the cheaper one wins outright (fc1: N = 4352 is 11.3 tiles of
         // 384 but 17 of 256 - 1033 against 1015 TF/s on the tall tile, while qkv, N = 9 x 384, stays on the wide one: 1131 against 1078)
         if (cfg == 9 ? c10 < best : c10 < 0.97 * best) { best = c10; cfg = 10; }
@@ -950,10 +950,15 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
 #if VITG_PROFILING_BUILD
     if (cfg == 8 && g.N >= 256 && gemm_w4_applicable(g, MODE)) return launch_gemm_w4(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, s);   // 4 waves x 128x128 (gemm_w4.hip)
 #endif
+#if !VITG_PROFILING_BUILD
+    // PRODUCT library: this file ships ONE kernel, the 256x128x32 ring-3 tile (2 blocks / CU: the small-M shapes of a context-parallel rank, N < 256);
+    // the wide tiles run on v_mfma_f32_16x16x32 (gemm_mi16.hip, above).  What else arrives here - fp32 output WITH an activation on a wide-tile
+    // shape (no caller in the engine; gemm_mi16.hip's fp32 epilogue carries no activation) - runs on this kernel too: its staged epilogue has every form.
+    return launch256<T, MODE, 128, 4, 3, 32>(g, s);
+#else
     if (cfg == 10 && g.M >= 384) return launch256<T, MODE, 256, 2, 2, 64, false, 1, 384>(g, s);               // 384x256x64 phased (wave tile 192x64)
     if (cfg == 9 && MODE != MODE_SWIGLU && g.N >= 384) return launch256<T, MODE, 384, 2, 2, 64, false, 1>(g, s);   // 256x384x64 phased (wave tile 128x96)
     if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32>(g, s);
-#if VITG_PROFILING_BUILD
     // research configurations (profiles/r01_gemm_shapes.md): only in libvideoitg_hip_prof.so
     if (cfg == 4 && (g.K / 64) % 2 == 0 && g.K >= 256) return launch256p<T, MODE>(g, s);
     if (cfg == 1) return launch256<T, MODE, 256, 2, 4, 32>(g, s);
@@ -961,13 +966,13 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
     if (cfg == 7) return launch256<T, MODE, 256, 2, 2, 64, false, 2>(g, s);     // 7 = phased, 2 k-steps per interval
     if (cfg == 5) return launch256<T, MODE, 256, 2, 2, 64, true>(g, s);       // 5 = inline-asm LDS reads + counted lgkmcnt (measured = cfg 3)
     if (cfg == 3) return launch256<T, MODE, 256, 2, 2, 64, false>(g, s);      // 3 = free-running ring-2 loop
-#endif
     return launch256<T, MODE, 256, 2, 2, 64, false, 1>(g, s);                  // 6 = phased, 1 k-step per interval
+#endif   // VITG_PROFILING_BUILD
 #if 0
     // N = k*256 + 128 (SigLIP: 1152 = 4.5 tiles, 3456 = 13.5): a 256-wide last tile would be half padding.  Run the k*256
     // columns with the 256x256 kernel and the last 128 columns with the 256x128 kernel (two launches, same stream).
     // Measured: qkv +-0, out-proj -4 %, fc2 +2 % -> off by default (gemm_flags bit5 enables it).
-    if (MODE != MODE_SWIGLU && g.N % 256 == 128 && g.N >= 384 && (tuning().gemm_flags & 32)) {
+    if (MODE != MODE_SWIGLU && g.N % 256 == 128 && g.N >= 384 && (RESEARCH(gemm_flags) & 32)) {
         GemmArgs a = g, b = g;
         a.N = g.N - 128;
         b.N = 128;

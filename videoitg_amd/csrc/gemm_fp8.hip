@@ -347,7 +347,7 @@ static int launch_fp8(Gemm8Args ga, hipStream_t s) {
     }
     ga.g.tiles_m = ceil_div(ga.g.M, BM);
     ga.g.tiles_n = ceil_div(ga.g.N, BN);
-    ga.g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
+    ga.g.group_m = RESEARCH(gemm_group) > 0 ? RESEARCH(gemm_group) : 4;
     hipLaunchKernelGGL((gemm_fp8_kernel<T, MODE, BM, BN, MXA, MXO>), dim3(ga.g.tiles_m * ga.g.tiles_n), dim3(F8_THREADS), lds, s, ga);
     return (int)hipGetLastError();
 }

@@ -499,7 +499,7 @@ static int launch16(GemmArgs g, hipStream_t s) {
     }
     g.tiles_m = ceil_div(g.M, BM);
     g.tiles_n = ceil_div(g.N, BN);
-    g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
+    g.group_m = RESEARCH(gemm_group) > 0 ? RESEARCH(gemm_group) : 4;
     static int cus_dev[16] = {0};
     int cus = cur_dev < 16 ? cus_dev[cur_dev] : 0;
     if (!cus) {
@@ -508,12 +508,13 @@ static int launch16(GemmArgs g, hipStream_t s) {
     }
     const int nwg = g.tiles_m * g.tiles_n;
     // one block per CU walking the tile list when there are at least two tiles per CU (gemm256.hip: "software relaunch")
-    const bool loop = nwg >= 2 * cus && !(tuning().gemm_flags & 0x1000000);
+    const bool loop = nwg >= 2 * cus && !(RESEARCH(gemm_flags) & 0x1000000);
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
     hipLaunchKernelGGL((gemm16_kernel<T, MODE, BM, BN, false, WM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G16_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
 
+#if VITG_PROFILING_BUILD   // stream-K lost its A/B against split-K x2 on the per-rank shapes (profiles/r03_context_parallel.md): profiling library only
 template <typename T>
 static int launch16_sk(GemmArgs g, int blocks, hipStream_t s) {
     constexpr int lds = 2 * (256 + 256) * 128;
@@ -535,16 +536,19 @@ int launch_gemm_mi16_streamk(const GemmArgs& g, int dtype, int blocks, hipStream
 }
 
 static int wm4_modes() {
-    const int v = tuning().gemm_wm4;
+    const int v = RESEARCH(gemm_wm4);
     return v < 0 ? 0 : v == 0 ? WM4_DEFAULT_MODES : v;
 }
+#endif
 
 template <typename T, int MODE>
 static int launch16_m(const GemmArgs& g, int cfg, hipStream_t s) {
     if (cfg == 10 && g.M >= 384) {
         // gemm_wm4 (A/B, bit per epilogue mode: 1 16-bit output, 2 fp32 residual, 4 SwiGLU, 8 16-bit residual): the 4 x 2 wave grid (96 x 128 wave tiles)
+#if VITG_PROFILING_BUILD   // (+3.7 % at long K, -1.7 % at K = 1152, nothing in the step: profiling library only)
         constexpr int bit = MODE == MODE_STORE16 ? 1 : MODE == MODE_F32 ? 2 : MODE == MODE_SWIGLU ? 4 : 8;
         if (wm4_modes() & bit) return launch16<T, MODE, 384, 256, 4>(g, s);
+#endif
         return launch16<T, MODE, 384, 256>(g, s);
     }
     if constexpr (MODE != MODE_SWIGLU) {

@@ -289,7 +289,7 @@ int launch_gemm_pe(const GemmArgs& g_in, int dtype, int mode, hipStream_t s) {
     GemmArgs g = g_in;
     g.tiles_m = ceil_div(g.M, PE_BM);
     g.tiles_n = ceil_div(g.N, PE_BN);
-    g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
+    g.group_m = RESEARCH(gemm_group) > 0 ? RESEARCH(gemm_group) : 4;
 #define PE_GO(T)                                                                                         \
     (mode == MODE_SWIGLU ? launch_pe_t<T, PE_ACT_SWIGLU>(g, s) : g.act == VITG_ACT_GELU_TANH ? launch_pe_t<T, VITG_ACT_GELU_TANH>(g, s)                              \
                                  : g.act == VITG_ACT_GELU_ERF ? launch_pe_t<T, VITG_ACT_GELU_ERF>(g, s) : launch_pe_t<T, VITG_ACT_NONE>(g, s))

@@ -215,7 +215,7 @@ static int launch_w4_tms(const GemmArgs& g, hipStream_t s) {
 }
 template <typename T, int MODE>
 static int launch_w4_tm(const GemmArgs& g, hipStream_t s) {
-    return (tuning().gemm_flags & 128) ? launch_w4_tms<T, MODE, 5>(g, s) : launch_w4_tms<T, MODE, 4>(g, s);     // bit7: 5-stage ring (160 KiB)
+    return (RESEARCH(gemm_flags) & 128) ? launch_w4_tms<T, MODE, 5>(g, s) : launch_w4_tms<T, MODE, 4>(g, s);     // bit7: 5-stage ring (160 KiB)
 }
 
 bool gemm_w4_applicable(const GemmArgs& g, int mode) {

@@ -245,7 +245,7 @@ static int launch_wf_tm(GemmArgs g, hipStream_t s) {
         if (!cus) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur_dev);
         g.stagger_blocks = 2 * cus;                      // the initial fill: two blocks per CU
         // half of what a 128 x 256 tile takes while it shares its CU (~1.1 us per K-tile) unless gemm_stagger gives ns explicitly
-        const int st = tuning().gemm_stagger;
+        const int st = RESEARCH(gemm_stagger);
         g.stagger_ns = st > 1 ? st : st == 1 ? (g.K / 64) * 550 + 3000 : 0;
     }
     hipLaunchKernelGGL((gemm_wf_kernel<T, MODE, ABL, WF_BM>), dim3(g.tiles_m * g.tiles_n), dim3(2 * WF_BM), LDS, s, g);
@@ -263,7 +263,7 @@ int launch_gemm_wf(const GemmArgs& g_in, int dtype, int mode, hipStream_t s) {
     GemmArgs g = g_in;
     g.tiles_m = ceil_div(g.M, 256);
     g.tiles_n = ceil_div(g.N, WF_BN);
-    g.group_m = tuning().gemm_group > 0 ? tuning().gemm_group : 4;
+    g.group_m = RESEARCH(gemm_group) > 0 ? RESEARCH(gemm_group) : 4;
     const int abl = (g.flags >> 16) & 3;                 // profiling only (gemm.hip masks these bits in product runs)
     if (abl && mode == MODE_STORE16 && dtype == DT_BF16) {
         switch (abl) {
@@ -273,7 +273,7 @@ int launch_gemm_wf(const GemmArgs& g_in, int dtype, int mode, hipStream_t s) {
             default: break;
         }
     }
-    if (tuning().gemm_flags & 0x2000000) {               // bit25: two independent 4-wave blocks per CU (128 x 256 tiles)
+    if (RESEARCH(gemm_flags) & 0x2000000) {               // bit25: two independent 4-wave blocks per CU (128 x 256 tiles)
 #define WF_GO2(T)                                                                                    \
     (mode == MODE_STORE16 ? launch_wf_tm<T, MODE_STORE16, 0, 128>(g, s)                              \
                           : mode == MODE_F32 ? launch_wf_tm<T, MODE_F32, 0, 128>(g, s) : launch_wf_tm<T, MODE_SWIGLU, 0, 128>(g, s))

@@ -318,7 +318,9 @@ class SelectorEngine:
         self.cp_overlap = os.environ.get("VITG_CP_OVERLAP", "1") not in ("", "0")
         # fp32-residual GEMMs with fewer output tiles than CUs (one context-parallel rank): VITG_STREAMK=1 runs them as a stream-K partition instead
         # of split-K x2.  Opt-in: measured SLOWER on the per-rank o / down shapes (447 / 694 against 682 / 911 TF/s, profiles/r03_context_parallel.md)
-        self.stream_k = os.environ.get("VITG_STREAMK", "0") not in ("", "0")
+        # (profiling library only since round 4: the product library no longer carries the stream-K kernels)
+        from . import _lib as _l
+        self.stream_k = _l.PROFILING and os.environ.get("VITG_STREAMK", "0") not in ("", "0")
 
     # workspace: ONE buffer per name, grown to the largest row count seen and handed out as a [:rows] view, so a run over
     # documents with varying prompt lengths / frame counts holds max-size buffers instead of one set per distinct shape.

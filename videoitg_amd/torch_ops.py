@@ -66,12 +66,12 @@ _def("gemm_splitk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int 
      lambda a, w, out, workspace, splits, bias=None, res=None: (_raw.gemm_splitk(a, w, out, workspace, splits, bias=bias, res=res), None)[1],
      lambda *a, **k: None)
 
-_def("gemm_streamk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int blocks, Tensor? bias=None, Tensor? res=None) -> ()",
-     lambda a, w, out, workspace, blocks, bias=None, res=None: (_raw.gemm_streamk(a, w, out, workspace, blocks, bias=bias, res=res), None)[1],
-     lambda *a, **k: None)
-
 # ---- norm folded into the GEMMs around it (profiling library only: measured slower than the stand-alone norm kernels)
 if _raw._lib.PROFILING:
+  # stream-K (round 3) lost its A/B against split-K x2 on the per-rank shapes: profiling library only since round 4
+  _def("gemm_streamk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int blocks, Tensor? bias=None, Tensor? res=None) -> ()",
+       lambda a, w, out, workspace, blocks, bias=None, res=None: (_raw.gemm_streamk(a, w, out, workspace, blocks, bias=bias, res=res), None)[1],
+       lambda *a, **k: None)
   _def("gemm_norm_producer(Tensor a, Tensor w, Tensor(a!) out, Tensor res, Tensor next_gamma, Tensor(b!) xh, Tensor(c!) partials, "
        "Tensor? bias=None, int res_mod=0) -> ()",
        lambda a, w, out, res, next_gamma, xh, partials, bias=None, res_mod=0:
@@ -305,4 +305,4 @@ class _Namespace:
 K = _Namespace()
 OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
                        "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx",
-                       "gemm_res16", "layernorm16", "bilinear_pool16", "gemm_streamk", "patch_embed16"]
+                       "gemm_res16", "layernorm16", "bilinear_pool16", "patch_embed16"] + (["gemm_streamk"] if _raw._lib.PROFILING else [])
