@@ -13,10 +13,10 @@ EPS16 = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 
 # The PRODUCT library takes four option keys (gemm_tile, gemm_cfg, attn_ab, attn_sp: the defaults and one cross-check kernel set each,
 # include/videoitg_hip.h).  The A/B switches and the kernel variants that lost their A/B live in libvideoitg_hip_prof.so; the cases that need them
-# run when the suite is pointed at that library (VITG_PROFILING_LIB=1 python -m pytest tests -m gpu) and are skipped otherwise.
+# run when the suite is pointed at that library (VITG_PROFILING_LIB=1 python -m pytest tests -m gpu) and are deselected otherwise (tests/conftest.py).
 from videoitg_amd import _lib as _L   # noqa: E402
 PROF = _L.PROFILING
-research_only = pytest.mark.skipif(not PROF, reason="research knob / variant: profiling library only (VITG_PROFILING_LIB=1)")
+research_only = pytest.mark.research       # tests/conftest.py deselects these against the product library
 
 
 def R(*values, id=None):

@@ -8,8 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("VITG_PROFILING_LIB", "0") in ("", "0"), reason="profiling library not selected")]
+pytestmark = [pytest.mark.gpu, pytest.mark.research]      # (tests/conftest.py deselects the module unless VITG_PROFILING_LIB=1)
 
 DTYPES = [torch.bfloat16, torch.float16]
 EPS16 = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
