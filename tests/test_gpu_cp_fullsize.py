@@ -31,24 +31,39 @@ def _mod():
     return mod
 
 
-@pytest.fixture(scope="module")
-def single_gpu():
-    torch.cuda.empty_cache()
-    return _mod().single_gpu_logits(CASE)
+_SINGLE = {}
 
 
-@pytest.mark.parametrize("world", [8, 4, 2])
-def test_context_parallel_full_size_meets_oracle(world, single_gpu):
+def single_gpu(case):
+    """the one-GPU forward of a fixture's video (computed once per case)"""
+    if case not in _SINGLE:
+        torch.cuda.empty_cache()
+        _SINGLE[case] = _mod().single_gpu_logits(case)
+    return _SINGLE[case]
+
+
+# the headline video at 8 / 4 / 2 ranks; the reference-native 384^2 shape (27 x 27 grid, no position-table interpolation) at 8 ranks; the
+# LLM-heavy 64-frame video (16 x 16 pooled grid, N = 16 444: 4 096 + rows per rank) at 4 ranks
+@pytest.mark.parametrize("world,case", [(8, CASE), (4, CASE), (2, CASE), (8, "b0_512x384"), (4, "c1_64x384")])
+def test_context_parallel_full_size_meets_oracle(world, case):
     mod = _mod()
+    rec = mod.load_case(case)
+    ref1 = single_gpu(case)
     torch.cuda.empty_cache()
-    got, forms = mod.run(world, CASE, port=29560 + world)
-    rep = mod.report(CASE, got, single_gpu)
-    print(f"context-parallel x{world} at 512 x 448^2, full model: {rep}; rows per rank {forms['n_local']}; split-K shapes {forms['splitk']}")
-    assert got.shape == (512,) and torch.isfinite(got).all()
+    got, forms = mod.run(world, case, port=29560 + world + (0 if case == CASE else 20 if case.startswith("b0") else 40))
+    rep = mod.report(case, got, ref1)
+    print(f"context-parallel x{world} on {case}, full model: {rep}; rows per rank {forms['n_local']}; split-K shapes {forms['splitk']}")
+    assert got.shape == (rec["frames"],) and torch.isfinite(got).all()
     assert rep["max_abs_dscore_vs_oracle"] <= SCORE_TOL, rep
-    assert rep["top32_set_match"], rep
+    gap = rec["gap_k_k1"]
+    # the headline video: Top-32 set identical (VERDICT r3 item 1; holds because the error is 3e-4 against a rank-32/33 gap of 1.56e-3); the other
+    # fixtures: identical wherever the oracle's own rank-K / K+1 gap exceeds twice the tolerance, else at most one frame swapped at the boundary
+    if case == CASE or gap is None or gap > 2 * SCORE_TOL:
+        assert rep[f"top{rec['k']}_set_match"], rep
+    else:
+        assert rep[f"top{rec['k']}_kept"] >= rec["k"] - 1, rep
     assert rep["max_abs_dlogit_vs_single_gpu"] <= LOGIT_TOL_VS_SINGLE, rep
-    if world == 8:
+    if world == 8 and case == CASE:
         # the few-tile forms really ran on rank 0 (M = 1600 rows): o and down projections on split-K
         ks = {s[0][2] for s in forms["splitk"]}
         assert 3584 in ks and 18944 in ks, forms
@@ -61,7 +76,7 @@ def test_context_parallel_full_size_fp8_llm_mlp():
     mod = _mod()
     torch.cuda.empty_cache()
     got, forms = mod.run(8, CASE, fp8=FP8_POLICY, port=29571)
-    single = mod.single_gpu_logits(CASE, fp8=FP8_POLICY)
+    single = mod.single_gpu_logits(CASE, fp8=FP8_POLICY)      # (the fp8 tier's own one-GPU forward)
     rep = mod.report(CASE, got, single)
     print(f"context-parallel x8 fp8 {FP8_POLICY}: {rep}")
     assert torch.isfinite(got).all()
