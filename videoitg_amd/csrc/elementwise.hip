@@ -165,7 +165,8 @@ __global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* _
 
 // LayerNorm over 16-bit rows (the tower's 16-bit residual stream, round 3: the reference's own arithmetic - model.half(),
 // /root/reference/eagle/model/builder.py:59) -> 16-bit rows of the same type: 2 B read + 2 B written per element instead of 4 + 2.  One wave per row, 8 elements (16 B) per lane and chunk, row in registers, fp32 statistics, next row prefetched.
-template <typename T, int NV, bool PF>
+// NTM (experiment builds only, VITG_EXP_LN_NT): bit0 = non-temporal loads of the stream rows, bit1 = non-temporal stores of the normalised rows
+template <typename T, int NV, bool PF, int NTM = 0>
 __global__ void ln16_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bia,
                             T* __restrict__ out, int ldo, long M, int D, float eps) {
     typedef typename T16<T>::vec8 vec8;
@@ -179,7 +180,7 @@ __global__ void ln16_kernel(const T* __restrict__ x, int ldx, const float* __res
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 8;
-            if (c < D) dst[i] = *(const vec8*)(xr + c);
+            if (c < D) dst[i] = (NTM & 1) ? __builtin_nontemporal_load((const vec8*)(xr + c)) : *(const vec8*)(xr + c);
             else dst[i] = vec8{};
         }
     };
@@ -220,7 +221,8 @@ __global__ void ln16_kernel(const T* __restrict__ x, int ldx, const float* __res
                     o[e + 4] = T16<T>::from_f32((f[i][e + 4] - mean) * rstd * w1[e] + b1[e]);
                 }
             }
-            *(vec8*)(out + row * ldo + c) = o;
+            if constexpr ((NTM & 2) != 0) __builtin_nontemporal_store(o, (vec8*)(out + row * ldo + c));
+            else *(vec8*)(out + row * ldo + c) = o;
         }
         if constexpr (PF) {
 #pragma unroll
@@ -435,7 +437,11 @@ extern "C" int vitg_patchify(const void* pix, int pix_dtype, void* out, int T, i
     // coalesced whole-row form when pixel rows are 16-B granular (every production resolution: 384, 448, 224 ...); the per-element kernel
     // below keeps the odd sizes of the test fixtures (62, 70)
     const size_t rows_lds = (size_t)3 * patch * R * 2;
-    static const bool per_element = [] { const char* e = getenv("VITG_PATCHIFY_ROWS"); return e && atoi(e) == 0; }();      // A/B knob
+#if VITG_PROFILING_BUILD || defined(VITG_EXP)
+    static const bool per_element = [] { const char* e = getenv("VITG_PATCHIFY_ROWS"); return e && atoi(e) == 0; }();      // A/B knob (profiling / experiment builds)
+#else
+    constexpr bool per_element = false;
+#endif
     if (R % 8 == 0 && Kpad % 8 == 0 && rows_lds <= 64 * 1024 && !per_element) {
         dim3 rblk(256), rgrid((unsigned)(T * G));
 #define PR(TI, TO) hipLaunchKernelGGL((patchify_rows_kernel<TI, TO>), rgrid, rblk, rows_lds, s, (const TI*)pix, (TO*)out, R, patch, G, Kpad)
@@ -466,7 +472,12 @@ static int norm_dispatch(const float* x, int ldx, const float* w, const float* b
     if (ldo < D) return VITG_ERR_SHAPE;
     const int need = ceil_div(ldo, 256);
     const long want = (M + 3) / 4;
-    static const int cap = [] { const char* e = getenv("VITG_NORM_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16384; }();   // A/B knob; 16384 blocks measured 5-6 % faster than 4096 (0.757 -> 0.710 ms on the ViT LN), +0.5 % on the step
+    // 16384 blocks measured 5-6 % faster than 4096 (0.757 -> 0.710 ms on the ViT LN), +0.5 % on the step; VITG_NORM_GRID: A/B knob of the profiling / experiment builds
+#if VITG_PROFILING_BUILD || defined(VITG_EXP)
+    static const int cap = [] { const char* e = getenv("VITG_NORM_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16384; }();
+#else
+    constexpr int cap = 16384;
+#endif
     dim3 blk(256), grid((unsigned)(want < cap ? want : cap));     // rows grid-strided over the resident waves
     const int of32 = out_dtype == DT_F32;
 #define NK(TO, NV) do { if (want > cap) hipLaunchKernelGGL((norm_kernel<TO, RMS, NV, true>), grid, blk, 0, s, x, ldx, w, b, out, ldo, of32, M, D, eps); \
@@ -494,9 +505,15 @@ extern "C" int vitg_layernorm16(const void* x, int ldx, const float* w, const fl
     if (D % 8 || ldo % 8 || ldx % 8) return VITG_ERR_ALIGN;
     if (ldo < D) return VITG_ERR_SHAPE;
     const int need = ceil_div(ldo, 512);
-    // (VITG_LN16_CAP / VITG_LN16_BLOCK: A/B knobs for the grid cap and the block size; defaults measured, profiles/r03_residual16.md)
+    // (VITG_LN16_CAP / VITG_LN16_BLOCK: A/B knobs for the grid cap and the block size - profiling / experiment builds only; defaults measured,
+    // profiles/r03_residual16.md)
+#if VITG_PROFILING_BUILD || defined(VITG_EXP)
     static const long cap_env = [] { const char* e = getenv("VITG_LN16_CAP"); return e ? atol(e) : 0L; }();
     static const int blk_env = [] { const char* e = getenv("VITG_LN16_BLOCK"); return e ? atoi(e) : 0; }();
+#else
+    constexpr long cap_env = 0;
+    constexpr int blk_env = 0;
+#endif
     const int threads = (blk_env == 128 || blk_env == 512 || blk_env == 1024) ? blk_env : 256;
     const int wpb = threads / 64;
     const long want = (M + wpb - 1) / wpb;
@@ -506,6 +523,15 @@ extern "C" int vitg_layernorm16(const void* x, int ldx, const float* w, const fl
 #define LK(T, NV) do { if (want > cap) hipLaunchKernelGGL((ln16_kernel<T, NV, true>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); \
                         else hipLaunchKernelGGL((ln16_kernel<T, NV, false>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); } while (0)
 #define LKS(T) do { if (need <= 1) LK(T, 1); else if (need <= 3) LK(T, 3); else if (need <= 8) LK(T, 8); else return VITG_ERR_SHAPE; } while (0)
+#ifdef VITG_EXP   // experiment build: cache-policy A/B of the tower-size launch (fp16, NV = 3, grid-strided)
+    static const int nt_env = [] { const char* e = getenv("VITG_EXP_LN_NT"); return e ? atoi(e) : 0; }();
+    if (nt_env && dtype == DT_F16 && need > 1 && need <= 3 && want > cap) {
+        if (nt_env == 1) hipLaunchKernelGGL((ln16_kernel<f16_t, 3, true, 1>), grid, blk, 0, s, (const f16_t*)x, ldx, w, b, (f16_t*)out, ldo, M, D, eps);
+        else if (nt_env == 2) hipLaunchKernelGGL((ln16_kernel<f16_t, 3, true, 2>), grid, blk, 0, s, (const f16_t*)x, ldx, w, b, (f16_t*)out, ldo, M, D, eps);
+        else hipLaunchKernelGGL((ln16_kernel<f16_t, 3, true, 3>), grid, blk, 0, s, (const f16_t*)x, ldx, w, b, (f16_t*)out, ldo, M, D, eps);
+        return CHECK_LAUNCH();
+    }
+#endif
     if (dtype == DT_F16) LKS(f16_t); else if (dtype == DT_BF16) LKS(bf16_t); else return VITG_ERR_DTYPE;
 #undef LKS
 #undef LK

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
             const int m = m0 + min(R, g.M - 1 - m0);
             const int t = m / g.pt_P, rem = m - t * g.pt_P, py = rem / g.pt_G, px = rem - py * g.pt_G;
             const int sc = dslot ^ ((R >> 1) & 7);       // source chunk 0..7 of the 128-B row: pair sc >> 1, half sc & 1
-            a_cur[j] = (unsigned)(((t * 3 * g.pt_R + py * g.pt_p) * g.pt_R + px * g.pt_p + (sc & 1) * (g.pt_p - 8)) * 2);
+            a_cur[j] = (unsigned)((t * 3 * g.pt_R + py * g.pt_p) * g.pt_R + px * g.pt_p + (sc & 1) * (g.pt_p - 8)) * 2u;   // (elements < 2^31: host check)
             a_pair[j] = sc >> 1;
         } else {
             a_cur[j] = ((unsigned)(min(R, g.M - 1 - m0) * g.lda) + (unsigned)((dslot ^ ((R >> 1) & 7)) << 3)) * 2u;
