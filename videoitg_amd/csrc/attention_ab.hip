@@ -57,7 +57,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, h = lane >> 5;
+#ifdef VITG_EXP
+    const int L0 = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int L = a.rev ? (int)gridDim.x - 1 - L0 : L0;
+#else
     const int L = xcd_contiguous_block(blockIdx.x, gridDim.x);
+#endif
     const int qb = L % a.nqb;
     const int hg = (L / a.nqb) % a.group;
     const int kvh = (L / (a.nqb * a.group)) % a.kv_heads;
@@ -460,6 +465,9 @@ int attention_ab_dispatch(const AttnArgs& a_, int batch, int heads, int dtype, i
 #ifdef VITG_EXP
     static const int exp_bits = [] { const char* e = getenv("VITG_EXP_ATTN"); return e ? atoi(e) : 0; }();
     a.ablate = exp_bits;
+    a.rev = exp_next_dir(1);
+#else
+    a.rev = 0;
 #endif
     const bool pv32 = form == 4;
     if (qs && form == 0 && waves == 8)
