@@ -478,7 +478,6 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    a.rev = 0;
     a.ablate = variant >> 4;             // profiling ablations (WRONG results): only in a process that set VITG_PROFILING=1
     variant &= 15;
     if (a.ablate) {

@@ -57,12 +57,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, h = lane >> 5;
-#ifdef VITG_EXP
-    const int L0 = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int L = a.rev ? (int)gridDim.x - 1 - L0 : L0;
-#else
     const int L = xcd_contiguous_block(blockIdx.x, gridDim.x);
-#endif
     const int qb = L % a.nqb;
     const int hg = (L / a.nqb) % a.group;
     const int kvh = (L / (a.nqb * a.group)) % a.kv_heads;
@@ -311,13 +306,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     };
 
     const bool group_b = wave_u >= NW / 2;
-#ifdef VITG_EXP   // experiment build only (build.sh --exp): wave-priority A/Bs, run-time bits from VITG_EXP_ATTN (tools/r04)
-#define EXP_PRIO(bit, p) do { if (a.ablate & (bit)) __builtin_amdgcn_s_setprio(p); } while (0)
-    if ((a.ablate & 2) && group_b) __builtin_amdgcn_s_setprio(1);      // static: the carried-tile group wins arbitration
-    if ((a.ablate & 8) && !group_b) __builtin_amdgcn_s_setprio(1);     // static: the in-order group wins
-#else
-#define EXP_PRIO(bit, p) do {} while (0)
-#endif
     f32x16 s[2];
     vec8 p[4];
     if constexpr (LSUM) {                    // the constant pad chunk of the 3 x 64 V rows
@@ -354,16 +342,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         for (int t = 0; t < nkt; ++t) {
             const int vb_next = vb_cur == 2 ? 0 : vb_cur + 1;
             issue_next(t, vb_next);
-            EXP_PRIO(1, 1);
             qk_mfma(t & 1, s);
             mask_tail(t, s);
             __builtin_amdgcn_sched_barrier(0);
-            EXP_PRIO(1, 0); EXP_PRIO(4, 1);
             softmax(s, p);
             __builtin_amdgcn_sched_barrier(0);
-            EXP_PRIO(4, 0); EXP_PRIO(1, 1);
             pv_mfma(vb_cur, p);
-            EXP_PRIO(1, 0);
             vb_cur = vb_next;
             __syncthreads();                               // drains vmcnt too: tile t+1 has landed
         }
@@ -373,17 +357,13 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
             const int vb_next = vb_cur == 2 ? 0 : vb_cur + 1;
             issue_next(t, vb_next);
             if (t > 0) {
-                EXP_PRIO(4, 1);
                 softmax(s, p);                             // scores of tile t-1, carried across the barrier
                 __builtin_amdgcn_sched_barrier(0);
-                EXP_PRIO(4, 0); EXP_PRIO(1, 1);
                 pv_mfma(vb_prev, p);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            EXP_PRIO(1, 1);
             qk_mfma(t & 1, s);
             mask_tail(t, s);
-            EXP_PRIO(1, 0);
             vb_prev = vb_cur;
             vb_cur = vb_next;
             __syncthreads();
@@ -460,15 +440,7 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
 // form (attn_ab): 0 default | 4 PV on 32x32x16 (round 2) | 5 PV on 16x16x32 with the row sums on the VALU (round 3 before the row-sum column)
 // qs: Q arrives pre-multiplied by scale * log2(e) (a.scale_log2e == 1) and the default form may take the scores straight from the matrix pipe;
 // form 6 = pre-scaled Q WITHOUT that (the multiply by 1 and the max subtraction stay on the VALU: A/B)
-int attention_ab_dispatch(const AttnArgs& a_, int batch, int heads, int dtype, int waves, int form, bool qs, hipStream_t s) {
-    AttnArgs a = a_;
-#ifdef VITG_EXP
-    static const int exp_bits = [] { const char* e = getenv("VITG_EXP_ATTN"); return e ? atoi(e) : 0; }();
-    a.ablate = exp_bits;
-    a.rev = exp_next_dir(1);
-#else
-    a.rev = 0;
-#endif
+int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, bool qs, hipStream_t s) {
     const bool pv32 = form == 4;
     if (qs && form == 0 && waves == 8)
         return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, true, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, true, true>(a, batch, heads, s);

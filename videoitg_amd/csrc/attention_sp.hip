@@ -354,10 +354,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     typedef std::true_type Y;
     typedef std::false_type N;
 
-#ifdef VITG_EXP   // experiment build only: static wave priority for the second-dispatched half (MI355X_MICROARCH.md "two waves per SIMD" item 4)
-    if ((a.ablate & 0x100) && wave_u >= NW / 2) __builtin_amdgcn_s_setprio(1);
-    if ((a.ablate & 0x200) && wave_u < NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     // ---- prologue: K(0), K(1) in flight; S(0) computed without overlap ----------------------------------------------------
     issue_k(0, 0);
     if (nkt > 1) issue_k(1, 1);
@@ -446,12 +442,7 @@ static int launch_sp(AttnArgs a, int batch, int heads, hipStream_t s) {
 // called by vitg_attention (attention.hip).  pv16 (attn_sp = 3, hd 128 with 8 waves): PV on v_mfma_f32_16x16x32 - built, bit-for-bit tested and
 // measured 3-4 % SLOWER than PV on 32x32x16 here (2.50-2.54 against 2.43 ms on the LLM shape, profiles/r03_attention.md): there is no padding to drop
 // at hd 128, the 16x16 shape issues at ~17 instead of 16 cycles and the re-layout adds 16 swaps to a hand-interleaved stream.  Opt-in, not the default.
-int attention_sp_dispatch(const AttnArgs& a_, int batch, int heads, int head_dim, int dtype, int nw, bool pv16, hipStream_t s) {
-    AttnArgs a = a_;
-#ifdef VITG_EXP
-    static const int exp_bits = [] { const char* e = getenv("VITG_EXP_ATTN"); return e ? atoi(e) : 0; }();
-    a.ablate = exp_bits & 0x300;           // (bits 0-4 of `ablate` are this file's profiling ablations)
-#endif
+int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv16, hipStream_t s) {
 #if !VITG_PROFILING_BUILD
     // PRODUCT library: head dim 128 only (the hd-72 form and PV on 16x16x32 lost their A/Bs: profiling library)
     (void)pv16;

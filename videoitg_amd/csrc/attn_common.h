@@ -17,7 +17,6 @@ struct AttnArgs {
     int kv_heads, nqb;               // kv heads, q-blocks per head
     int ablate;                      // profiling only (tools/attn_ablate.py): bit0 no QK^T, bit1 no exp, bit2 no PV, bit3 no K/V staging
     float scale_log2e;               // softmax scale * log2(e)
-    int rev;                         // experiment builds: walk the block list backwards (serpentine launch order)
 };
 
 // first statement of every attention kernel: adopt the device-side key count (wave-uniform scalar load)

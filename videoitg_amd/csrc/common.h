@@ -144,12 +144,6 @@ struct Tuning {
     // 5 VALU row sums | 6 pre-scaled Q without the shift column; attn_sp 1 forced on for both head sizes | 3 hd 128 with PV on 16x16x32 (3-4 % slower)
 };
 Tuning& tuning();
-#ifdef VITG_EXP
-// experiment build (VITG_EXP_SERP): "serpentine" launch order - successive launches of the tower's big kernels walk their tile / block lists in
-// alternating directions, so that a kernel starts on the rows its predecessor wrote LAST (still in the 256 MiB Infinity Cache).  bit0: GEMMs and
-// the hd-72 attention, bit1: the 16-bit LayerNorm too.  exp_next_dir(kind_bit) returns this launch's direction (0 ascending / 1 descending).
-int exp_next_dir(int kind_bit);
-#endif
 #if VITG_PROFILING_BUILD
 #define RESEARCH(field) (::vitg::tuning().field)
 #else

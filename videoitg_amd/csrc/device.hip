@@ -44,15 +44,6 @@ Tuning& tuning() {
     }();
     return t;
 }
-#ifdef VITG_EXP
-int exp_next_dir(int kind_bit) {
-    static const int serp = env_int("VITG_EXP_SERP");
-    static int dir = 0;
-    if (!(serp & kind_bit)) return 0;
-    dir ^= 1;
-    return dir;
-}
-#endif
 }  // namespace vitg
 
 extern "C" int vitg_set_option(const char* key, int value) {

@@ -165,46 +165,21 @@ __global__ void norm_kernel(const float* __restrict__ x, int ldx, const float* _
 
 // LayerNorm over 16-bit rows (the tower's 16-bit residual stream, round 3: the reference's own arithmetic - model.half(),
 // /root/reference/eagle/model/builder.py:59) -> 16-bit rows of the same type: 2 B read + 2 B written per element instead of 4 + 2.  One wave per row, 8 elements (16 B) per lane and chunk, row in registers, fp32 statistics, next row prefetched.
-// NTM (experiment builds only, VITG_EXP_LN_NT): bit0 = non-temporal loads of the stream rows, bit1 = non-temporal stores of the normalised rows
-template <typename T, int NV, bool PF, int NTM = 0>
-#ifdef VITG_EXP
-#define LN16_ORDER_PARAM , int order
-#define LN16_ORDER_ARG(v) , v
-#else
-#define LN16_ORDER_PARAM
-#define LN16_ORDER_ARG(v)
-#endif
+template <typename T, int NV, bool PF>
 __global__ void ln16_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bia,
-                            T* __restrict__ out, int ldo, long M, int D, float eps LN16_ORDER_PARAM) {
+                            T* __restrict__ out, int ldo, long M, int D, float eps) {
     typedef typename T16<T>::vec8 vec8;
     const int lane = threadIdx.x & 63;
     const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
     long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
     vec8 v[NV], nx[PF ? NV : 1];
-#ifdef VITG_EXP
-    // experiment (serpentine launch order): order 0 = rows in launch order, 1 = every XCD sweeps its own eighth of the rows upwards, 2 = downwards
-    // (blocks b, b + 8, .. sit on XCD b % 8); the launcher passes 1 / 2 only when M divides by 8 x waves per block
-    auto phys = [&](long r) -> long {
-        if (order == 0) return r;
-        const long wpb = blockDim.x >> 6, blk = r / wpb, w = r - blk * wpb;       // logical block / wave of this row index
-        const long slab = blk & 7, j = blk >> 3, per = (M + 7) / 8;
-        long pr = j * wpb + w;                                                      // position inside the slab
-        if (pr >= per) return -1;
-        if (order == 2) pr = per - 1 - pr;
-        const long out_r = slab * per + pr;
-        return out_r < M ? out_r : -1;
-    };
-#else
-    auto phys = [&](long r) -> long { return r; };
-#endif
-    auto load_row = [&](auto& dst, long r_) {
-        const long r = phys(r_) < 0 ? 0 : phys(r_);
+    auto load_row = [&](auto& dst, long r) {
         const T* xr = x + r * ldx;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 8;
-            if (c < D) dst[i] = (NTM & 1) ? __builtin_nontemporal_load((const vec8*)(xr + c)) : *(const vec8*)(xr + c);
+            if (c < D) dst[i] = *(const vec8*)(xr + c);
             else dst[i] = vec8{};
         }
     };
@@ -245,10 +220,7 @@ __global__ void ln16_kernel(const T* __restrict__ x, int ldx, const float* __res
                     o[e + 4] = T16<T>::from_f32((f[i][e + 4] - mean) * rstd * w1[e] + b1[e]);
                 }
             }
-            const long prow = phys(row);
-            if (prow < 0) continue;
-            if constexpr ((NTM & 2) != 0) __builtin_nontemporal_store(o, (vec8*)(out + prow * ldo + c));
-            else *(vec8*)(out + prow * ldo + c) = o;
+            *(vec8*)(out + row * ldo + c) = o;
         }
         if constexpr (PF) {
 #pragma unroll
@@ -463,7 +435,7 @@ extern "C" int vitg_patchify(const void* pix, int pix_dtype, void* out, int T, i
     // coalesced whole-row form when pixel rows are 16-B granular (every production resolution: 384, 448, 224 ...); the per-element kernel
     // below keeps the odd sizes of the test fixtures (62, 70)
     const size_t rows_lds = (size_t)3 * patch * R * 2;
-#if VITG_PROFILING_BUILD || defined(VITG_EXP)
+#if VITG_PROFILING_BUILD
     static const bool per_element = [] { const char* e = getenv("VITG_PATCHIFY_ROWS"); return e && atoi(e) == 0; }();      // A/B knob (profiling / experiment builds)
 #else
     constexpr bool per_element = false;
@@ -499,7 +471,7 @@ static int norm_dispatch(const float* x, int ldx, const float* w, const float* b
     const int need = ceil_div(ldo, 256);
     const long want = (M + 3) / 4;
     // 16384 blocks measured 5-6 % faster than 4096 (0.757 -> 0.710 ms on the ViT LN), +0.5 % on the step; VITG_NORM_GRID: A/B knob of the profiling / experiment builds
-#if VITG_PROFILING_BUILD || defined(VITG_EXP)
+#if VITG_PROFILING_BUILD
     static const int cap = [] { const char* e = getenv("VITG_NORM_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16384; }();
 #else
     constexpr int cap = 16384;
@@ -533,7 +505,7 @@ extern "C" int vitg_layernorm16(const void* x, int ldx, const float* w, const fl
     const int need = ceil_div(ldo, 512);
     // (VITG_LN16_CAP / VITG_LN16_BLOCK: A/B knobs for the grid cap and the block size - profiling / experiment builds only; defaults measured,
     // profiles/r03_residual16.md)
-#if VITG_PROFILING_BUILD || defined(VITG_EXP)
+#if VITG_PROFILING_BUILD
     static const long cap_env = [] { const char* e = getenv("VITG_LN16_CAP"); return e ? atol(e) : 0L; }();
     static const int blk_env = [] { const char* e = getenv("VITG_LN16_BLOCK"); return e ? atoi(e) : 0; }();
 #else
@@ -546,26 +518,9 @@ extern "C" int vitg_layernorm16(const void* x, int ldx, const float* w, const fl
     const long cap = cap_env > 0 ? cap_env : 16384;
     dim3 blk(threads), grid((unsigned)(want < cap ? want : cap));
     hipStream_t s = (hipStream_t)stream;
-#ifdef VITG_EXP
-    // serpentine launch order (VITG_EXP_SERP bit1): the XCD-slab sweep, direction alternating with the other big kernels of the tower
-    int ln_order = 0;
-    {
-        static const int serp = [] { const char* e = getenv("VITG_EXP_SERP"); return e ? atoi(e) : 0; }();
-        if ((serp & 2) && want > cap && M % (8 * wpb) == 0 && (grid.x % 8) == 0) ln_order = exp_next_dir(2) ? 2 : 1;
-    }
-#endif
-#define LK(T, NV) do { if (want > cap) hipLaunchKernelGGL((ln16_kernel<T, NV, true>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps LN16_ORDER_ARG(ln_order)); \
-                        else hipLaunchKernelGGL((ln16_kernel<T, NV, false>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps LN16_ORDER_ARG(0)); } while (0)
+#define LK(T, NV) do { if (want > cap) hipLaunchKernelGGL((ln16_kernel<T, NV, true>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); \
+                        else hipLaunchKernelGGL((ln16_kernel<T, NV, false>), grid, blk, 0, s, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); } while (0)
 #define LKS(T) do { if (need <= 1) LK(T, 1); else if (need <= 3) LK(T, 3); else if (need <= 8) LK(T, 8); else return VITG_ERR_SHAPE; } while (0)
-#ifdef VITG_EXP   // experiment build: cache-policy A/B of the tower-size launch (fp16, NV = 3, grid-strided)
-    static const int nt_env = [] { const char* e = getenv("VITG_EXP_LN_NT"); return e ? atoi(e) : 0; }();
-    if (nt_env && dtype == DT_F16 && need > 1 && need <= 3 && want > cap) {
-        if (nt_env == 1) hipLaunchKernelGGL((ln16_kernel<f16_t, 3, true, 1>), grid, blk, 0, s, (const f16_t*)x, ldx, w, b, (f16_t*)out, ldo, M, D, eps, 0);
-        else if (nt_env == 2) hipLaunchKernelGGL((ln16_kernel<f16_t, 3, true, 2>), grid, blk, 0, s, (const f16_t*)x, ldx, w, b, (f16_t*)out, ldo, M, D, eps, 0);
-        else hipLaunchKernelGGL((ln16_kernel<f16_t, 3, true, 3>), grid, blk, 0, s, (const f16_t*)x, ldx, w, b, (f16_t*)out, ldo, M, D, eps, 0);
-        return CHECK_LAUNCH();
-    }
-#endif
     if (dtype == DT_F16) LKS(f16_t); else if (dtype == DT_BF16) LKS(bf16_t); else return VITG_ERR_DTYPE;
 #undef LKS
 #undef LK

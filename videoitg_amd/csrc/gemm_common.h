@@ -46,7 +46,6 @@ struct GemmArgs {
     // [T, 3, R, R] (16-bit, NCHW), row m = (frame, py, px) reads its p x p x 3 patch straight from there
     int pt_R, pt_G, pt_P;     // image side, patches per side (R / p), patches per frame (G * G); pt_R == 0: off
     int pt_p, pt_pairs;       // patch side p (8..16), (channel, ky) pairs = 3 p
-    int rev;                  // experiment builds: walk the tile list backwards (serpentine launch order, common.h exp_next_dir)
 };
 
 enum { MODE_STORE16 = 0, MODE_F32 = 1, MODE_SWIGLU = 2 };

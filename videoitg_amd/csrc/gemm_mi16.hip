@@ -108,11 +108,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     const int wr = wave / WN, wc = wave % WN;
     int tm, tn;
     if constexpr (SK) { const int t = sk_t0 + vb; tm = t % g.tiles_m; tn = t / g.tiles_m; }
-#ifdef VITG_EXP
-    else block_to_tile(g.rev ? nwg_ - 1 - vb : vb, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
-#else
     else block_to_tile(vb, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
-#endif
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA assignment (as gemm256.hip): one instruction = 8 rows x 128 B; lane -> (row = lane / 8, LDS chunk slot = lane % 8);
@@ -156,14 +152,9 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
             }
         }
         asm volatile("" : "+v"(off));                    // keeps base + offset in the saddr form (no per-lane 64-bit pointer)
-#ifdef VITG_EXP_NT_A      // experiment build: the activation operand streams through the L2 non-temporally (the weight panel is what should stay)
-        constexpr int A_AUX = 2;
-#else
-        constexpr int A_AUX = 0;
-#endif
         if (j < A_INSTR)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ka + off),
-                                             (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, A_AUX);
+                                             (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + j) * 1024), 16, 0, 0);
         else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kw + off),
                                              (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * W_INSTR + j - A_INSTR) * 1024), 16, 0, 0);
@@ -511,9 +502,6 @@ static int launch16(GemmArgs g, hipStream_t s) {
         if (cur_dev < 16) cus_dev[cur_dev] = cus;
     }
     const int nwg = g.tiles_m * g.tiles_n;
-#ifdef VITG_EXP
-    g.rev = exp_next_dir(1);
-#endif
     // one block per CU walking the tile list when there are at least two tiles per CU (gemm256.hip: "software relaunch")
     const bool loop = nwg >= 2 * cus && !(RESEARCH(gemm_flags) & 0x1000000);
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
@@ -591,9 +579,6 @@ static int launch16_patch(GemmArgs g, hipStream_t s) {
     g.tiles_n = ceil_div(g.N, BN);
     g.group_m = 4;
     const int cus = device_cu_count(cur_dev), nwg = g.tiles_m * g.tiles_n;
-#ifdef VITG_EXP
-    g.rev = exp_next_dir(1);
-#endif
     hipLaunchKernelGGL((gemm16_kernel<T, MODE_RES16, BM, BN, false, 2, true>), dim3(nwg >= 2 * cus ? cus : nwg), dim3(G16_THREADS), lds, s, g);
     return (int)hipGetLastError();
 }
