@@ -63,7 +63,7 @@ def worker(rank: int, world: int, port: int, case: str, fp8, q) -> None:
             # which launch forms this rank took (the point of the test is that the few-tile / split forms ran): plans cached by the engine
             forms = {"splitk": sorted({(k, v[1]) for k, v in eng._splitk.items() if v[0] == "split" and v[1] > 1}),
                      "n_local": cp._gatherers[next(iter(cp._gatherers))].plan.n_local}
-            q.put((out.float().cpu(), forms))
+            q.put((out.float().cpu().tolist(), forms))     # by value: a tensor would travel as a shared-memory fd that dies with this process
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -78,6 +78,7 @@ def run(world: int = 8, case: str = "c2_512x448", fp8=None, port: int = 29561, t
         p.start()
     try:
         got, forms = q.get(timeout=timeout)
+        got = torch.tensor(got, dtype=torch.float32)
     finally:
         for p in procs:
             p.join(timeout)

@@ -44,7 +44,7 @@ def worker(rank, world, frames, port, q, fp8=False):
         assert torch.equal(whole, out)
         torch.cuda.synchronize()
         if rank == 0:
-            q.put(out.float().cpu())
+            q.put(out.float().cpu().tolist())      # by value: a tensor would travel as a shared-memory fd that dies with this process
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -56,7 +56,7 @@ def run(world=2, frames=9, port=29533, fp8=False):
     procs = [ctx.Process(target=worker, args=(r, world, frames, port, q, fp8)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=600)
+    got = torch.tensor(q.get(timeout=600), dtype=torch.float32)
     for p in procs:
         p.join(600)
         assert p.exitcode == 0, p.exitcode
