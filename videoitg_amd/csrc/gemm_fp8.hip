@@ -54,12 +54,17 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
     constexpr int A_BYTES = BM * F8_ROWB, W_BYTES = BN * F8_ROWB, STAGE = A_BYTES + W_BYTES;
     constexpr int A_INSTR = A_BYTES / 1024 / 8, W_INSTR = W_BYTES / 1024 / 8, LPT = A_INSTR + W_INSTR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // one block per CU walking the tile list when the launcher found at least two tiles per CU (round 4; as gemm_mi16.hip): gridDim.x < tiles
+    const int nwg_ = g.tiles_m * g.tiles_n;
+    for (int vb = (int)blockIdx.x; vb < nwg_; vb += (int)gridDim.x) {
+    // per-lane quantities re-derived from an opaque copy of the thread id in every pass (hoisted they would stay live through the loop)
     int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
     int tm, tn;
-    block_to_tile(blockIdx.x, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    block_to_tile(vb, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- LDS-DMA: one instruction = 8 rows x 128 B; lane -> (row = lane / 8, slot = lane % 8); XOR swizzle on the SOURCE chunk
@@ -334,6 +339,11 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
         static_assert(8 * STAGE_BYTES <= F8_STAGES * STAGE, "16-bit staging must fit in the ring");
         epilogue_staged<T, MODE, MT, NT>(g, acc, smem + wave * STAGE_BYTES, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
     }
+    // the next tile's first DMA stage overwrites the staging windows: every wave's LDS reads of this tile have to be retired first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    }   // tile loop
 }
 
 template <typename T, int MODE, int BM, int BN, bool MXA = false, bool MXO = false>
@@ -348,7 +358,11 @@ static int launch_fp8(Gemm8Args ga, hipStream_t s) {
     ga.g.tiles_m = ceil_div(ga.g.M, BM);
     ga.g.tiles_n = ceil_div(ga.g.N, BN);
     ga.g.group_m = RESEARCH(gemm_group) > 0 ? RESEARCH(gemm_group) : 4;
-    hipLaunchKernelGGL((gemm_fp8_kernel<T, MODE, BM, BN, MXA, MXO>), dim3(ga.g.tiles_m * ga.g.tiles_n), dim3(F8_THREADS), lds, s, ga);
+    const int nwg = ga.g.tiles_m * ga.g.tiles_n, cus = device_cu_count(cur_dev);
+    // one block per CU walking the tile list when there are at least two tiles per CU (as gemm_mi16.hip; round 4: fc1 +5 %, qkv +2-4 %, the fp8 job
+    // +0.5 % against one hardware block per tile, bit-identical; profiles/r04_experiments.md section 7)
+    const bool loop = nwg >= 2 * cus;
+    hipLaunchKernelGGL((gemm_fp8_kernel<T, MODE, BM, BN, MXA, MXO>), dim3(loop ? cus : nwg), dim3(F8_THREADS), lds, s, ga);
     return (int)hipGetLastError();
 }
 
