@@ -76,3 +76,18 @@ def test_product_library_ships_no_research_scaffolding():
         for f in fs:
             if f.endswith(".py") and f != "_lib.py":
                 assert "libvideoitg_hip_prof" not in open(os.path.join(dp, f)).read(), f
+
+
+def test_alternative_library_path_is_confined_to_experiment_builds_of_this_library():
+    """VITG_LIB_PATH (A/B measurements of csrc/build.sh --exp builds) accepts only libvideoitg_hip_exp_<NAME>.so next to the product library"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for bad in ("/tmp/libvideoitg_hip_exp_x.so", os.path.join(root, "videoitg_amd", "libsomething.so")):
+        r = subprocess.run([sys.executable, "-c", "import videoitg_amd._lib"], env={**os.environ, "VITG_LIB_PATH": bad, "PYTHONPATH": root},
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "VITG_LIB_PATH must name" in r.stderr
+    ok = os.path.join(root, "videoitg_amd", "libvideoitg_hip_exp_doesnotexist.so")
+    r = subprocess.run([sys.executable, "-c", "import videoitg_amd._lib as l; print(l.LIB_PATH)"], env={**os.environ, "VITG_LIB_PATH": ok, "PYTHONPATH": root},
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == ok          # (selecting is allowed; loading a missing file then fails loudly in load())

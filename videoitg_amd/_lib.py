@@ -16,7 +16,11 @@ LIB_PATH = os.path.join(_HERE, "libvideoitg_hip_prof.so" if PROFILING else "libv
 # A/B measurements of experiment builds (csrc/build.sh --exp NAME; tools/r04): an explicit path to another build of the SAME C ABI.  Still no
 # fallback - if the named file is missing, load() raises.
 if os.environ.get("VITG_LIB_PATH"):
-    LIB_PATH = os.path.abspath(os.environ["VITG_LIB_PATH"])
+    _alt = os.path.abspath(os.environ["VITG_LIB_PATH"])
+    # only another build of THIS library, sitting next to it (csrc/build.sh writes them there): not a way to load arbitrary code
+    if os.path.dirname(_alt) != _HERE or not (os.path.basename(_alt).startswith("libvideoitg_hip_exp_") and _alt.endswith(".so")):
+        raise ImportError(f"VITG_LIB_PATH must name a libvideoitg_hip_exp_<NAME>.so inside {_HERE} (csrc/build.sh --exp NAME), not {_alt}")
+    LIB_PATH = _alt
 
 BF16, F16, F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2
