@@ -198,20 +198,6 @@ int vitg_attention_dyn(const void* q, const void* k, const void* v, void* o, int
                        int k_rs, int v_rs, int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype, int variant,
                        void* stream);
 
-/* vitg_attention / vitg_attention_dyn (kv_len_dev may be NULL) with a caller-owned WORKSPACE of at least vitg_attention_ws_bytes() bytes (16-B aligned,
- * contents irrelevant before and after the call, must not be shared by calls in flight on different streams).  With it the library may cut a
- * head-dim-128 call by WORK instead of by q-block (csrc/attention_sp.hip, LEAN): the (q-block, 64-key tile) units are dealt to one block per CU in
- * equal runs, runs that hold only a key range of their q-block leave raw fp32 accumulators + (max, row sum) in the workspace and a second kernel
- * merges them in a fixed order (deterministic; results differ from the classic launch by fp32 re-association only).  Taken when the classic launch
- * would end on a thin round: the decoder's 12 860 queries x 28 heads are 1 428 blocks on 256 CUs = 6 rounds for 5.58 of work; one context-parallel
- * rank's 1 660 x 28 are 196 blocks, 60 CUs idle.  ws == NULL, a short workspace, head dim 72 or a launch that fills its rounds:
- * exactly vitg_attention / vitg_attention_dyn.  Same flash-attn call sites (grounding_qwen2.py:45-53). */
-int vitg_attention_ws_bytes(long* bytes);     /* for the current device */
-int vitg_attention_ws(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads, int S, int Sk_max,
-                      const int* kv_len_dev, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs, int v_rs,
-                      int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype, int variant, void* ws, long ws_bytes,
-                      void* stream);
-
 /* Bilinear G x G -> HW x HW token pool (align_corners=False, no antialias) of fp32 features [T*G*G, ldx] into
  * 16-bit [T*HW*HW, ldo]; HW == G is a plain cast.  cmap == NULL: x holds all G*G rows per frame; otherwise x holds Pc
  * compact rows per frame and cmap[y*G+x] is the compact row of token (y,x).  Replaces F.interpolate at mlp_proj.py:57-68. */

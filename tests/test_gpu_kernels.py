@@ -440,52 +440,6 @@ def test_attention_key_count_from_device_memory(ops, attn_waves, dtype, H, HKV, 
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H,HKV,S,Sk,real", [(28, 4, 600, 2000, None), (28, 4, 600, 2000, 1777), (28, 4, 1660, 6000, None), (4, 2, 3000, 3000, None),
-                                             (28, 4, 523, 1999, 1), (14, 2, 300, 70000, None)])
-def test_attention_cut_by_work_matches_the_classic_launch(ops, dtype, H, HKV, S, Sk, real):
-    """vitg_attention_ws (head dim 128): with a workspace the library deals the (q-block, key tile) units of a launch whose last round would be
-    thin to one block per CU in equal runs; runs that hold a key RANGE of their q-block leave fp32 partials that a second kernel merges.
-    Against the classic launch (same inputs, no workspace): fp32 re-association only - a few ulp16 of |v|; against the fp32 reference like
-    every attention test; bit-identical from run to run; the workspace is scratch (NaN-filled before the call).  `real`: key count from
-    device memory (the runs are cut from the device-side count)."""
-    D, B = 128, 1
-    q, k, v = rnd((B, H, S, D), 50, dtype=dtype), rnd((B, HKV, Sk, D), 51, dtype=dtype), rnd((B, HKV, Sk, D), 52, dtype=dtype)
-    n_keys = Sk if real is None else real
-    if n_keys > 300:
-        k[0, 0, 257] = (q[0, 0, 5] * 4).to(dtype).float()          # a spiked key: the runs of that q-block end on different running maxima
-    if real is not None:
-        k[:, :, real:] = 1e4
-    qf = q.permute(0, 2, 1, 3).reshape(B * S, H * D).to(dtype).cuda().contiguous()
-    kvw = 2 * HKV * D
-    kv = torch.cat([k.permute(0, 2, 1, 3).reshape(B, Sk, HKV * D), v.permute(0, 2, 1, 3).reshape(B, Sk, HKV * D)], -1).to(dtype).cuda().contiguous().view(B * Sk, kvw)
-    st = dict(batch=B, heads=H, kv_heads=HKV, seq=S, kv_seq=Sk, head_dim=D, q_strides=(S * H * D, H * D, D), k_strides=(Sk * kvw, kvw, D),
-              v_strides=(Sk * kvw, kvw, D), o_strides=(S * H * D, H * D, D), scale=D ** -0.5)
-    n = None if real is None else torch.tensor([real], dtype=torch.int32, device="cuda")
-    classic = torch.zeros((S, H * D), dtype=dtype, device="cuda")
-    ops.attention(qf, kv, kv[:, HKV * D:], classic, kv_len=n, **st)
-    nbytes = ops.attention_ws_bytes()
-    assert nbytes > 0
-    outs = []
-    for fill in (0x7f, 0xff):                                      # 0x7f7f7f7f / 0xffffffff: large / NaN floats wherever a stale slot would be read
-        ws = torch.full((nbytes,), fill, dtype=torch.uint8, device="cuda")
-        o = torch.full((S, H * D), float("nan"), dtype=dtype, device="cuda")
-        ops.attention(qf, kv, kv[:, HKV * D:], o, kv_len=n, ws=ws, **st)
-        outs.append(o)
-    assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1])
-    tol = 6 * EPS16[dtype] * v[:, :, :n_keys].abs().max().item()
-    assert (outs[0].float() - classic.float()).abs().max().item() <= tol
-    if S * n_keys <= 4_000_000:
-        want = ref_attention(q, k[:, :, :n_keys], v[:, :, :n_keys], D ** -0.5)
-        got = outs[0].float().cpu().view(1, S, H, D).permute(0, 2, 1, 3)
-        assert (got - want).abs().max().item() <= tol
-    # a short workspace is refused silently: exactly the classic launch
-    o = torch.full((S, H * D), float("nan"), dtype=dtype, device="cuda")
-    ops.attention(qf, kv, kv[:, HKV * D:], o, kv_len=n, ws=torch.empty((1024,), dtype=torch.uint8, device="cuda"), **st)
-    assert torch.equal(o, classic)
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,splits", [(1660, 3584, 3584, 2), (1660, 3584, 18944, 2), (700, 1024, 4096, 4), (300, 520, 2048, 3)])
 def test_gemm_splitk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K, splits):
     """split-K (o / down projection of one context-parallel rank): same value as the one-pass fp32-residual GEMM up to fp32

@@ -1,10 +1,11 @@
 #!/bin/bash
+# (needs the by-work attention of commit b76ba79: git apply tools/experiments/attention_by_work.patch, rebuild)
 # round 4, GPU call 16: hd-128 attention cut by WORK (vitg_attention_ws, attention_sp.hip LEAN): kernel tests, stand-alone A/B on the one-GPU and the
 # per-rank shapes, A/B inside one rank of the 8-way step and inside the one-GPU step
 set -uo pipefail
 OUT="$PWD/gpurun_out/${CALL_TAG:-r04_c16}"; mkdir -p "$OUT"
 timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "attention" > "$OUT/pytest_attention.txt" 2>&1; tail -3 "$OUT/pytest_attention.txt"
-timeout 600 python tools/attn_lean_ab.py 3 2>&1 | tee "$OUT/attn_lean_ab.txt"
+timeout 600 python tools/experiments/attn_lean_ab.py 3 2>&1 | tee "$OUT/attn_lean_ab.txt"
 for r in 1 2; do
   for v in 0 1; do
     echo "VITG_LEAN_ATTN=$v round $r"

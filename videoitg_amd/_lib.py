@@ -52,8 +52,6 @@ SIGNATURES = {
     "vitg_rope": [_p, _i, _p, _p, _l, _i, _i, _i, _p],
     "vitg_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "vitg_attention_dyn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p],
-    "vitg_attention_ws_bytes": [C.POINTER(C.c_long)],
-    "vitg_attention_ws": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _l, _p],
     "vitg_bilinear_pool": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "vitg_bilinear_pool16": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "vitg_gather_rows": [_p, _l, _p, _i, _i, _i, _p, _l, _i, _p],

@@ -458,33 +458,10 @@ int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, in
 
 using namespace vitg;
 
-// Workspace of the work-partitioned hd-128 launch (attention_sp.hip, LEAN): two slots per CU, each 256 queries x 128 fp32 accumulators +
-// (running max, row sum) per query
-static long lean_ws_bytes(int cus) { return 2L * cus * (512L * 16 * 16 + 512L * 8); }
-
-// Takes the work-partitioned launch when the caller lent a workspace and the classic launch would end on a thin round: with B blocks of 256
-// queries (or 128: two per CU) on C CUs the classic launch is r / ceil(r) busy, r = B / C - 5.58 / 6 on the decoder's 12 860 x 28 heads, 0.77
-// on one context-parallel rank's 1 660 x 28 - while equal runs keep every CU busy for r block times at the price of two run prologues and
-// the merge.  Launches that are long (r >= 16: the last round is < 6 %) or tiny (fewer than 8 key tiles per run) stay classic.
-static void lean_decide(AttnArgs& a, int batch, int heads, void* ws, long ws_bytes) {
-    a.lean_blocks = 0;
-    if (!ws) return;
-    const int cus = device_cu_count(current_device());
-    if (ws_bytes < lean_ws_bytes(cus) || ((uintptr_t)ws & 15)) return;
-    const long nq8 = (long)ceil_div(a.S, 256) * heads * batch, nq4 = (long)ceil_div(a.S, 128) * heads * batch;
-    const double r8 = (double)nq8 / cus, r4 = (double)nq4 / (2.0 * cus);
-    const double e8 = r8 / ceil(r8), e4 = r4 / ceil(r4);
-    const long nkt = ceil_div(a.Sk, ATT_BK);
-    if (r8 >= 16.0 || fmax(e8, e4) >= 0.96 || nq8 * nkt < 8L * cus) return;
-    a.lean_blocks = cus;
-    a.ws_o = (float*)ws;
-    a.ws_ml = (float*)((char*)ws + 2L * cus * (512L * 16 * 16));
-}
-
 static int attention_entry(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads,
                            int S, int Sk, const int* sk_dev, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs,
                            int v_rs, int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype,
-                           int variant, void* stream, void* ws = nullptr, long ws_bytes = 0) {
+                           int variant, void* stream) {
     if (batch <= 0 || heads <= 0 || S <= 0) return 0;
     if (Sk <= 0) return VITG_ERR_SHAPE;
     if (kv_heads <= 0 || heads % kv_heads) return VITG_ERR_SHAPE;
@@ -498,7 +475,6 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     a.q_rs = q_rs; a.k_rs = k_rs; a.v_rs = v_rs; a.o_rs = o_rs;
     a.q_hs = q_hs; a.k_hs = k_hs; a.v_hs = v_hs; a.o_hs = o_hs;
     a.S = S; a.Sk = Sk; a.sk_dev = sk_dev; a.group = heads / kv_heads; a.kv_heads = kv_heads; a.nqb = 0;
-    a.ws_o = nullptr; a.ws_ml = nullptr; a.nq_total = 0; a.lean_blocks = 0;
     a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -549,7 +525,6 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     // The variants that lost their A/B (hd-72 cross-tile pipelined loop, hd-72 software-pipelined loop, DMA staging at hd 128, 16-wave blocks, PV on
     // 32x32x16, VALU row sums, hd-128 PV on 16x16x32) are instantiated in the profiling library only.
     if (tr && head_dim == 128 && tuning().attn_sp == 0) {
-        lean_decide(a, batch, heads, ws, ws_bytes);
         rc = attention_sp_dispatch(a, batch, heads, head_dim, dtype, nw, false, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
@@ -569,7 +544,6 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     // Software-pipelined loop (attention_sp.hip): default for hd 128 (LLM shape 1023 vs 916 TF/s); for hd 72 the per-tile
     // kernel at 4 waves/SIMD is still ahead (630 vs 597 TF/s), profiles/r01_attention.md.  attn_sp = 1 / 2 pins it on / off.
     if (tr && (tuning().attn_sp == 1 || ((tuning().attn_sp == 0 || tuning().attn_sp == 3) && head_dim == 128 && !a.ablate))) {
-        if (head_dim == 128 && tuning().attn_sp == 0 && !nw_env) lean_decide(a, batch, heads, ws, ws_bytes);
         rc = attention_sp_dispatch(a, batch, heads, head_dim, dtype, nw, tuning().attn_sp == 3, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
@@ -602,21 +576,6 @@ extern "C" int vitg_attention(const void* q, const void* k, const void* v, void*
                               int variant, void* stream) {
     return attention_entry(q, k, v, o, batch, heads, kv_heads, S, Sk, nullptr, head_dim, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs,
                            q_hs, k_hs, v_hs, o_hs, scale, dtype, variant, stream);
-}
-
-extern "C" int vitg_attention_ws_bytes(long* bytes) {
-    if (!bytes) return VITG_ERR_ARG;
-    *bytes = lean_ws_bytes(device_cu_count(current_device()));
-    return 0;
-}
-
-extern "C" int vitg_attention_ws(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads, int S, int Sk_max,
-                                 const int* kv_len_dev, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs, int v_rs,
-                                 int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, int dtype, int variant, void* ws, long ws_bytes,
-                                 void* stream) {
-    if (ws && ws_bytes < 0) return VITG_ERR_ARG;
-    return attention_entry(q, k, v, o, batch, heads, kv_heads, S, Sk_max, kv_len_dev, head_dim, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs,
-                           o_rs, q_hs, k_hs, v_hs, o_hs, scale, dtype, variant, stream, ws, ws_bytes);
 }
 
 extern "C" int vitg_attention_dyn(const void* q, const void* k, const void* v, void* o, int batch, int heads, int kv_heads,

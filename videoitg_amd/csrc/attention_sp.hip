@@ -43,20 +43,10 @@ constexpr float LAZY_RESCALE_LOG2 = 8.0f;
 // interval that CONSUMES it), the V^T fragment of lane group g reads keys 32 kb + 16 (g >> 1) + 4 (g & 1) + {0..3, 8..11}.  V keeps its 256-B rows;
 // its chunk swizzle gains row bit 2 (the two lane groups of a half-wave read rows r..r+3 and r+4..r+7, which the round-2 swizzle put on the same
 // banks).  One PV "step" of the interleaved stream = one V^T fragment + its two MFMAs, so the slice structure is unchanged.
-//
-// LEAN (round 4; head dim 128, 8 waves): the launch is cut by WORK, not by q-block.  The (q-block, 64-key tile) units of the whole call are laid
-// end to end (q-block major) and cut into gridDim.x equal runs, one block per CU: a block runs the tail of one q-block, whole q-blocks, and the
-// head of another.  A run that covers all keys of its q-block normalises and stores O as before; a run that covers a key RANGE stores the raw
-// fp32 accumulators and (running max, row sum) of its queries into its workspace slot (at most two such runs per block: its first and its last)
-// and attn_lean_merge_kernel combines the slots of a q-block in block order: O = sum_i 2^(m_i - M) O_i / sum_i 2^(m_i - M) l_i - fixed order, no
-// atomics, run-to-run bit-identical.  Why: with one 256-query block per CU a launch of B blocks on C CUs takes ceil(B / C) block times - the
-// decoder's 1 428 blocks on 256 CUs run 6 rounds for 5.58 of work, one context-parallel rank's 196 blocks leave 60 CUs idle (0.77) - while equal
-// runs take B / C block times plus two prologues and the merge ("key-split attention with an LSE merge when < 1 block per CU").
-template <typename T, int D, int NW, bool PV16 = false, bool LEAN = false>
+template <typename T, int D, int NW, bool PV16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     adopt_device_key_count(a);
     static_assert(!PV16 || D == 128, "PV16 is written for head dim 128");
-    static_assert(!LEAN || (D == 128 && !PV16), "the work-partitioned launch is written for head dim 128 on the 32x32x16 PV form");
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
     constexpr int KS = C::DK / 16;           // QK^T k-steps per 32-key half
@@ -66,40 +56,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, h = lane >> 5;
-    // LEAN: this block's run of (q-block, key tile) units [u, u1); otherwise one q-block, all key tiles
-    const int nkt_all = ceil_div(a.Sk, ATT_BK);
-    long u = 0, u1 = 0, per = 1;
-    int cu = 0;
-    bool first_seg = true;
-    if constexpr (LEAN) {
-        cu = xcd_contiguous_block(blockIdx.x, gridDim.x);          // consecutive runs (q-blocks of one kv head) on one XCD
-        const long total = (long)a.nq_total * nkt_all;
-        per = (total + gridDim.x - 1) / gridDim.x;
-        u = cu * per;
-        u1 = min(u + per, total);
-        if (u >= u1) return;
-    }
-    do {
-    const int L = LEAN ? (int)(u / nkt_all) : xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int kt0 = LEAN ? (int)(u % nkt_all) : 0;                  // first tile POSITION of this run inside its q-block
-    const int nkt = LEAN ? (int)min((long)(nkt_all - kt0), u1 - u) : nkt_all;
-    const int Sk = a.Sk;
-    // LEAN: position -> key tile.  The softmax does not care in which order a q-block meets its keys, the L2 does: the 32 blocks of an XCD read
-    // the same K/V, and 6.6 MB per kv head do not fit 4 MiB - the classic launch lives on its blocks sweeping the keys in step.  Runs start at
-    // arbitrary positions of their q-blocks, so position p of q-block L is key tile (p + rho_L) mod F for the F = nkt_all - 1 whole tiles (the last
-    // tile, the one that can be partial, stays last), with rho_L = the time at which the block that OPENS q-block L reaches it: every block that
-    // opens a q-block is then at key tile (time since launch) mod F, whatever its run looks like, and the blocks that start by finishing
-    // somebody else's q-block form one second sweep (offset per mod F) - two sweeps through the L2 instead of 32 (measured: profiles/r04_experiments.md 11).
-    const int Fw = nkt_all - 1;
-    int rho = 0;
-    if constexpr (LEAN) {
-        if (Fw > 0) { const long s0 = (long)L * nkt_all; rho = (int)((s0 - (s0 / per) * per) % Fw); }
-    }
-    auto tile_of = [&](int t) -> int {
-        if constexpr (!LEAN) return t;
-        const int pos = kt0 + t, r = pos + rho;
-        return pos >= Fw ? Fw : (r >= Fw ? r - Fw : r);
-    };
+    const int L = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int qb = L % a.nqb;
     const int hg = (L / a.nqb) % a.group;
     const int kvh = (L / (a.nqb * a.group)) % a.kv_heads;
@@ -145,31 +102,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     for (int i = 0; i < K_PW; ++i) dk_off[i] = dma_src(wave_u + NW * i, K_CPR, a.k_rs, true, ATT_BK - 1);
 #pragma unroll
     for (int i = 0; i < V_PW; ++i) dv_off[i] = dma_src(wave_u + NW * i, V_CPR, a.v_rs, false, ATT_BK - 1);
-    auto issue_k = [&](int kt_run, int buf) {
-        const int kt = tile_of(kt_run);
+    auto issue_k = [&](int kt, int buf) {
         char* kb = smem + buf * KT_BYTES;
         const char* Kt = (const char*)(K + (long)kt * ATT_BK * a.k_rs);
-        const bool tail = kt * ATT_BK + ATT_BK > Sk;          // wave-uniform: clamp rows past the last key
+        const bool tail = kt * ATT_BK + ATT_BK > a.Sk;          // wave-uniform: clamp rows past the last key
 #pragma unroll
         for (int i = 0; i < K_PW; ++i) {
             const int ii = wave_u + NW * i;
             if (ii < K_CPR) {
-                const unsigned off = tail ? dma_src(ii, K_CPR, a.k_rs, true, Sk - 1 - kt * ATT_BK) : dk_off[i];
+                const unsigned off = tail ? dma_src(ii, K_CPR, a.k_rs, true, a.Sk - 1 - kt * ATT_BK) : dk_off[i];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + off),
                                                  (__attribute__((address_space(3))) void*)(kb + ii * 1024), 16, 0, 0);
             }
         }
     };
-    auto issue_v = [&](int kt_run, int buf) {
-        const int kt = tile_of(kt_run);
+    auto issue_v = [&](int kt, int buf) {
         char* vb = smem + V_BASE + buf * VT_BYTES;
         const char* Vt = (const char*)(V + (long)kt * ATT_BK * a.v_rs);
-        const bool tail = kt * ATT_BK + ATT_BK > Sk;
+        const bool tail = kt * ATT_BK + ATT_BK > a.Sk;
 #pragma unroll
         for (int i = 0; i < V_PW; ++i) {
             const int ii = wave_u + NW * i;
             if (ii < V_CPR) {
-                const unsigned off = tail ? dma_src(ii, V_CPR, a.v_rs, false, Sk - 1 - kt * ATT_BK) : dv_off[i];
+                const unsigned off = tail ? dma_src(ii, V_CPR, a.v_rs, false, a.Sk - 1 - kt * ATT_BK) : dv_off[i];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + off),
                                                  (__attribute__((address_space(3))) void*)(vb + ii * 1024), 16, 0, 0);
             }
@@ -206,6 +161,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < (PV16 ? DT : 1); ++i) { o16[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o16[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float m_run = -1e30f, l_run = 0.f;
+    const int nkt = ceil_div(a.Sk, ATT_BK);
 
     // S = K Q^T for one 64-key tile out of K buffer `kbuf`
     auto qk_mfma = [&](int kbuf, f32x16 (&s)[2]) {
@@ -270,13 +226,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
             if (t + 2 < nkt) issue_k(t + 2, PAR);          // K(t+2) -> read in interval t+1   (K(t) in that buffer is dead)
         }
         // only the interval without a next tile (HAS_QK false) can hold the last, possibly partial, tile
-        if (!HAS_QK && tile_of(t) * ATT_BK + ATT_BK > Sk) {       // partial tile: lane (q, h) s[tt][r] is key kt*64 + tt*32 + 8*(r>>2) + 4*h + (r&3)
-            const int kt = tile_of(t);
+        if (!HAS_QK && t * ATT_BK + ATT_BK > a.Sk) {       // partial tile: lane (q, h) s[tt][r] is key t*64 + tt*32 + 8*(r>>2) + 4*h + (r&3)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kt * ATT_BK + tt * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= Sk) s_cur[tt][r] = -INFINITY;
+                    if (t * ATT_BK + tt * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= a.Sk) s_cur[tt][r] = -INFINITY;
         }
         // ---- one basic block from here to the rescale test ------------------------------------------------------------
         // MFMA i of the interval (QK^T steps first, then PV steps) is followed by slice i of the softmax VALU stream; a
@@ -431,21 +386,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
 
     // ---- epilogue: lane (q, h) holds O[q][dt*32 + 8*(r>>2) + 4*h + (r&3)] -------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    bool stored = false;
-    if constexpr (LEAN) {
-        if (kt0 != 0 || nkt != nkt_all) {                  // a key RANGE of the q-block: raw accumulators + (max, row sum) into this run's slot
-            const int slot = 2 * cu + (first_seg ? 0 : 1);
-            f32x4* po = (f32x4*)a.ws_o + (size_t)slot * (NW * 64 * DT * 4) + tid;       // [dt][g4][thread]: 1 KiB per wave store
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    po[(dt * 4 + g4) * (NW * 64)] = f32x4{o[dt][g4 * 4], o[dt][g4 * 4 + 1], o[dt][g4 * 4 + 2], o[dt][g4 * 4 + 3]};
-            ((f32x2*)a.ws_ml)[(size_t)slot * (NW * 64) + tid] = f32x2{m_run, l_tot};
-            stored = true;
-        }
-    }
-    if (!stored) {
     const float inv = 1.0f / l_tot;
     if constexpr (PV16) {
         const u32x2 ii = __builtin_amdgcn_permlane16_swap(bitcast<uint32_t>(inv), bitcast<uint32_t>(inv), false, false);
@@ -482,64 +422,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
             }
     }
     }
-    }   // !stored
-    if constexpr (LEAN) {
-        u += nkt;
-        first_seg = false;
-        __syncthreads();                                   // the drain's V reads are done before the next run's prologue refills the ring
-    }
-    } while (LEAN && u < u1);
-}
-
-// Combines the key-range runs of the LEAN launch: one block per q-block, thread = the (wave, lane) of the attention block, same partition
-// arithmetic as the kernel.  q-blocks that one run covered completely were stored by that run and are skipped.
-template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_lean_merge_kernel(AttnArgs a, int lean_blocks) {
-    adopt_device_key_count(a);
-    constexpr int DT = D / 32;
-    const int nkt_all = ceil_div(a.Sk, ATT_BK);
-    const long total = (long)a.nq_total * nkt_all, per = (total + lean_blocks - 1) / lean_blocks;
-    const int L = blockIdx.x;
-    const long ua = (long)L * nkt_all, ub = ua + nkt_all - 1;
-    const int c_lo = (int)(ua / per), c_hi = (int)(ub / per);
-    if (c_lo == c_hi) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, h = lane >> 5;
-    const f32x2* ml = (const f32x2*)a.ws_ml;
-    auto slot_of = [&](int c) { return 2 * c + ((int)(((long)c * per) / nkt_all) == L ? 0 : 1); };
-    float M = -INFINITY;
-    for (int c = c_lo; c <= c_hi; ++c) M = fmaxf(M, ml[(size_t)slot_of(c) * (NW * 64) + tid][0]);
-    f32x4 acc[DT * 4];
-#pragma unroll
-    for (int i = 0; i < DT * 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float lsum = 0.f;
-    for (int c = c_lo; c <= c_hi; ++c) {
-        const int slot = slot_of(c);
-        const f32x2 t = ml[(size_t)slot * (NW * 64) + tid];
-        const float w = __builtin_amdgcn_exp2f(t[0] - M);
-        lsum += w * t[1];
-        const f32x4* po = (const f32x4*)a.ws_o + (size_t)slot * (NW * 64 * DT * 4) + tid;
-#pragma unroll
-        for (int i = 0; i < DT * 4; ++i) acc[i] += po[i * (NW * 64)] * w;
-    }
-    const float inv = 1.0f / lsum;
-    const int qb = L % a.nqb;
-    const int hg = (L / a.nqb) % a.group;
-    const int kvh = (L / (a.nqb * a.group)) % a.kv_heads;
-    const int b = L / (a.nqb * a.group * a.kv_heads);
-    const int head = kvh * a.group + hg;
-    const int qrow = qb * (NW * 32) + wave * 32 + ql;
-    if (qrow < a.S) {
-        T* op = (T*)a.o + b * a.o_bs + (long)head * a.o_hs + (long)qrow * a.o_rs;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                typename T16<T>::vec4 w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = T16<T>::from_f32(acc[dt * 4 + g4][e] * inv);
-                *(typename T16<T>::vec4*)(op + dt * 32 + 8 * g4 + 4 * h) = w;
-            }
-    }
 }
 
 template <typename T, int D, int NW, bool PV16 = false>
@@ -557,33 +439,10 @@ static int launch_sp(AttnArgs a, int batch, int heads, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// LEAN launch: one block per CU over equal runs of (q-block, key tile) units, then the merge of the q-blocks that were cut (see the kernel's header)
-template <typename T>
-static int launch_sp_lean(AttnArgs a, int batch, int heads, hipStream_t s) {
-    constexpr int NW = 8, D = 128;
-    typedef AttnCfg<D> C;
-    a.nqb = ceil_div(a.S, NW * 32);
-    a.nq_total = a.nqb * heads * batch;
-    const size_t lds = 2 * (ATT_BK * C::LDK * 2 + ATT_BK * C::LDV * 2);
-    static std::atomic<unsigned> done_mask{0};
-    const int cur_dev = current_device();
-    if (!device_done(done_mask, cur_dev)) {
-        (void)hipFuncSetAttribute((const void*)attn_sp_kernel<T, D, NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        mark_device_done(done_mask, cur_dev);
-    }
-    hipLaunchKernelGGL((attn_sp_kernel<T, D, NW, false, true>), dim3(a.lean_blocks), dim3(NW * 64), lds, s, a);
-    hipLaunchKernelGGL((attn_lean_merge_kernel<T, D, NW>), dim3(a.nq_total), dim3(NW * 64), 0, s, a, a.lean_blocks);
-    return (int)hipGetLastError();
-}
-
 // called by vitg_attention (attention.hip).  pv16 (attn_sp = 3, hd 128 with 8 waves): PV on v_mfma_f32_16x16x32 - built, bit-for-bit tested and
 // measured 3-4 % SLOWER than PV on 32x32x16 here (2.50-2.54 against 2.43 ms on the LLM shape, profiles/r03_attention.md): there is no padding to drop
 // at hd 128, the 16x16 shape issues at ~17 instead of 16 cycles and the re-layout adds 16 swaps to a hand-interleaved stream.  Opt-in, not the default.
 int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv16, hipStream_t s) {
-    if (a.lean_blocks > 0) {                     // (attention_entry: head dim 128, a workspace, and a launch whose last round would be thin)
-        if (head_dim != 128 || !a.ws_o || !a.ws_ml) return -1;
-        return dtype == DT_BF16 ? launch_sp_lean<bf16_t>(a, batch, heads, s) : launch_sp_lean<f16_t>(a, batch, heads, s);
-    }
 #if !VITG_PROFILING_BUILD
     // PRODUCT library: head dim 128 only (the hd-72 form and PV on 16x16x32 lost their A/Bs: profiling library)
     (void)pv16;

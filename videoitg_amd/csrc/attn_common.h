@@ -17,10 +17,6 @@ struct AttnArgs {
     int kv_heads, nqb;               // kv heads, q-blocks per head
     int ablate;                      // profiling only (tools/attn_ablate.py): bit0 no QK^T, bit1 no exp, bit2 no PV, bit3 no K/V staging
     float scale_log2e;               // softmax scale * log2(e)
-    // work-partitioned launch of the hd-128 kernel (attention_sp.hip, LEAN; vitg_attention_ws): off unless lean_blocks > 0
-    float* ws_o; float* ws_ml;       // per-run raw fp32 accumulators [2 * lean_blocks][16][512] x 16 B / (running max, row sum) [2 * lean_blocks][512] x 8 B
-    int nq_total;                    // q-blocks of the whole call (nqb * heads * batch)
-    int lean_blocks;                 // blocks of the launch (one per CU)
 };
 
 // first statement of every attention kernel: adopt the device-side key count (wave-uniform scalar load)

@@ -316,10 +316,6 @@ class SelectorEngine:
         # VITG_CP_OVERLAP=0 (A/B): fused QKV projection and a blocking exchange, as in round 2.  The split costs one rank ~1 ms of compute per step
         # (two sub-round launches instead of one, tools/cp_rank_time.py) and buys the exchange - est. 0.1-0.15 ms x 28 layers - off the critical path
         self.cp_overlap = os.environ.get("VITG_CP_OVERLAP", "1") not in ("", "0")
-        # decoder attention: lend the library a workspace so that it may cut a launch by WORK instead of by q-block when the classic launch would
-        # end on a thin round (vitg_attention_ws; 1 428 blocks on 256 CUs = 6 rounds for 5.58 of work on one GPU, 196 blocks on one context-
-        # parallel rank).  VITG_LEAN_ATTN=0: the classic launch (A/B)
-        self.lean_attention = os.environ.get("VITG_LEAN_ATTN", "1") not in ("", "0")
         # fp32-residual GEMMs with fewer output tiles than CUs (one context-parallel rank): VITG_STREAMK=1 runs them as a stream-K partition instead
         # of split-K x2.  Opt-in: measured SLOWER on the per-rank o / down shapes (447 / 694 against 682 / 911 TF/s, profiles/r03_context_parallel.md)
         # (profiling library only since round 4: the product library no longer carries the stream-K kernels)
@@ -622,7 +618,6 @@ class SelectorEngine:
         cos, sin = cos[pos0:pos0 + N], sin[pos0:pos0 + N]
         scale = hd ** -0.5
         kvw = 2 * nkv * hd
-        attn_ws = self._buf("attn_ws", (K.attention_ws_bytes(),), torch.uint8) if (self.lean_attention and hd == 128) else None
         pend = None                                       # layer 0 normalises the assembled embeddings with the stand-alone kernel
         fuse = kv_gather is None                          # (the context-parallel ranks take the split-K path for o / down instead)
         for li, lw in enumerate(w.llm):
@@ -656,11 +651,11 @@ class SelectorEngine:
             if kv_gather is None:
                 K.attention(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N,
                             head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, qkv_n, hd), v_strides=(0, qkv_n, hd),
-                            o_strides=(0, op, hd), scale=scale, variant=self.attn_variant, kv_len=kv_len, ws=attn_ws)
+                            o_strides=(0, op, hd), scale=scale, variant=self.attn_variant, kv_len=kv_len)
             else:
                 K.attention(qkv, kv, kv[:, nkv * hd:], o, batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total,
                             head_dim=hd, q_strides=(0, qkv_n, hd), k_strides=(0, kvw, hd), v_strides=(0, kvw, hd),
-                            o_strides=(0, op, hd), scale=scale, variant=self.attn_variant, ws=attn_ws)
+                            o_strides=(0, op, hd), scale=scale, variant=self.attn_variant)
             pend = self._producer(self._operand(o, "llm_o", nq * hd, lw.o_w), lw.o_w, x, bias=None, res=x, gamma=lw.post_ln if fuse else None,
                                   name="llm", eps=cfg.rms_norm_eps, rms=True, dt=self.dtype)
             if pend is not None:

@@ -389,20 +389,10 @@ def rope_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, h
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, *, batch: int, heads: int, kv_heads: int,
               seq: int, head_dim: int, q_strides, k_strides, v_strides, o_strides, scale: float, variant: int = 0,
-              kv_seq: Optional[int] = None, kv_len: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+              kv_seq: Optional[int] = None, kv_len: Optional[torch.Tensor] = None):
     """q/k/v/o are base tensors (views at the first element); *_strides = (batch, row, head) in elements.
-    kv_len: optional int32 device scalar - the number of keys is read from it at kernel start (<= kv_seq; vitg_attention_dyn).
-    ws: optional workspace (attention_ws_bytes() bytes, uint8): lets the library cut a head-dim-128 call by work (vitg_attention_ws)."""
+    kv_len: optional int32 device scalar - the number of keys is read from it at kernel start (<= kv_seq; vitg_attention_dyn)."""
     _req(q)
-    if ws is not None:
-        _req(ws, torch.uint8)
-        if kv_len is not None:
-            _req(kv_len, torch.int32)
-        _lib.call("vitg_attention_ws", _ptr(q), _ptr(k), _ptr(v), _ptr(o), batch, heads, kv_heads, seq,
-                  seq if kv_seq is None else kv_seq, _ptr(kv_len) if kv_len is not None else None, head_dim,
-                  q_strides[0], k_strides[0], v_strides[0], o_strides[0], q_strides[1], k_strides[1], v_strides[1], o_strides[1],
-                  q_strides[2], k_strides[2], v_strides[2], o_strides[2], scale, dt_code(q.dtype), variant, _ptr(ws), ws.numel(), _stream())
-        return o
     if kv_len is not None:
         _req(kv_len, torch.int32)
         _lib.call("vitg_attention_dyn", _ptr(q), _ptr(k), _ptr(v), _ptr(o), batch, heads, kv_heads, seq,
@@ -415,13 +405,6 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor
               q_strides[0], k_strides[0], v_strides[0], o_strides[0], q_strides[1], k_strides[1], v_strides[1], o_strides[1],
               q_strides[2], k_strides[2], v_strides[2], o_strides[2], scale, dt_code(q.dtype), variant, _stream())
     return o
-
-
-def attention_ws_bytes() -> int:
-    """bytes of the workspace `attention(..., ws=)` wants on the current device"""
-    n = C.c_long(0)
-    _lib.call("vitg_attention_ws_bytes", C.byref(n))
-    return int(n.value)
 
 
 def bilinear_pool(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d: int, cmap: Optional[torch.Tensor] = None,

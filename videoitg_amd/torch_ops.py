@@ -100,12 +100,12 @@ _def("rope_(Tensor(a!) qkv, Tensor cos, Tensor sin, int heads, int head_dim) -> 
 # ---- non-causal flash attention ------------------------------------------------------------------------------------------
 _def("attention(Tensor q, Tensor k, Tensor v, Tensor(a!) o, int batch, int heads, int kv_heads, int seq, int head_dim, "
      "int[] q_strides, int[] k_strides, int[] v_strides, int[] o_strides, float scale, int variant=0, int? kv_seq=None, "
-     "Tensor? kv_len=None, Tensor(b!)? ws=None) -> ()",
+     "Tensor? kv_len=None) -> ()",
      lambda q, k, v, o, batch, heads, kv_heads, seq, head_dim, q_strides, k_strides, v_strides, o_strides, scale, variant=0,
-            kv_seq=None, kv_len=None, ws=None:
+            kv_seq=None, kv_len=None:
          (_raw.attention(q, k, v, o, batch=batch, heads=heads, kv_heads=kv_heads, seq=seq, head_dim=head_dim, q_strides=q_strides,
                          k_strides=k_strides, v_strides=v_strides, o_strides=o_strides, scale=scale, variant=variant,
-                         kv_seq=kv_seq, kv_len=kv_len, ws=ws), None)[1],
+                         kv_seq=kv_seq, kv_len=kv_len), None)[1],
      lambda *a, **k: None)
 
 # ---- pooling / gathers / head ------------------------------------------------------------------------------------------------
@@ -220,12 +220,10 @@ class _Namespace:
 
     @staticmethod
     def attention(q, k, v, o, *, batch, heads, kv_heads, seq, head_dim, q_strides, k_strides, v_strides, o_strides, scale,
-                  variant=0, kv_seq=None, kv_len=None, ws=None):
+                  variant=0, kv_seq=None, kv_len=None):
         _ops.attention(q, k, v, o, batch, heads, kv_heads, seq, head_dim, list(q_strides), list(k_strides), list(v_strides),
-                       list(o_strides), scale, variant, kv_seq, kv_len, ws)
+                       list(o_strides), scale, variant, kv_seq, kv_len)
         return o
-
-    attention_ws_bytes = staticmethod(_raw.attention_ws_bytes)
 
     @staticmethod
     def bilinear_pool(x, out, T, G, HW, d, cmap=None, pc=0):
