@@ -484,7 +484,7 @@ def test_gemm_res16(ops, gemm_cfg, dtype, M, N, K, P):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,D", [(1000, 1152), (37, 144), (70000, 1152), (64, 256), (5, 4096)])
+@pytest.mark.parametrize("M,D", [(1000, 1152), (37, 144), (70000, 1152), (64, 256), (5, 4096), (1001, 1152), (3, 1152), (131075, 1152)])
 def test_layernorm16(ops, dtype, M, D):
     from videoitg_amd.ops import pad64
     x = (rnd((M, D), 40, 3.0, torch.float32) + 0.5).to(dtype)

@@ -229,6 +229,76 @@ __global__ void ln16_kernel(const T* __restrict__ x, int ldx, const float* __res
     }
 }
 
+// Round 4: FOUR rows per wave, 16 lanes per row, for D = 128 NC exactly (the tower's 1152 = 9 x 128).  Every load / store instruction moves 4 x 256 B
+// with all 64 lanes (the one-row-per-wave form above runs its third 1-KiB chunk with 16 of 64 lanes) and the row reductions stay inside a DPP row of
+// 16 lanes (4 rotate-adds instead of 6 cross-lane steps); 9 KiB per wave in flight (+ the prefetched next four rows).  Same arithmetic as ln16_kernel
+// (fp32 two-pass statistics, one rounding of the result); the sums run in another order.  Measured (tools/r04/call18.sh, gpurun_out/r04_c18): stand-alone
+// 465-486 us against 520-545 (5.0-5.2 against 4.4-4.65 TB/s; a torch copy of the same bytes on that box: 443 us = 5.46 TB/s), inside the step 0.443-0.451
+// against 0.502-0.509 ms per launch, +0.45 % frames/s in three alternations.
+__device__ __forceinline__ float row16_sum(float v) {
+#define ROR(n) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+    ROR(8); ROR(4); ROR(2); ROR(1);
+#undef ROR
+    return v;
+}
+template <typename T, int NC, bool PF>
+__global__ __launch_bounds__(256) void ln16r4_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bia,
+                              T* __restrict__ out, int ldo, long M, int D, float eps) {
+    typedef typename T16<T>::vec8 vec8;
+    const int lane = threadIdx.x & 63, sub = lane & 15, rsel = lane >> 4;
+    const long nq = (long)gridDim.x * (blockDim.x >> 6);
+    long q = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long MQ = (M + 3) >> 2;
+    if (q >= MQ) return;
+    vec8 v[NC], nx[PF ? NC : 1];
+    auto load_rows = [&](auto& dst, long qq) {
+        const long r = min(qq * 4 + rsel, M - 1);
+        const T* xr = x + r * ldx + sub * 8;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) dst[i] = *(const vec8*)(xr + i * 128);
+    };
+    load_rows(v, q);
+    const float invD = 1.0f / D;
+    for (; q < MQ; q += nq) {
+        const long next = q + nq;
+        if constexpr (PF) { if (next < MQ) load_rows(nx, next); }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += T16<T>::to_f32(v[i][e]);
+        const float mean = row16_sum(s) * invD;
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = T16<T>::to_f32(v[i][e]) - mean; qq += d * d; }
+        const float rstd = rsqrtf(row16_sum(qq) * invD + eps);
+        const long row = q * 4 + rsel;
+        if (row < M) {
+            T* orow = out + row * ldo + sub * 8;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int c = i * 128 + sub * 8;
+                const f32x4 w0 = *(const f32x4*)(w + c), w1 = *(const f32x4*)(w + c + 4);
+                const f32x4 b0 = *(const f32x4*)(bia + c), b1 = *(const f32x4*)(bia + c + 4);
+                vec8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = T16<T>::from_f32((T16<T>::to_f32(v[i][e]) - mean) * rstd * w0[e] + b0[e]);
+                    o[e + 4] = T16<T>::from_f32((T16<T>::to_f32(v[i][e + 4]) - mean) * rstd * w1[e] + b1[e]);
+                }
+                *(vec8*)(orow + i * 128) = o;
+            }
+            for (int c = D + sub * 8; c < ldo; c += 128) *(vec8*)(out + row * ldo + c) = vec8{};
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) v[i] = nx[i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // RoPE (rotate_half layout) in place on the q and k heads of a packed qkv row:
 //   x[i] <- x[i] cos_i - x[i+hd/2] sin_i ;  x[i+hd/2] <- x[i+hd/2] cos_i + x[i] sin_i
@@ -514,6 +584,17 @@ extern "C" int vitg_layernorm16(const void* x, int ldx, const float* w, const fl
 #endif
     const int threads = (blk_env == 128 || blk_env == 512 || blk_env == 1024) ? blk_env : 256;
     const int wpb = threads / 64;
+    if (D == 9 * 128 && b && !cap_env && !blk_env) {           // the tower's width: four rows per wave (ln16r4_kernel)
+        constexpr int wpb4 = 4;
+        const long want4 = ((M + 3) / 4 + wpb4 - 1) / wpb4, cap4 = 8192;
+        dim3 blk4(256), grid4((unsigned)(want4 < cap4 ? want4 : cap4));
+        hipStream_t s4 = (hipStream_t)stream;
+#define LK4(T) do { if (want4 > cap4) hipLaunchKernelGGL((ln16r4_kernel<T, 9, true>), grid4, blk4, 0, s4, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); \
+                    else hipLaunchKernelGGL((ln16r4_kernel<T, 9, false>), grid4, blk4, 0, s4, (const T*)x, ldx, w, b, (T*)out, ldo, M, D, eps); } while (0)
+        if (dtype == DT_F16) LK4(f16_t); else if (dtype == DT_BF16) LK4(bf16_t); else return VITG_ERR_DTYPE;
+#undef LK4
+        return CHECK_LAUNCH();
+    }
     const long want = (M + wpb - 1) / wpb;
     const long cap = cap_env > 0 ? cap_env : 16384;
     dim3 blk(threads), grid((unsigned)(want < cap ? want : cap));
