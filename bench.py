@@ -232,6 +232,72 @@ class GemmTimer:
         return len(ms), sum(ms)
 
 
+class HwmonSampler:
+    """Package power and shader clock of cuda:0 from the amdgpu hwmon files (power1_average / power1_input in uW, power1_cap, freq1_input = sclk in
+    Hz), read every 20 ms by a thread while ONE extra step runs after the timed region.  Why it is in the line: every MFMA kernel of this step runs on
+    the package power cap (profiles/r02_power_trace.txt, profiles/r04_experiments.md section 11), so the shader clock under the step - not the nominal
+    2.4 GHz behind `peak` - is what `frac` has to be read against.  Absent files (another driver, a container without /sys): the block is null."""
+
+    def __init__(self):
+        import glob
+        import threading
+        self.power = self.sclk = self.cap = None
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:
+            pass
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            try:
+                names = os.listdir(d)
+                pw = next((os.path.join(d, n) for n in ("power1_average", "power1_input") if n in names), None)
+                pci = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))
+            except OSError:
+                continue
+            if pw and want and pci.lower().startswith(want):
+                self.power = pw
+                self.sclk = os.path.join(d, "freq1_input") if "freq1_input" in names else None
+                self.cap = os.path.join(d, "power1_cap") if "power1_cap" in names else None
+                break
+        self.p, self.f, self._stop = [], [], False
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.power else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            v = self._read(self.power)
+            if v is not None:
+                self.p.append(v / 1e6)
+            if self.sclk:
+                v = self._read(self.sclk)
+                if v is not None:
+                    self.f.append(v / 1e9)
+            time.sleep(0.02)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        if not self._thread:
+            return None
+        self._stop = True
+        self._thread.join()
+        if not self.p:
+            return None
+        cap = self._read(self.cap) if self.cap else None
+        return {"power_w": round(sum(self.p) / len(self.p), 1), "cap_w": round(cap / 1e6, 1) if cap else None,
+                "sclk_ghz": round(sum(self.f) / len(self.f), 3) if self.f else None, "samples": len(self.p)}
+
+
 def cpu_baseline(cfg, T, R, n_text, cores):
     """Oracle (kind "port") on this host's cores on the bounded sample SURVEY.md 8d prescribes for T = 512: the WHOLE needed tower depth
     (26 layers) on a 16-frame slice, x (T / 16) frame groups (frames are independent), plus 2 whole decoder layers at the FULL token
@@ -507,6 +573,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = timer8.enabled = False
     dt_side = dt / args.steps
+    power_clock = None
     if world == 1 and os.environ.get("VITG_BENCH_NO_SIDE_PASS", "0") in ("", "0"):
         # the other kernel classes (attention per head size, norms): one extra step with THEIR events, outside the timed region - two
         # event records per launch on ~450 more launches per step cost the step ~1 % when they sat inside it
@@ -518,6 +585,11 @@ def main():
         dt_side = time.perf_counter() - t1
         for st_ in side_timers:
             st_.enabled = False
+        hwmon = HwmonSampler()                           # package power / shader clock under the step: one more step, nothing timed
+        hwmon.start()
+        step()
+        barrier()
+        power_clock = hwmon.stop()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -573,6 +645,15 @@ def main():
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)},
             "top32": sorted(order[:32]),
         }
+        if power_clock is not None:
+            # the whole step (72 % of it GEMM time) at the clock the package power cap leaves it; `peak` / `frac` above stay on the nominal 2.4 GHz
+            power_clock["what"] = ("hwmon of this GPU sampled every 20 ms over one extra step after the timed region: package power, its cap, shader clock; "
+                                   "peak_at_sclk = peak x sclk / 2.4 GHz (the matrix pipes' rate at the clock the step really ran at)")
+            if power_clock.get("sclk_ghz"):
+                pk = MFMA_PEAK_TFLOPS * power_clock["sclk_ghz"] / 2.4
+                power_clock["peak_at_sclk"] = round(pk, 1)
+                power_clock["frac_of_peak_at_sclk"] = round(achieved / pk, 4)
+            out["roofline"]["power_clock"] = power_clock
         out["parity"] = parity_block(T, R, args.prompt_len, args.seed, last_logits, order, tol=fp8_tol if args.fp8 else 1e-3) if args.config == "full" else None
         if args.fp8:
             # the job itself ran on the fp8 weight path: the dominant kernel is gemm_fp8_kernel, priced against the dense fp8 peak
