@@ -234,7 +234,7 @@ class GemmTimer:
 
 class HwmonSampler:
     """Package power and shader clock of cuda:0 from the amdgpu hwmon files (power1_average / power1_input in uW, power1_cap, freq1_input = sclk in
-    Hz), read every 20 ms by a thread while ONE extra step runs after the timed region.  Why it is in the line: every MFMA kernel of this step runs on
+    Hz), read every 20 ms by a thread while three extra steps run after the timed region (the first third of the samples is dropped).  Why it is in the line: every MFMA kernel of this step runs on
     the package power cap (profiles/r02_power_trace.txt, profiles/r04_experiments.md section 11), so the shader clock under the step - not the nominal
     2.4 GHz behind `peak` - is what `frac` has to be read against.  Absent files (another driver, a container without /sys): the block is null."""
 
@@ -293,6 +293,7 @@ class HwmonSampler:
         self._thread.join()
         if not self.p:
             return None
+        self.p, self.f = self.p[len(self.p) // 3:], self.f[len(self.f) // 3:]      # the power file is itself a running average: drop its run-in
         cap = self._read(self.cap) if self.cap else None
         return {"power_w": round(sum(self.p) / len(self.p), 1), "cap_w": round(cap / 1e6, 1) if cap else None,
                 "sclk_ghz": round(sum(self.f) / len(self.f), 3) if self.f else None, "samples": len(self.p)}
@@ -585,9 +586,10 @@ def main():
         dt_side = time.perf_counter() - t1
         for st_ in side_timers:
             st_.enabled = False
-        hwmon = HwmonSampler()                           # package power / shader clock under the step: one more step, nothing timed
+        hwmon = HwmonSampler()                           # package power / shader clock under the step: three more steps, nothing timed
         hwmon.start()
-        step()
+        for _ in range(3):
+            step()
         barrier()
         power_clock = hwmon.stop()
     if world > 1:
@@ -647,7 +649,7 @@ def main():
         }
         if power_clock is not None:
             # the whole step (72 % of it GEMM time) at the clock the package power cap leaves it; `peak` / `frac` above stay on the nominal 2.4 GHz
-            power_clock["what"] = ("hwmon of this GPU sampled every 20 ms over one extra step after the timed region: package power, its cap, shader clock; "
+            power_clock["what"] = ("hwmon of this GPU sampled every 20 ms over three extra steps after the timed region (first third dropped): package power, its cap, shader clock; "
                                    "peak_at_sclk = peak x sclk / 2.4 GHz (the matrix pipes' rate at the clock the step really ran at)")
             if power_clock.get("sclk_ghz"):
                 pk = MFMA_PEAK_TFLOPS * power_clock["sclk_ghz"] / 2.4
