@@ -521,6 +521,7 @@ def main():
     if args.fp8:
         ops.gemm_fp8 = timer8.wrap(ops.gemm_fp8)
         ops.gemm_fp8_mx = timer8.wrap(ops.gemm_fp8_mx)  # (the tower MLP pair on MX block scales)
+        ops.gemm_fp8_res16 = timer8.wrap(ops.gemm_fp8_res16)   # (out-proj / fc2 of the tower on its 16-bit residual stream)
     # the other kernel classes of the step, timed the same way (HIP events around every launch on the launch stream): attention per
     # head size (MFMA-bound) and the norm kernels (HBM-bound) - north_star asks for both rooflines; reported as `roofline_other`
     t_attn = {72: GemmTimer(), 128: GemmTimer()}
@@ -855,7 +856,7 @@ def main():
             # score bound alone - each says whether it selects the oracle's frames.  The NAMED fp8 tier is `fp8_llm_mlp` (decoder MLP only);
             # `fp8` (all eight GEMMs) is the throughput end of the front and does not select the same frames.
             ref16 = last_logits.float().cpu().view(-1)
-            raw_fp8, raw_fp8_mx = ops.gemm_fp8, ops.gemm_fp8_mx
+            raw_fp8, raw_fp8_mx, raw_fp8_res16 = ops.gemm_fp8, ops.gemm_fp8_mx, ops.gemm_fp8_res16
             by_name = layer_gemm_flops_by_name(cfg, T, R, ids.shape[1] - 1, eng.skip_dead_rows)
             tiers = [("fp8_llm_mlp", "llm.gu,llm.down", 0.025,
                       "NAMED fp8 tier: e4m3 weights + activations in the decoder's gate/up and down projections only (SwiGLU output handed over as "
@@ -873,6 +874,7 @@ def main():
                 t8 = GemmTimer()
                 ops.gemm_fp8 = t8.wrap(raw_fp8)
                 ops.gemm_fp8_mx = t8.wrap(raw_fp8_mx)
+                ops.gemm_fp8_res16 = t8.wrap(raw_fp8_res16)
                 o8 = {}
 
                 def step_8():
@@ -888,7 +890,7 @@ def main():
                 torch.cuda.synchronize()
                 d8 = (time.perf_counter() - t4) / 2
                 t8.enabled = False
-                ops.gemm_fp8, ops.gemm_fp8_mx = raw_fp8, raw_fp8_mx
+                ops.gemm_fp8, ops.gemm_fp8_mx, ops.gemm_fp8_res16 = raw_fp8, raw_fp8_mx, raw_fp8_res16
                 n8, ms8 = t8.summary()
                 on8 = [k_ for k_ in by_name if eng8.w.fp8_on(k_)]
                 ach8 = sum(by_name[k_] for k_ in on8) * 2 / max(ms8 * 1e-3, 1e-9) / 1e12

@@ -138,6 +138,16 @@ int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const void* W8, int 
                   int out_dtype, int mode, const float* bias, int act, void* out, int ldo, const float* res, int ldr, int res_mod,
                   void* stream);
 
+/* The tower's 16-bit residual stream on the fp8 weight path (round 4): what vitg_gemm_res16 / vitg_layernorm16 are to vitg_gemm / vitg_layernorm.
+ *   vitg_gemm_fp8_res16:   out16[m,n] = round16( scales * sum_k A8[m,k] W8[n,k] + bias[n] + res16[m,n] ); res16 (type `dtype`, may alias out) is
+ *                          required; A8 carries per-token scales sa (a_mx == NULL) or MX block scales a_mx (sa ignored) as in vitg_gemm_fp8_mx.
+ *   vitg_norm_quant_fp8_16: vitg_norm_quant_fp8 on 16-bit rows (in_dtype VITG_F16 / VITG_BF16).
+ * Same call sites as vitg_gemm_res16 (SigLIP out_proj, fc2) and the LayerNorms in front of qkv / fc1. */
+int vitg_gemm_fp8_res16(const void* A8, int lda, const float* sa, const void* a_mx, int ld_amx, const void* W8, int ldw, const float* sw, int M,
+                        int N, int K, int dtype, const float* bias, void* out, int ldo, const void* res16, int ldr16, void* stream);
+int vitg_norm_quant_fp8_16(const void* x, long ldx, int in_dtype, const float* w, const float* b, void* out8, long ldo, float* scale, long M,
+                           int D, float eps, void* stream);
+
 /* MX forms of vitg_gemm_fp8: activations that stay e4m3 BETWEEN two GEMMs carry OCP-MX block scales - one E8M0 byte (scale 2^(b-127)) per
  * 32 consecutive elements of a row, which v_mfma_scale_f32_32x32x64_f8f6f4 consumes as an operand - instead of a per-token fp32 scale
  * that only a separate pass over the finished row can compute.  Scale array layout: [K/128][ld][4] bytes, i.e. the four block scales

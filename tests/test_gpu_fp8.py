@@ -123,6 +123,66 @@ def test_gemm_fp8_f32_residual(M, N, K, P):
     assert (x.cpu() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,mx", [(1000, 1152, 1152, False), (513, 256, 4352, False), (300, 1152, 4352, True), (77, 264, 128, False), (2048, 1152, 256, True)])
+def test_gemm_fp8_res16_is_the_fp32_residual_gemm_rounded_once(dtype, M, N, K, mx):
+    """vitg_gemm_fp8_res16 (the tower's 16-bit residual stream on the fp8 weight path): out16 = round16(scales * (A8 W8^T) + bias + res16), in place.
+    Bit-for-bit the 16-bit rounding of what vitg_gemm_fp8 / vitg_gemm_fp8_mx (fp32 residual form) compute from the same operands with the residual
+    widened to fp32 - same kernel, same accumulators, one rounding at the end; per-token scales and MX block scales."""
+    from videoitg_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    w = (torch.randn((N, K), generator=g) * K ** -0.5).half().cuda()
+    w8, sw = ops.quant_rows_fp8(w, K)
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    x16 = (torch.randn((M, N), generator=g) * 2).to(dtype).cuda()
+    if mx:                                                         # an MX-scaled operand as fc1's epilogue leaves it
+        K0 = 256
+        a0 = torch.randn((M, K0), generator=g).half().cuda()
+        w0 = (torch.randn((K, K0), generator=g) * K0 ** -0.5).half().cuda()
+        a08, sa0 = ops.quant_rows_fp8(a0, K0)
+        w08, sw0 = ops.quant_rows_fp8(w0, K0)
+        a8 = torch.zeros((M, K), dtype=torch.uint8, device="cuda")
+        sc = torch.zeros((K // 128, M, 4), dtype=torch.uint8, device="cuda")
+        ops.gemm_fp8_mx(a08, w08, sw0, a8, out_dtype=torch.float16, sa=sa0, o_mx=sc, act=1)
+        want32 = x16.float().clone()
+        ops.gemm_fp8_mx(a8, w8, sw, want32, out_dtype=dtype, a_mx=sc, bias=bias, res=want32)
+        got = x16.clone()
+        ops.gemm_fp8_res16(a8, w8, sw, got, res16=got, a_mx=sc, bias=bias)
+    else:
+        a = (torch.randn((M, K), generator=g) * (0.5 + torch.rand((M, 1), generator=g))).half().cuda()
+        a8, sa = ops.quant_rows_fp8(a, K)
+        want32 = x16.float().clone()
+        ops.gemm_fp8(a8, sa, w8, sw, want32, mode=ops.GEMM_F32, out_dtype=dtype, bias=bias, res=want32)
+        got = x16.clone()
+        ops.gemm_fp8_res16(a8, w8, sw, got, res16=got, sa=sa, bias=bias)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want32.to(dtype))
+    # not in place: the residual rows are left alone
+    keep = x16.clone()
+    out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    if mx:
+        ops.gemm_fp8_res16(a8, w8, sw, out, res16=x16, a_mx=sc, bias=bias)
+    else:
+        ops.gemm_fp8_res16(a8, w8, sw, out, res16=x16, sa=sa, bias=bias)
+    assert torch.equal(out, got) and torch.equal(x16, keep)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rms", [False, True])
+@pytest.mark.parametrize("M,D", [(50, 1152), (33, 3584), (20, 144), (1001, 1152)])
+def test_norm_quant_on_16_bit_rows_equals_the_fp32_row_kernel(dtype, rms, M, D):
+    """vitg_norm_quant_fp8_16: bytes and scales identical to vitg_norm_quant_fp8 on the same rows widened to fp32 (the widening is exact)"""
+    from videoitg_amd import ops
+    g = torch.Generator().manual_seed(M + D)
+    x = (torch.randn((M, D), generator=g) * 3 + 0.5).to(dtype).cuda()
+    w, b = (torch.randn(D, generator=g) * 0.1 + 1).cuda(), None if rms else (torch.randn(D, generator=g) * 0.1).cuda()
+    q0 = torch.full((M, ops.pad128(D)), 0x55, dtype=torch.uint8, device="cuda"); s0 = torch.empty(M, device="cuda")
+    q1 = torch.full((M, ops.pad128(D)), 0xAA, dtype=torch.uint8, device="cuda"); s1 = torch.empty(M, device="cuda")
+    ops.norm_quant_fp8(x.float(), w, b, q0, s0, D, 1e-6)
+    ops.norm_quant_fp8_16(x, w, b, q1, s1, D, 1e-6)
+    assert torch.equal(q0, q1) and torch.equal(s0, s1)
+
+
 @pytest.mark.parametrize("M,F_,K", [(200, 576, 256), (1300, 1024, 512)])
 def test_gemm_fp8_swiglu(M, F_, K):
     from videoitg_amd import ops

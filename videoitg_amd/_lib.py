@@ -44,6 +44,8 @@ SIGNATURES = {
     "vitg_quant_rows_fp8": [_p, _l, _i, _p, _l, _p, _l, _i, _p],
     "vitg_norm_quant_fp8": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _f, _p],
     "vitg_gemm_fp8": [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],
+    "vitg_gemm_fp8_res16": [_p, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p],
+    "vitg_norm_quant_fp8_16": [_p, _l, _i, _p, _p, _p, _l, _p, _l, _i, _f, _p],
     "vitg_gemm_fp8_mx": [_p, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "vitg_mfma_probe": [_p, _i, _i, _i, _p, C.POINTER(C.c_double), _p],
     "vitg_layernorm": [_p, _i, _p, _p, _p, _i, _i, _l, _i, _f, _p],

@@ -131,7 +131,9 @@ __device__ __forceinline__ void epilogue_swiglu_quad(const GemmArgs& g, int m, i
 // two - and >= 32*NT*128 bytes for fp32 output).
 // Requires out/res leading dimensions and n_base to keep 16-B alignment (checked by the host code).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int MODE, int MT, int NT, int MT0 = 0, int MTN = MT, bool NRM = false>
+// R16 (MODE_F32 only; gemm_fp8.hip, round 4): the residual is a 16-bit row of type T (g.res16, ld g.ldr16) and so is the output (g.out, ld g.ldo) -
+// out16 = round16(acc + bias + res16), the tower's 16-bit residual stream on the fp8 weight path (vitg_gemm_fp8_res16).
+template <typename T, int MODE, int MT, int NT, int MT0 = 0, int MTN = MT, bool NRM = false, bool R16 = false>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)[NT][MT], char* stage, int m_base, int n_base,
                                                 int lane) {
     // processes accumulator row-tiles mt in [MT0, MT0 + MTN); m_base is the row of mt = MT0
@@ -189,6 +191,17 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& g, f32x16 (&acc)
                 const int row = idx / CH, c = idx % CH;
                 f32x4 v = *(const f32x4*)(stage + row * RB + ((c ^ swz(row)) << 4));
                 const int m = m_base + (mt - MT0) * 32 + row, n = n_base + c * 4;
+                if constexpr (R16) {
+                    if (IN || (m < g.M && n < g.N)) {
+                        const char* const rb = (const char*)((const T*)g.res16 + (size_t)m_base * g.ldr16 + n_base);
+                        const typename T16<T>::vec4 r = *(const typename T16<T>::vec4*)(rb + (unsigned)(((mt - MT0) * 32 + row) * g.ldr16 + c * 4) * 2u);
+                        typename T16<T>::vec4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e] + T16<T>::to_f32(r[e]));
+                        char* const ob16 = (char*)((T*)g.out + (size_t)m_base * g.ldo + n_base);
+                        *(typename T16<T>::vec4*)(ob16 + (unsigned)(((mt - MT0) * 32 + row) * g.ldo + c * 4) * 2u) = o;
+                    }
+                } else
                 if (IN || (m < g.M && n < g.N)) {
                     if (g.res) {
                         const int rm = g.res_mod > 0 ? m % g.res_mod : m;

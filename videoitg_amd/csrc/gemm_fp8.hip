@@ -250,7 +250,8 @@ __global__ __launch_bounds__(F8_THREADS, 2) void gemm_fp8_kernel(Gemm8Args ga) {
     if constexpr (MODE == MODE_F32) {
         constexpr int SB = 32 * NT * 128;
         static_assert(8 * SB <= F8_STAGES * STAGE, "fp32 staging must fit in the ring");
-        epilogue_staged<T, MODE_F32, MT, NT>(g, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
+        if (g.res16) epilogue_staged<T, MODE_F32, MT, NT, 0, MT, false, true>(g, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);   // 16-bit residual stream
+        else epilogue_staged<T, MODE_F32, MT, NT>(g, acc, smem + wave * SB, m0 + wr * (MT * 32), n0 + wc * (NT * 32), lane);
     } else if constexpr (MXO) {
         // ---- MX output: bias + activation (or SwiGLU) in fp32, then per (token row, 32-column output block = one MFMA tile): amax over the
         // lane's 16 values and its lane ^ 32 partner's 16, E8M0 exponent e = ceil(log2(amax / 448)) (no saturation), q = e4m3(v * 2^-e);
@@ -465,20 +466,20 @@ __global__ __launch_bounds__(256) void quant_rows_wave_kernel(const TI* __restri
 
 // LayerNorm / RMSNorm fused with the per-token quantiser: y = norm(x) * w (+ b) in fp32, then amax / fp8 as above.  One WAVE per
 // row (like norm_kernel in elementwise.hip), the row in registers: a single HBM read, no LDS, no block barrier; D <= 256 * VPL.
-template <bool RMS, int VPL>
-__global__ __launch_bounds__(256) void norm_quant_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+template <bool RMS, int VPL, typename TI = float>
+__global__ __launch_bounds__(256) void norm_quant_kernel(const TI* __restrict__ x, long ldx, const float* __restrict__ w,
                                                          const float* __restrict__ b, unsigned char* __restrict__ out, long ldo,
                                                          float* __restrict__ scale, long M, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + row * ldx;
+    const TI* xr = x + row * ldx;
     f32x4 v[VPL];
     float s = 0.f, ss = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * 64 + lane) * 4;
-        v[i] = c < D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[i] = c < D ? load4<TI>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s += v[i][e]; ss += v[i][e] * v[i][e]; }
     }
@@ -550,6 +551,27 @@ extern "C" int vitg_gemm_fp8(const void* A8, int lda, const float* sa, const voi
     return rc == 0 ? 0 : VITG_ERR_LAUNCH;
 }
 
+// 16-bit residual stream on the fp8 weight path (round 4; include/videoitg_hip.h): out16 = round16(scales * (A8 W8^T) + bias + res16), A8 with per-token
+// scales (a_mx == NULL) or MX block scales (a_mx set: fc2 behind an MX-producing fc1)
+extern "C" int vitg_gemm_fp8_res16(const void* A8, int lda, const float* sa, const void* a_mx, int ld_amx, const void* W8, int ldw, const float* sw,
+                                   int M, int N, int K, int dtype, const float* bias, void* out, int ldo, const void* res16, int ldr16, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || K % F8_ROWB != 0) return VITG_ERR_SHAPE;
+    if ((lda % 16) || (ldw % 16) || lda < K || ldw < K) return VITG_ERR_ALIGN;
+    if (!A8 || !W8 || !sw || !out || !res16 || (!sa && !a_mx)) return VITG_ERR_ARG;
+    if (a_mx && ld_amx < M) return VITG_ERR_SHAPE;
+    if (N % 8 != 0 || ldo % 4 != 0 || ldr16 % 4 != 0 || ldo < N || ldr16 < N) return VITG_ERR_ALIGN;
+    if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
+    Gemm8Args ga = {};
+    GemmArgs& g = ga.g;
+    g.A = A8; g.lda = lda; g.W = W8; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.act = VITG_ACT_NONE; g.out = out; g.ldo = ldo; g.res = nullptr; g.res16 = res16; g.ldr16 = ldr16;
+    g.group_m = 4; g.split_k = 1;
+    ga.sa = sa; ga.sw = sw; ga.a_mx = (const unsigned char*)a_mx; ga.ld_amx = ld_amx;
+    const int rc = dtype == DT_BF16 ? launch_fp8_t<bf16_t>(ga, MODE_F32, (hipStream_t)stream) : launch_fp8_t<f16_t>(ga, MODE_F32, (hipStream_t)stream);
+    return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+}
+
 // MX forms of vitg_gemm_fp8 (see include/videoitg_hip.h): exactly one of a_mx (consumer, mode F32) / o_mx (producer, mode STORE16)
 extern "C" int vitg_gemm_fp8_mx(const void* A8, int lda, const float* sa, const void* a_mx, int ld_amx, const void* W8, int ldw, const float* sw,
                                 int M, int N, int K, int out_dtype, int mode, const float* bias, int act, void* out, int ldo, void* o_mx,
@@ -601,6 +623,24 @@ extern "C" int vitg_quant_rows_fp8(const void* x, long ldx, int in_dtype, void* 
     else if (in_dtype == DT_BF16) hipLaunchKernelGGL((quant_rows_kernel<bf16_t>), grid, blk, 0, s, (const bf16_t*)x, ldx, (unsigned char*)out8, ldo, scale, D);
     else if (in_dtype == DT_F16) hipLaunchKernelGGL((quant_rows_kernel<f16_t>), grid, blk, 0, s, (const f16_t*)x, ldx, (unsigned char*)out8, ldo, scale, D);
     else return VITG_ERR_DTYPE;
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}
+
+// vitg_norm_quant_fp8 on 16-bit rows (the tower's 16-bit residual stream): LayerNorm (b != NULL) / RMSNorm of x16 [M, ldx] -> e4m3 + per-token scales
+extern "C" int vitg_norm_quant_fp8_16(const void* x, long ldx, int in_dtype, const float* w, const float* b, void* out8, long ldo, float* scale,
+                                      long M, int D, float eps, void* stream) {
+    if (M <= 0) return 0;
+    if (D <= 0 || D > 4096 || ldo > 4096 || ldo < D) return VITG_ERR_SHAPE;
+    if (D % 4 || ldx % 4 || ldo % 16) return VITG_ERR_ALIGN;
+    if (!w || !x) return VITG_ERR_ARG;
+    if (in_dtype != DT_BF16 && in_dtype != DT_F16) return VITG_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((M + 3) / 4)), blk(256);
+#define NQ16(R, V) do { if (in_dtype == DT_F16) hipLaunchKernelGGL((norm_quant_kernel<R, V, f16_t>), grid, blk, 0, s, (const f16_t*)x, ldx, w, b, (unsigned char*)out8, ldo, scale, M, D, eps); \
+                        else hipLaunchKernelGGL((norm_quant_kernel<R, V, bf16_t>), grid, blk, 0, s, (const bf16_t*)x, ldx, w, b, (unsigned char*)out8, ldo, scale, M, D, eps); } while (0)
+    if (b) { if (ldo <= 1280) NQ16(false, 5); else NQ16(false, 16); }
+    else { if (ldo <= 1280) NQ16(true, 5); else NQ16(true, 16); }
+#undef NQ16
     return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
 }
 

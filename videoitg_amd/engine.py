@@ -307,6 +307,8 @@ class SelectorEngine:
         # fp8 tower: fc1 (+ GELU) hands its output to fc2 as e4m3 + MX block scales straight from its epilogue (vitg_gemm_fp8_mx) instead
         # of 16 bits + a stand-alone per-token quantiser pass; VITG_FP8_MX=0 keeps the per-token form (A/B, tests)
         self.fp8_mx = os.environ.get("VITG_FP8_MX", "1") not in ("", "0")
+        # fp8 tower GEMMs on the tower's 16-bit residual stream (round 4; before: the fp32 stream, its out-proj / fc2 HBM-bound)
+        self.fp8_r16 = os.environ.get("VITG_FP8_R16", "1") not in ("", "0")
         self._normplan: Dict[tuple, int] = {}
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[str, torch.Tensor] = {}
@@ -459,27 +461,45 @@ class SelectorEngine:
         Dv, Dvp, Fvp = v.hidden_size, pad64(v.hidden_size), pad64(v.intermediate_size)
         H, hd = v.num_attention_heads, v.head_dim
         eps, vdt = v.layer_norm_eps, self.vdtype
-        # (fp16 only: a bf16 stream would carry 8 mantissa bits through 26 layers; never together with fp8 tower GEMMs or the fused norm)
+        # (fp16 only: a bf16 stream would carry 8 mantissa bits through 26 layers; never together with the fused norm)
         # (and only when the projector runs in the same type: vitg_bilinear_pool16 writes the pooled rows in the tower's type - ADVICE r3)
-        r16 = self.residual16 and vdt == torch.float16 and self.dtype == vdt and not w.fp8_part("vit") and not self.fuse_norm and Dv % 8 == 0
+        # (round 4: fp8 tower GEMMs run on it too - vitg_gemm_fp8_res16 / vitg_norm_quant_fp8_16; VITG_FP8_R16=0 keeps that tier on the fp32 stream: A/B)
+        r16 = (self.residual16 and vdt == torch.float16 and self.dtype == vdt and (self.fp8_r16 or not w.fp8_part("vit")) and not self.fuse_norm
+               and Dv % 8 == 0)
         self.vit_stream_bytes = 2 if r16 else 4          # what this call's residual stream really was (bench.py prices LayerNorm / pool on it)
         x = self._buf("vit_x16" if r16 else "vit_x", (M, Dv), vdt if r16 else torch.float32)
         src = self.pool_sources(G, hw) if (hw is not None and self.skip_dead_rows and len(w.vit) > 0) else None
         full_layers = w.vit if src is None else w.vit[:-1]
 
         def norm(xs, gw, gb, name, cw=None):
-            """LayerNorm of stream rows as the A operand of the next GEMM (weight cw)"""
+            """LayerNorm of stream rows as the A operand of the next GEMM (weight cw: e4m3 + per-token scales for an Fp8Weight)"""
             if not r16:
                 return self._norm(xs, gw, gb, name, Dv, eps, vdt, cw=cw)
+            if isinstance(cw, Fp8Weight):
+                a8 = self._buf(name + "_q8", (xs.shape[0], K.pad128(Dv)), torch.uint8)
+                sa = self._buf(name + "_qs", (xs.shape[0],), torch.float32)
+                return K.norm_quant_fp8_16(xs, gw, gb, a8, sa, Dv, eps)
             h_ = self._buf(name, (xs.shape[0], Dvp), vdt, zero=True)
             return K.layernorm16(xs, gw, gb, h_, Dv, eps)
 
-        def update(a, wt, bias, xs):
-            """xs += a @ wt.T + bias  (16-bit stream: one rounding per update, fp32 accumulation inside the epilogue)"""
-            if r16:
+        def update(a, wt, bias, xs, name="vit_u", d=0):
+            """xs += a @ wt.T + bias  (16-bit stream: one rounding per update, fp32 accumulation inside the epilogue); `a` = 16-bit rows, quantised
+            here (buffer `name`, payload width d) when wt is an Fp8Weight"""
+            if r16 and isinstance(wt, Fp8Weight):
+                a8, sa = self._operand(a, name, d, wt)
+                K.gemm_fp8_res16(a8, wt.w8, wt.sw, xs, res16=xs, sa=sa, bias=bias)
+            elif r16:
                 K.gemm_res16(a, wt, xs, bias=bias, res16=xs)
             else:
                 self._gemm(a, wt, xs, mode=K.GEMM_F32, bias=bias, res=xs)
+
+        def mlp_mx16(hq8, fc1_w, fc1_b, fc2_w, fc2_b, xs, name):
+            """_mlp_fp8_mx on the 16-bit stream: the hidden activation leaves fc1 as e4m3 + MX block scales, fc2 adds into the 16-bit rows"""
+            Mx, kp = hq8[0].shape[0], fc2_w.w8.shape[1]
+            f8 = self._buf(name + "_f8", (Mx, kp), torch.uint8)
+            fsc = self._buf(name + "_fsc", (kp // 128, Mx, 4), torch.uint8)
+            K.gemm_fp8_mx(hq8[0], fc1_w.w8, fc1_w.sw, f8, out_dtype=self.vdtype, sa=hq8[1], o_mx=fsc, bias=fc1_b, act=K.ACT_GELU_TANH)
+            K.gemm_fp8_res16(f8, fc2_w.w8, fc2_w.sw, xs, res16=xs, a_mx=fsc, bias=fc2_b)
 
         # `pend` = (xh, stats) when the GEMM that produced x also emitted the operand / statistics of the next LayerNorm (fuse_norm)
         # patch embedding (+ bias + position table).  On the 16-bit stream the im2col happens inside the GEMM's operand loader
@@ -515,10 +535,13 @@ class SelectorEngine:
                         q_strides=st, k_strides=st, v_strides=st, o_strides=(P * Dvp, Dvp, hd), scale=scale,
                         variant=vit_variant)
             if r16:
-                update(o, lw.out_w, lw.out_b, x)
+                update(o, lw.out_w, lw.out_b, x, "vit_o", Dv)
                 h = norm(x, lw.ln2_w, lw.ln2_b, "vit_h", lw.fc1_w)
+                if self.fp8_mx and isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight):
+                    mlp_mx16(h, lw.fc1_w, lw.fc1_b, lw.fc2_w, lw.fc2_b, x, "vit")
+                    continue
                 self._gemm(h, lw.fc1_w, f, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
-                update(f, lw.fc2_w, lw.fc2_b, x)
+                update(f, lw.fc2_w, lw.fc2_b, x, "vit_f", Fvp)
                 continue
             pend = self._producer(self._operand(o, "vit_o", Dv, lw.out_w), lw.out_w, x, bias=lw.out_b, res=x, gamma=lw.ln2_w, name="vit", eps=eps,
                                   rms=False, dt=vdt)
@@ -559,17 +582,17 @@ class SelectorEngine:
                     q_strides=(Pc * Dv, Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * Dvp, Dvp, hd), scale=scale,
                     variant=vit_variant)
         if r16:
-            update(oc, lw.out_w, lw.out_b, xq)
+            update(oc, lw.out_w, lw.out_b, xq, "vit_oc", Dv)
         else:
             self._gemm(self._operand(oc, "vit_oc", Dv, lw.out_w), lw.out_w, xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
         hq = norm(xq, lw.ln2_w, lw.ln2_b, "vit_hq", lw.fc1_w)
         if self.fp8_mx and isinstance(lw.fc1_w, Fp8Weight) and isinstance(lw.fc2_w, Fp8Weight):
-            self._mlp_fp8_mx(hq, lw.fc1_w, lw.fc1_b, lw.fc2_w, lw.fc2_b, xq, "vit_c")
+            (mlp_mx16 if r16 else self._mlp_fp8_mx)(hq, lw.fc1_w, lw.fc1_b, lw.fc2_w, lw.fc2_b, xq, "vit_c")
             return xq, G, cmap, Pc
         fc = self._buf("vit_fc", (Mc, Fvp), vdt)
         self._gemm(hq, lw.fc1_w, fc, mode=K.GEMM_STORE16, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
         if r16:
-            update(fc, lw.fc2_w, lw.fc2_b, xq)
+            update(fc, lw.fc2_w, lw.fc2_b, xq, "vit_fc", Fvp)
         else:
             self._gemm(self._operand(fc, "vit_fc", Fvp, lw.fc2_w), lw.fc2_w, xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
         return xq, G, cmap, Pc

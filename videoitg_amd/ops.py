@@ -238,6 +238,40 @@ def norm_quant_fp8(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], 
     return out, scale
 
 
+def norm_quant_fp8_16(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, scale: torch.Tensor, d: int,
+                      eps: float):
+    """norm_quant_fp8 on 16-bit rows (the tower's 16-bit residual stream; vitg_norm_quant_fp8_16)"""
+    _req(x)
+    _req(out, torch.uint8)
+    _req(scale, torch.float32)
+    _lib.call("vitg_norm_quant_fp8_16", _ptr(x), x.stride(0), dt_code(x.dtype), _ptr(_req(w, torch.float32)),
+              _ptr(None if b is None else _req(b, torch.float32)), _ptr(out), out.stride(0), _ptr(scale), x.shape[0], d, eps, _stream())
+    return out, scale
+
+
+def gemm_fp8_res16(a8: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, out: torch.Tensor, *, res16: torch.Tensor,
+                   sa: Optional[torch.Tensor] = None, a_mx: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                   n: Optional[int] = None, m: Optional[int] = None) -> torch.Tensor:
+    """out16 = round16(scales * (a8 @ w8.T) + bias + res16): the 16-bit residual update on the fp8 weight path (vitg_gemm_fp8_res16);
+    a8 with per-token scales `sa` or MX block scales `a_mx` (uint8 [K/128, rows >= M, 4])"""
+    _req(a8, torch.uint8); _req(w8, torch.uint8); _req(sw, torch.float32); _req(out); _req(res16, out.dtype)
+    M = a8.shape[0] if m is None else m
+    N = w8.shape[0] if n is None else n
+    K = w8.shape[1]
+    assert a8.shape[1] == K and a8.stride(1) == 1 and w8.stride(1) == 1 and out.stride(1) == 1 and res16.stride(1) == 1
+    assert (sa is None) != (a_mx is None)
+    if sa is not None:
+        _req(sa, torch.float32)
+    else:
+        _req(a_mx, torch.uint8)
+        assert a_mx.dim() == 3 and a_mx.shape[0] == K // 128 and a_mx.shape[1] >= M and a_mx.shape[2] == 4 and a_mx.is_contiguous()
+    if bias is not None:
+        _req(bias, torch.float32)
+    _lib.call("vitg_gemm_fp8_res16", _ptr(a8), a8.stride(0), _ptr(sa), _ptr(a_mx), 0 if a_mx is None else a_mx.shape[1], _ptr(w8), w8.stride(0),
+              _ptr(sw), M, N, K, dt_code(out.dtype), _ptr(bias), _ptr(out), out.stride(0), _ptr(res16), res16.stride(0), _stream())
+    return out
+
+
 def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, out: torch.Tensor, *, mode: int,
              out_dtype: torch.dtype, n: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
              res: Optional[torch.Tensor] = None, res_mod: int = 0, m: Optional[int] = None) -> torch.Tensor:

@@ -146,6 +146,13 @@ _def("gemm_fp8(Tensor a8, Tensor sa, Tensor w8, Tensor sw, Tensor(a!) out, int m
           None)[1],
      lambda *a, **k: None)
 
+_def("norm_quant_fp8_16(Tensor x, Tensor w, Tensor? b, Tensor(a!) out, Tensor(b!) scale, int d, float eps) -> ()",
+     lambda x, w, b, out, scale, d, eps: (_raw.norm_quant_fp8_16(x, w, b, out, scale, d, eps), None)[1], lambda *a, **k: None)
+_def("gemm_fp8_res16(Tensor a8, Tensor w8, Tensor sw, Tensor(a!) out, Tensor res16, Tensor? sa=None, Tensor? a_mx=None, Tensor? bias=None, "
+     "int? n=None, int? m=None) -> ()",
+     lambda a8, w8, sw, out, res16, sa=None, a_mx=None, bias=None, n=None, m=None:
+         (_raw.gemm_fp8_res16(a8, w8, sw, out, res16=res16, sa=sa, a_mx=a_mx, bias=bias, n=n, m=m), None)[1],
+     lambda *a, **k: None)
 _def("gemm_fp8_mx(Tensor a8, Tensor w8, Tensor sw, Tensor(a!) out, int out_dtype, Tensor? sa=None, Tensor? a_mx=None, Tensor(b!)? o_mx=None, "
      "int? n=None, Tensor? bias=None, int act=0, Tensor? res=None, int? m=None, bool swiglu=False) -> ()",
      lambda a8, w8, sw, out, out_dtype, sa=None, a_mx=None, o_mx=None, n=None, bias=None, act=0, res=None, m=None, swiglu=False:
@@ -293,6 +300,16 @@ class _Namespace:
         return out
 
     @staticmethod
+    def norm_quant_fp8_16(x, w, b, out, scale, d, eps):
+        _ops.norm_quant_fp8_16(x, w, b, out, scale, d, eps)
+        return out, scale
+
+    @staticmethod
+    def gemm_fp8_res16(a8, w8, sw, out, *, res16, sa=None, a_mx=None, bias=None, n=None, m=None):
+        _ops.gemm_fp8_res16(a8, w8, sw, out, res16, sa, a_mx, bias, n, m)
+        return out
+
+    @staticmethod
     def gemm_fp8_mx(a8, w8, sw, out, *, out_dtype, sa=None, a_mx=None, o_mx=None, n=None, bias=None, act=0, res=None, m=None, swiglu=False):
         _ops.gemm_fp8_mx(a8, w8, sw, out, _CODE[out_dtype], sa, a_mx, o_mx, n, bias, act, res, m, swiglu)
         return out
@@ -305,4 +322,4 @@ class _Namespace:
 K = _Namespace()
 OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
                        "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx",
-                       "gemm_res16", "layernorm16", "bilinear_pool16", "patch_embed16"] + (["gemm_streamk"] if _raw._lib.PROFILING else [])
+                       "gemm_res16", "layernorm16", "bilinear_pool16", "patch_embed16", "norm_quant_fp8_16", "gemm_fp8_res16"] + (["gemm_streamk"] if _raw._lib.PROFILING else [])
