@@ -67,3 +67,17 @@ def test_plain_gpus_n_command_becomes_its_own_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+
+
+def test_hwmon_sampler_is_silent_without_a_gpu():
+    """`roofline.power_clock` comes from the amdgpu hwmon files of the GPU the bench runs on; where they do not exist (this CPU container, another
+    driver) the sampler starts nothing and reports None - the JSON line then simply has no such block."""
+    s = bench.HwmonSampler()
+    if s.power is None:                       # no matching hwmon directory: the normal case off the GPU box
+        s.start()
+        assert s.stop() is None
+    else:                                     # a GPU box: a short sample carries the three readings
+        import time
+        s.start(); time.sleep(0.2)
+        r = s.stop()
+        assert r is None or (r["power_w"] > 0 and r["samples"] >= 1)
