@@ -27,6 +27,12 @@ for name, M, N, K, mode in shapes:
     t8 = timeit(lambda: ops.gemm_fp8(a8, sa, w8, sw, out, mode=mode, out_dtype=dt, res=res))
     tq = timeit(lambda: ops.quant_rows_fp8(a, K, a8, sa))
     fl = 2.0 * M * N * K / 1e9
+    if name in ("vit_out", "vit_fc2"):        # the tower's residual GEMMs on its 16-bit stream (round 4): fp8 operands, 16-bit residual in / out
+        x16 = torch.randn((M, N), device="cuda").to(dt)
+        t8r = timeit(lambda: ops.gemm_fp8_res16(a8, w8, sw, x16, res16=x16, sa=sa))
+        t16r = timeit(lambda: ops.gemm_res16(a, w, x16, res16=x16))
+        print(f"{name:9s} 16-bit residual stream: fp16 {2.0 * M * N * K / 1e9 / t16r:7.1f} TF/s ({t16r:.3f} ms)   fp8 {2.0 * M * N * K / 1e9 / t8r:7.1f} TF/s ({t8r:.3f} ms)", flush=True)
+        del x16
     print(f"{name:9s} M={M:6d} N={N:5d} K={K:5d} mode={mode}: fp16 {fl / t16:7.1f} TF/s ({t16:.3f} ms)   fp8 {fl / t8:7.1f} TF/s ({t8:.3f} ms)   "
           f"quant_rows(A) {tq:.3f} ms = {(M * K * 3) / tq / 1e9:.2f} TB/s", flush=True)
     del a, w, out, a8, w8
