@@ -55,6 +55,9 @@ def parse():
                     help="BASELINE.json configs[3]: V concurrent videos PER GPU, each scored by replaying a hipGraph-captured forward "
                          "(replicas: one model per GPU, no collective on the data path; weak scaling).  0 = the default one-video job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-complete", action="store_true",
+                    help="additionally run ONE complete fp32 oracle pass of B0 (512 x 384^2, the reference-native shape; SURVEY.md 8d) on this host's "
+                         "cores and report it beside the extrapolated cpu_baseline (tens of minutes; off by default, never inside the timed region)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the from-uint8-frames (GPU preprocessing) measurement")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--fp8-policy", default="llm_mlp",
@@ -138,6 +141,99 @@ def layer_gemm_flops_by_name(cfg, T, R, n_text, skip_dead_rows=True):
             "vit.fc2": full * Dv * Fv + last * Pc * Dv * Fv,
             "llm.qkv": Ll * 2.0 * N * D * (D + 2 * kvw), "llm.o": Ll * 2.0 * N * D * D,
             "llm.gu": Ll * 2.0 * N * 2 * D * Fl, "llm.down": Ll * 2.0 * N * D * Fl}
+
+
+def algorithmic_gemm_bytes(cfg, T, R, n_text, stream_bytes=2, skip_dead_rows=True):
+    """HBM bytes the step's GEMM launches HAVE to move, per video: every operand read once, every output written once, residual tiles read
+    once (16-bit activations and weights; the tower's residual stream at `stream_bytes` per element, the decoder's at 4).  What
+    `roofline.traffic` (fabric bytes from the PMC profile) is to be read against.  Returns (bytes, launches)."""
+    v = cfg.vision
+    G = R // v.patch_size
+    P = G * G
+    Dv, Fv, Lv = v.hidden_size, v.intermediate_size, cfg.num_vit_layers_needed()
+    fl = algorithmic_flops(cfg, T, R, n_text)
+    D, Fl, Ll = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    kvw = cfg.num_key_value_heads * cfg.head_dim
+    N, M, s = fl["N"], T * P, stream_bytes
+    Mp = T * fl["hw"] ** 2
+    by = T * 3 * R * R * 2 + 3 * v.patch_size ** 2 * Dv * 2 + M * Dv * s + P * Dv * 4                       # patch embedding (+ position table)
+    layer = ((M * Dv * 2 + 3 * Dv * Dv * 2 + M * 3 * Dv * 2)                                                # qkv
+             + (M * Dv * 2 + Dv * Dv * 2 + 2 * M * Dv * s)                                                  # out-proj: residual read + written
+             + (M * Dv * 2 + Dv * Fv * 2 + M * Fv * 2)                                                      # fc1
+             + (M * Fv * 2 + Dv * Fv * 2 + 2 * M * Dv * s))                                                 # fc2
+    by += Lv * layer
+    by += (Mp * Dv * 2 + Dv * D * 2 + Mp * D * 2) + (Mp * D * 2 + D * D * 2 + Mp * D * 4)                   # projector
+    llm = ((N * D * 2 + D * (D + 2 * kvw) * 2 + N * (D + 2 * kvw) * 2)                                      # qkv
+           + (N * D * 2 + D * D * 2 + 2 * N * D * 4)                                                        # o: fp32 residual read + written
+           + (N * D * 2 + 2 * D * Fl * 2 + N * Fl * 2)                                                      # gate/up -> silu(gate) * up
+           + (N * Fl * 2 + D * Fl * 2 + 2 * N * D * 4))                                                     # down
+    by += Ll * llm
+    return float(by), 1 + 4 * Lv + 2 + 4 * Ll
+
+
+def preflight_ranks(world: int, visible_devices: int, backend: str, single_device: bool):
+    """`bench.py --gpus N` must fail fast and say why.  -> None, or the reason this job cannot run as asked."""
+    if world < 1:
+        return f"--gpus {world}: need at least one rank"
+    if single_device:
+        return None                                  # the one-GPU dry run of the N > 1 code path (gloo; timings mean nothing)
+    if world > visible_devices:
+        return (f"{world} ranks asked for, {visible_devices} GPU(s) visible to this process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?): one process "
+                f"per GPU is the only layout this job runs (the reference: accelerate launch --num_processes=8, scripts/eval_lmms_eval/videomme_grounding.sh:3-5)")
+    if world > 1 and backend != "nccl":
+        return (f"VITG_DIST_BACKEND={backend}: a multi-GPU measurement runs over RCCL (backend 'nccl'); another backend is accepted only with "
+                f"VITG_BENCH_SINGLE_DEVICE=1 (the dry run)")
+    return None
+
+
+class Watchdog:
+    """A rank that hangs (a peer died, a collective never completes) must not hang the driver: if `phase()` is not re-armed or `stop()`ped within
+    `limit_s`, say which phase hung and end the process with exit code 124."""
+
+    def __init__(self, limit_s: float, rank: int = 0, _exit=None, _err=None):
+        import threading
+        self.limit, self.rank, self._t, self._threading = float(limit_s), rank, None, threading
+        self._exit = _exit or (lambda code: os._exit(code))
+        self._err = _err or (lambda m: (sys.stderr.write(m + "\n"), sys.stderr.flush()))
+        self.fired = None
+
+    def phase(self, name: str):
+        self.stop()
+        if self.limit <= 0:
+            return
+
+        def fire():
+            self.fired = name
+            self._err(f"bench.py: rank {self.rank} made no progress in phase '{name}' for {self.limit:.0f} s (VITG_BENCH_TIMEOUT_S) - a peer rank "
+                      f"died or a collective never completed; giving up instead of hanging the launcher")
+            self._exit(124)
+        self._t = self._threading.Timer(self.limit, fire)
+        self._t.daemon = True
+        self._t.start()
+
+    def stop(self):
+        if self._t is not None:
+            self._t.cancel()
+            self._t = None
+
+
+def first_step_with_overlap_fallback(step, eng, any_rank_failed):
+    """The context-parallel layers launch their K|V all-gather asynchronously from a side stream (engine.llm_forward, parallel.RowGatherer.start).
+    That path has met RCCL on ONE rank only; if its first step raises on ANY rank, every rank falls back to the blocking exchange
+    (eng.cp_overlap = False, what VITG_CP_OVERLAP=0 selects) and says so in the JSON line.  `any_rank_failed(bool) -> bool` is the
+    agreement (an all-reduce MAX over ranks).  -> None, or the reason of the fallback."""
+    err = None
+    try:
+        step()
+    except Exception as e:                                        # noqa: BLE001 - whatever the async path raised is the reason
+        err = f"{type(e).__name__}: {e}"
+    if not any_rank_failed(err is not None):
+        return None
+    if not getattr(eng, "cp_overlap", False):
+        raise RuntimeError(f"context-parallel step failed with the blocking exchange too: {err}")
+    eng.cp_overlap = False
+    step()                                                        # must work on every rank now; an exception here ends the job loudly
+    return err or "another rank's first step failed on the asynchronous exchange"
 
 
 def parity_block(T, R, prompt_len, seed, logits, order, tol=1e-3):
@@ -248,6 +344,7 @@ class HwmonSampler:
         import glob
         import threading
         self.power = self.sclk = self.cap = None
+        self.reason = None                               # why there is no reading (the line says so instead of dropping the key)
         want = None
         try:
             pr = torch.cuda.get_device_properties(torch.cuda.current_device())
@@ -267,6 +364,10 @@ class HwmonSampler:
                 self.cap = os.path.join(d, "power1_cap") if "power1_cap" in names else None
                 break
         self.p, self.f, self._stop = [], [], False
+        if self.power is None:
+            n_hw = len(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+            self.reason = (f"no amdgpu hwmon power file for PCI device {want}: {n_hw} hwmon director{'y' if n_hw == 1 else 'ies'} under /sys/class/drm/card*/device/hwmon "
+                           f"(container without /sys/class/drm, or another driver layout)")
         self._thread = threading.Thread(target=self._run, daemon=True) if self.power else None
 
     @staticmethod
@@ -298,6 +399,7 @@ class HwmonSampler:
         self._stop = True
         self._thread.join()
         if not self.p:
+            self.reason = f"{self.power} could not be read"
             return None
         self.p, self.f = self.p[len(self.p) // 3:], self.f[len(self.f) // 3:]      # the power file is itself a running average: drop its run-in
         cap = self._read(self.cap) if self.cap else None
@@ -380,6 +482,26 @@ def cpu_baseline(cfg, T, R, n_text, cores):
                                  "frames_per_s": round(rec["frames"] / (o["seconds"]["tower"] + o["seconds"]["llm"]), 4)}
     out["complete_passes_build_container"] = done
     return out
+
+
+def cpu_complete_pass(cfg, threads, T=512, R=384, prompt_len=60):
+    """--cpu-complete: ONE complete fp32 oracle pass of B0 (512 frames x 384^2, the reference-native shape; 563 TFLOP) on this host - what SURVEY.md
+    8(d) asks for beside the extrapolated sample "when the host has >= 64 cores".  Same streamed counter-generated weights as the committed fixture
+    tests/golden/full_b0_512x384.json (made on the build container's 8 vCPUs), whose logits this pass has to reproduce."""
+    from oracle import fullsize                      # checker/baseline only
+    torch.set_num_threads(threads)
+    ids, pix = fullsize.workload_inputs(cfg, T, R, prompt_len)
+    with torch.inference_mode():
+        out = fullsize.streaming_forward(cfg, ids, pix, seed=0, frame_chunk=32)
+    sec = out["seconds"]
+    rec = {"frames": T, "resolution": R, "threads": threads, "seconds": sec, "seconds_compute": round(sec["tower"] + sec["llm"], 1),
+           "frames_per_s": round(T / (sec["tower"] + sec["llm"]), 4),
+           "what": "complete oracle pass (torch CPU fp32), all 26 + 28 layers on all frames / tokens; weight generation excluded like in the fixtures"}
+    path = os.path.join(ROOT, "tests", "golden", "full_b0_512x384.json")
+    if os.path.exists(path):
+        want = torch.tensor(json.load(open(path))["logits"])
+        rec["max_abs_dlogit_vs_committed_fixture"] = round((out["logits"].float() - want).abs().max().item(), 6)
+    return rec
 
 
 def time_video_replays(eng, cfg, dtype, dev, T, R, prompt_len, n_videos, first_seed, steps, warmup, barrier):
@@ -466,25 +588,39 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    single_device = os.environ.get("VITG_BENCH_SINGLE_DEVICE", "0") not in ("", "0")
+    backend_asked = os.environ.get("VITG_DIST_BACKEND", "nccl")        # "nccl" = RCCL over xGMI
     if world != args.gpus:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            why = preflight_ranks(args.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0, backend_asked, single_device)
+            if why:                                     # before any rank is started: the launcher never sees a half-started job
+                sys.exit(f"bench.py: {why}")
             return spawn_ranks(args.gpus)               # plain `python bench.py --gpus N`: this process becomes the launcher of its N ranks
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path for the product)"
-    if os.environ.get("VITG_BENCH_SINGLE_DEVICE", "0") not in ("", "0"):
+    why = preflight_ranks(world, torch.cuda.device_count(), backend_asked, single_device)
+    if why:
+        sys.exit(f"bench.py: rank {rank}: {why}")
+    if single_device:
         local = 0                               # dry run of the N > 1 code path on a one-GPU box (with VITG_DIST_BACKEND=gloo: RCCL refuses
                                                 # two ranks on one device); timings of such a run mean nothing
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = None
+    # a hung rank ends itself with a message (exit 124) instead of hanging the launcher: per phase (rendezvous, model build, warm-up, timed steps)
+    dog = Watchdog(float(os.environ.get("VITG_BENCH_TIMEOUT_S", "900")) if world > 1 else 0.0, rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("VITG_DIST_BACKEND", "nccl")          # "nccl" = RCCL over xGMI
+        backend = backend_asked
+        dog.phase("rendezvous (init_process_group)")
+        limit = datetime.timedelta(seconds=float(os.environ.get("VITG_DIST_TIMEOUT_S", "300")))      # collectives: RCCL's own watchdog aborts after this
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
+        dog.phase("model build")
 
     from videoitg_amd import ops, synth
     from videoitg_amd.config import ITGConfig, tiny_config
@@ -570,9 +706,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    cp_fallback = None
+    dog.phase("first step (RCCL communicator set-up + first context-parallel forward)")
+    if cp is not None:
+        def any_rank_failed(mine: bool) -> bool:
+            import torch.distributed as dist
+            flag = torch.tensor([1 if mine else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            return bool(flag.item())
+        cp_fallback = first_step_with_overlap_fallback(step, eng, any_rank_failed)
+    dog.phase("warm-up")
     for _ in range(args.warmup):
         step()
     barrier()
+    dog.phase("timed steps")
     timer.enabled = timer8.enabled = True               # HIP events around the DOMINANT kernel's launches only (the roofline contract)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -580,8 +727,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = timer8.enabled = False
+    dog.stop()
     dt_side = dt / args.steps
-    power_clock = None
+    power_clock, power_reason = None, "not sampled: multi-GPU run" if world > 1 else "not sampled: VITG_BENCH_NO_SIDE_PASS"
     if world == 1 and os.environ.get("VITG_BENCH_NO_SIDE_PASS", "0") in ("", "0"):
         # the other kernel classes (attention per head size, norms): one extra step with THEIR events, outside the timed region - two
         # event records per launch on ~450 more launches per step cost the step ~1 % when they sat inside it
@@ -599,6 +747,7 @@ def main():
             step()
         barrier()
         power_clock = hwmon.stop()
+        power_reason = hwmon.reason
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -621,6 +770,9 @@ def main():
         avg_ms = gemm_ms / max(n_launch, 1)
         achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         achieved_alg = fl["gemm"] / world * args.steps / max(gemm_ms * 1e-3, 1e-9) / 1e12
+        # what the GEMM launches HAVE to move (operands once, outputs once, residual tiles once) - the figure the fabric traffic is read against
+        alg_bytes, alg_launches = algorithmic_gemm_bytes(cfg, T, R, ids.shape[1] - 1, 2 if eng.residual16 else 4, eng.skip_dead_rows)
+        alg_per_launch = alg_bytes / world / alg_launches
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
         if os.path.exists(tpath):
@@ -649,11 +801,24 @@ def main():
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "traffic": traffic, "traffic_source": "profile constant: profiles/gemm_traffic.json, the rocprofv3 PMC passes of tools/profile_step.sh "
                                                                "(FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE) on this workload - NOT measured in this run",
+                         "traffic_algorithmic": round(alg_per_launch), "traffic_over_algorithmic": round(traffic / alg_per_launch, 2) if traffic else None,
+                         "traffic_algorithmic_what": "operands read once + outputs written once + residual tiles read once, 16-bit operands, per GEMM launch "
+                                                     f"({alg_bytes / 1e9:.0f} GB per video over {alg_launches} launches)",
                          "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": round(per_launch_flops / 1e12, 4), "achieved_algorithmic": round(achieved_alg, 1),
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 3)},
             "top32": sorted(order[:32]),
         }
+        from videoitg_amd import _lib
+        out["library"] = {"path": os.path.relpath(_lib.LIB_PATH, ROOT) if _lib.LIB_PATH.startswith(ROOT) else _lib.LIB_PATH,
+                          "VITG_LIB_PATH_override": bool(os.environ.get("VITG_LIB_PATH"))}
+        out["tower_residual_stream_bytes"] = eng.vit_stream_bytes
+        if cp is not None:
+            out["cp_overlap"] = bool(eng.cp_overlap)
+            out["cp_overlap_fallback"] = cp_fallback       # None, or why every rank fell back to the blocking K|V exchange (VITG_CP_OVERLAP=0)
+        if power_clock is None:
+            out["roofline"]["power_clock"] = None
+            out["roofline"]["power_clock_unavailable"] = power_reason
         if power_clock is not None:
             # the whole step (72 % of it GEMM time) at the clock the package power cap leaves it; `peak` / `frac` above stay on the nominal 2.4 GHz
             power_clock["what"] = ("hwmon of this GPU sampled every 20 ms over three extra steps after the timed region (first third dropped): package power, its cap, shader clock; "
@@ -671,6 +836,9 @@ def main():
             on8 = [k for k in by_name if eng.w.fp8_on(k)]                   # the GEMMs this policy runs on the fp8 kernel
             layer_gemm = sum(by_name[k] for k in on8) / world
             ach8 = layer_gemm * args.steps / max(ms8 * 1e-3, 1e-9) / 1e12
+            out["fp8"] = {"policy": args.fp8_policy, "gemms_on_fp8": on8, "tower_on_16bit_stream": bool(getattr(eng, "fp8_r16", False)),
+                          "note": "--fp8-policy defaults to llm_mlp since round 4 (round 3: all); tiers 'all' / 'seven' run the tower on the 16-bit residual "
+                                  "stream since round 4 - not like-for-like with the round-3 --fp8 records"}
             out["dtype"] = (f"fp8 policy '{args.fp8_policy}' (e4m3 weights per output channel + e4m3 activations into those layer GEMMs; "
                             f"{args.dtype} elsewhere)")
             out["roofline"] = {"kernel": "gemm_fp8_kernel (the layer GEMMs this policy runs on e4m3)", "gemms": on8, "bound": "mfma", "achieved": round(ach8, 1), "peak": 5000.0,
@@ -936,6 +1104,14 @@ def main():
                 cores = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(cfg, T, R, ids.shape[1] - 1, cores)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            if args.cpu_complete:
+                # validates the extrapolation once: the sample above prices B0's work as t_vit(384-equivalent) ... so compare like with like -
+                # the complete pass is B0 (512 x 384^2), the extrapolated figure restated for B0 from the same per-token rates
+                th = out["cpu_baseline"]["threads"]
+                cpass = cpu_complete_pass(cfg, max(th["tower"], th["decoder"]))
+                fl_b0 = algorithmic_flops(cfg, 512, 384, ids.shape[1] - 1)["total"]
+                cpass["extrapolated_frames_per_s_same_flops"] = round(out["cpu_baseline"]["value"] * fl["total"] / fl_b0, 4)
+                out["cpu_baseline"]["complete_pass_this_host"] = cpass
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

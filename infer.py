@@ -39,8 +39,8 @@ def frame_at(video_path, frame_idx):
     """one decoded frame (uint8 HWC) by its ORIGINAL frame index - what infer.py:88-89 does with decord's vr[frame_idx]"""
     if video_path == "synthetic":
         return np.random.default_rng(1234 + int(frame_idx)).integers(0, 256, (120, 160, 3), dtype=np.uint8)
-    from decord import VideoReader, cpu                 # not in this image; same ImportError the reference raises
-    return VideoReader(video_path, ctx=cpu(0), num_threads=4)[frame_idx].asnumpy()
+    from videoitg_amd.mm_utils import open_video_reader   # decord, or the built-in reader for .avi (MJPEG) / .y4m files
+    return open_video_reader(video_path, num_threads=4)[frame_idx].asnumpy()
 
 
 def save_selected_frames(video_path, selected_indices, save_dir="./vis"):

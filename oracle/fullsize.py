@@ -30,7 +30,7 @@ def workload_inputs(cfg, T: int, R: int, prompt_len: int, pix_seed: int = 1234):
 
 
 def streaming_forward(cfg, input_ids: torch.Tensor, pix: torch.Tensor, seed: int = 0, frame_chunk: int = 16,
-                      log=None) -> Dict[str, object]:
+                      log=None, plan=None) -> Dict[str, object]:
     """One sample (B=1, one <image>), counter-generated weights of `cfg`'s architecture -> dict(logits fp32 [T], checks, seconds)."""
     say = log or (lambda *_: None)
     v = cfg.vision
@@ -39,7 +39,7 @@ def streaming_forward(cfg, input_ids: torch.Tensor, pix: torch.Tensor, seed: int
     n_vit = cfg.num_vit_layers_needed()
     vsd = synth.counter_state_dict(
         _specs(synth.vision_param_specs(cfg),
-               lambda k: k.startswith("vision_model.embeddings.") or int(k.split(".")[3]) < n_vit), seed)
+               lambda k: k.startswith("vision_model.embeddings.") or int(k.split(".")[3]) < n_vit), seed, plan=plan)
     t_w = time.perf_counter() - t0
     t1 = time.perf_counter()
     feats = O.siglip_tower(pix.float(), vsd, patch=v.patch_size, num_heads=v.num_attention_heads,
@@ -50,18 +50,21 @@ def streaming_forward(cfg, input_ids: torch.Tensor, pix: torch.Tensor, seed: int
     del vsd
     lspecs = list(synth.llm_param_specs(cfg))
     t2 = time.perf_counter()
-    sd = synth.counter_state_dict(_specs(lspecs, lambda k: not k.startswith("model.layers.") and k != "model.embed_tokens.weight"), seed)
+    sd = synth.counter_state_dict(_specs(lspecs, lambda k: not k.startswith("model.layers.") and k != "model.embed_tokens.weight"), seed, plan=plan)
     t_w += time.perf_counter() - t2
     visual = O.mlp_projector(feats, sd, cfg.vision_token_num)
     checks = dict(vit_sum=float(feats.double().sum()), vit_abs=float(feats.double().abs().sum()),
                   vit_sample=feats.reshape(-1)[:: max(1, feats.numel() // 16)][:16].tolist(),
-                  visual_sum=float(visual.double().sum()), visual_abs=float(visual.double().abs().sum()))
+                  visual_sum=float(visual.double().sum()), visual_abs=float(visual.double().abs().sum()),
+                  vit_absmax=float(feats.abs().max()), visual_absmax=float(visual.abs().max()))
     del feats
     # embedding rows of the prompt only (the table is 545 M values; 60 rows are read)
     ids = input_ids.reshape(-1)
     text = ids[ids != O.IMAGE_TOKEN_INDEX]
     espec = next(s for s in lspecs if s[0] == "model.embed_tokens.weight")
     small = synth.counter_rows(seed, espec[0], espec[1], text, espec[2], espec[3])
+    if plan is not None:
+        small = plan.apply({"model.embed_tokens.weight": small})["model.embed_tokens.weight"]
     remap = ids.clone()
     remap[ids != O.IMAGE_TOKEN_INDEX] = torch.arange(text.numel())
     x, mask, tts = O.splice(remap.unsqueeze(0), None, [visual], {"model.embed_tokens.weight": small},
@@ -70,21 +73,23 @@ def streaming_forward(cfg, input_ids: torch.Tensor, pix: torch.Tensor, seed: int
     N = x.shape[1]
     cos, sin = O.rope_tables(N, cfg.head_dim, cfg.rope_theta)
     t_llm = 0.0
-    layer_abs = []
+    layer_abs, layer_max = [], []
     for i in range(cfg.num_hidden_layers):
         t3 = time.perf_counter()
-        sdi = synth.counter_state_dict(_specs(lspecs, lambda k: k.startswith(f"model.layers.{i}.")), seed)
+        sdi = synth.counter_state_dict(_specs(lspecs, lambda k: k.startswith(f"model.layers.{i}.")), seed, plan=plan)
         t_w += time.perf_counter() - t3
         t4 = time.perf_counter()
         x = O.qwen2_layer(x, sdi, i, num_heads=cfg.num_attention_heads, num_kv_heads=cfg.num_key_value_heads,
                           eps=cfg.rms_norm_eps, cos=cos, sin=sin, key_mask=None)
         t_llm += time.perf_counter() - t4
         layer_abs.append(float(x.double().abs().mean()))
+        layer_max.append(float(x.abs().max()))
         del sdi
         say(f"llm layer {i} done ({t_llm:.0f}s so far)")
     h = O.rms_norm(x, sd["model.norm.weight"], cfg.rms_norm_eps)
     logits = O.score_head(h, tts, [T], sd)[0].reshape(-1)
     checks["llm_layer_mean_abs"] = layer_abs
+    checks["llm_absmax"] = max(layer_max)
     checks["final_sum"] = float(h.double().sum())
     return dict(logits=logits, N=N, checks=checks,
                 seconds=dict(weights=round(t_w, 1), tower=round(t_vit, 1), llm=round(t_llm, 1),

@@ -58,8 +58,10 @@ def test_plain_gpus_n_command_becomes_its_own_launcher(monkeypatch):
     seen = {}
     monkeypatch.setattr(bench.os, "execv", lambda exe, cmd: seen.update(exe=exe, cmd=cmd))
     monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VITG_DIST_BACKEND", "VITG_BENCH_SINGLE_DEVICE"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)   # an 8-GPU node as the launcher's pre-flight sees it
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
     bench.main()                                                       # returns right after the (mocked) exec: no GPU is touched
     cmd = seen["cmd"]
     assert seen["exe"] == bench.sys.executable and cmd[:3] == [bench.sys.executable, "-m", "torch.distributed.run"]
@@ -69,6 +71,97 @@ def test_plain_gpus_n_command_becomes_its_own_launcher(monkeypatch):
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
 
 
+def test_gpus_n_fails_fast_and_says_why(monkeypatch):
+    """more ranks than visible GPUs, or a backend that is not RCCL, ends `bench.py --gpus N` with a reason BEFORE any rank starts
+    (nothing is exec'ed, nothing hangs); the one-GPU dry run (VITG_BENCH_SINGLE_DEVICE=1 + gloo) stays possible."""
+    import pytest
+    assert bench.preflight_ranks(8, 8, "nccl", False) is None and bench.preflight_ranks(1, 1, "nccl", False) is None
+    assert "4 GPU(s) visible" in bench.preflight_ranks(8, 4, "nccl", False)
+    assert "RCCL" in bench.preflight_ranks(2, 2, "gloo", False)
+    assert bench.preflight_ranks(2, 1, "gloo", True) is None
+    assert bench.preflight_ranks(0, 8, "nccl", False)
+    execd = []
+    monkeypatch.setattr(bench.os, "execv", lambda exe, cmd: execd.append(cmd))
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "8"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VITG_DIST_BACKEND", "VITG_BENCH_SINGLE_DEVICE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "8 ranks asked for, 2 GPU(s) visible" in str(e.value) and not execd
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("VITG_DIST_BACKEND", "gloo")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "RCCL" in str(e.value) and not execd
+
+
+def test_watchdog_names_the_phase_that_hung():
+    """a rank that makes no progress ends ITSELF with exit code 124 and the name of the phase, instead of hanging the launcher"""
+    import time
+    said, codes = [], []
+    dog = bench.Watchdog(0.05, rank=3, _exit=codes.append, _err=said.append)
+    dog.phase("rendezvous")
+    dog.phase("warm-up")                       # re-arming cancels the first timer
+    time.sleep(0.3)
+    assert codes == [124] and dog.fired == "warm-up" and "rank 3" in said[0] and "'warm-up'" in said[0]
+    quiet = bench.Watchdog(0.05, _exit=codes.append, _err=said.append)
+    quiet.phase("timed steps")
+    quiet.stop()
+    time.sleep(0.15)
+    assert codes == [124]                      # stopped in time: nothing fired
+    off = bench.Watchdog(0.0, _exit=codes.append, _err=said.append)      # single-GPU runs: no watchdog
+    off.phase("x")
+    time.sleep(0.05)
+    assert codes == [124]
+
+
+def test_first_step_falls_back_to_the_blocking_exchange_on_every_rank():
+    """the asynchronous K|V exchange has met RCCL on one rank only: if the first context-parallel step raises on ANY rank, all ranks switch to the
+    blocking exchange (eng.cp_overlap = False = VITG_CP_OVERLAP=0), the step is repeated, and the reason goes into the JSON line"""
+    import pytest
+
+    class Eng:
+        cp_overlap = True
+    calls = []
+
+    def step_ok():
+        calls.append("ok")
+    eng = Eng()
+    assert bench.first_step_with_overlap_fallback(step_ok, eng, lambda mine: mine) is None and eng.cp_overlap and calls == ["ok"]
+    # this rank is fine, another one failed: fall back anyway (the agreement is an all-reduce MAX)
+    eng = Eng()
+    why = bench.first_step_with_overlap_fallback(step_ok, eng, lambda mine: True)
+    assert "another rank" in why and eng.cp_overlap is False and calls == ["ok", "ok", "ok"]
+
+    def step_async_breaks():
+        if eng.cp_overlap:
+            raise RuntimeError("NCCL error: in-place all_gather on a side stream")
+        calls.append("blocking")
+    eng = Eng()
+    why = bench.first_step_with_overlap_fallback(step_async_breaks, eng, lambda mine: mine)
+    assert why.startswith("RuntimeError: NCCL error") and eng.cp_overlap is False and calls[-1] == "blocking"
+    eng = Eng()
+    eng.cp_overlap = False                     # already blocking and still failing: loud
+
+    def always():
+        raise ValueError("boom")
+    with pytest.raises(RuntimeError, match="blocking exchange too"):
+        bench.first_step_with_overlap_fallback(always, eng, lambda mine: mine)
+
+
+def test_algorithmic_gemm_bytes_of_the_headline_workload():
+    """what the step's 220 GEMM launches have to move: ~2.8 GB per launch on the 16-bit tower stream (623 GB / 220), more on the fp32 one"""
+    from videoitg_amd.config import ITGConfig
+    cfg = ITGConfig()
+    by, n = bench.algorithmic_gemm_bytes(cfg, 512, 448, 60, 2)
+    assert n == 1 + 4 * 26 + 2 + 4 * 28 == 219
+    assert 2.6e9 < by / n < 3.1e9
+    by4, _ = bench.algorithmic_gemm_bytes(cfg, 512, 448, 60, 4)
+    assert by4 - by == (26 * 4 + 1) * 512 * 1024 * 1152 * 2                       # out-proj + fc2 read and write the stream, the patch embedding writes it
+
+
 def test_hwmon_sampler_is_silent_without_a_gpu():
     """`roofline.power_clock` comes from the amdgpu hwmon files of the GPU the bench runs on; where they do not exist (this CPU container, another
     driver) the sampler starts nothing and reports None - the JSON line then simply has no such block."""
@@ -76,6 +169,7 @@ def test_hwmon_sampler_is_silent_without_a_gpu():
     if s.power is None:                       # no matching hwmon directory: the normal case off the GPU box
         s.start()
         assert s.stop() is None
+        assert s.reason and "hwmon" in s.reason        # ... and says why, so the JSON line can carry `power_clock_unavailable`
     else:                                     # a GPU box: a short sample carries the three readings
         import time
         s.start(); time.sleep(0.2)

@@ -411,6 +411,39 @@ def test_infer_entry_point_runs_offline():
         assert sorted(os.listdir(vis)) == [f"frame_{i:03d}_idx{f}.jpg" for i, f in enumerate(sel)]
 
 
+def test_infer_entry_point_on_a_real_video_file():
+    """python infer.py --video clip.avi on a REAL file (infer.py:44-51, 81-94): a 20 s MJPEG-in-AVI clip written here, decoded by
+    the built-in reader (decord is not in the image), sampled at 2 fps by get_frame_indices, scored on the GPU; the Top-K are original frame
+    indices out of the sampler's list and the saved JPEGs are those frames of the file."""
+    import ast
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from videoitg_amd import mm_utils, video_io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    T, fps = 600, 29.97
+    clip = np.zeros((T, 72, 96, 3), np.uint8)
+    for i in range(T):
+        clip[i] = (i * 7) % 200 + 20
+        clip[i, 10:30, (i % 60):(i % 60) + 20] = (240, 30, 60)
+    with tempfile.TemporaryDirectory() as tmp:
+        path, vis = os.path.join(tmp, "clip.avi"), os.path.join(tmp, "vis")
+        video_io.write_avi(path, clip, fps=fps, codec="MJPG")
+        out = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--model", "synthetic:tiny", "--video", path, "--topk", "6",
+                              "--num-frames", "32", "--save-dir", vis], capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sel = ast.literal_eval(next(l for l in out.stdout.strip().splitlines() if l.startswith("[")))
+        sampled = mm_utils.get_frame_indices(T, fps, 2, 32)
+        assert len(sel) == 6 and sel == sorted(sel) and set(sel) <= set(sampled)
+        assert sorted(os.listdir(vis)) == [f"frame_{i:03d}_idx{f}.jpg" for i, f in enumerate(sel)]
+        for i, f in enumerate(sel):                              # the saved frame IS frame f of the file (grey level of its lower half)
+            im = np.asarray(Image.open(os.path.join(vis, f"frame_{i:03d}_idx{f}.jpg")))
+            assert abs(int(im[60, 48, 1]) - int(clip[f, 60, 48, 1])) <= 6, (i, f)
+
+
 def test_graph_captured_forward_replays_bit_identically(golden_dir):
     """HIP-graph capture of the per-video forward (BASELINE.json configs[3]): replay with NEW pixel values and NEW prompt
     token values (same layout) must equal the eager forward bit for bit; a different layout is refused."""

@@ -107,6 +107,45 @@ def test_full_size_graph_replay_equals_eager():
     eng.release_workspace()
 
 
+def test_batch_of_eight_videos_through_one_capture_at_the_headline_workload(golden_dir):
+    """BASELINE.json configs[3] at its own size: 8 different 512-frame x 448^2 videos - other pixels, prompts of other
+    lengths inside one 64-token bucket - through ONE captured forward (one video per GPU is the reference's data parallelism: whole documents per
+    rank, lmms_eval/utils.py:689-695, lmms_eval/models/videoitg.py:274-328).  Each replay equals the eager forward of the same document bit for
+    bit, there is one capture, and the fixture video (tests/golden/full_c2_512x448.json: a complete fp32 oracle pass) comes out of the graph
+    within north_star's 1e-3 with the oracle's Top-32."""
+    import json
+    import os
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig
+    from videoitg_amd.engine import GraphCache, SelectorEngine
+    from videoitg_amd.synth_device import packed_random_weights
+    from videoitg_amd.torch_ops import K
+    rec = json.load(open(os.path.join(golden_dir, "full_c2_512x448.json")))
+    cfg = ITGConfig()
+    eng = SelectorEngine(packed_random_weights(cfg, torch.float16, "cuda:0", seed=rec["weight_seed"]))
+    cache = GraphCache(eng, bucket=64)
+    videos = [(rec["pixel_seed"], rec["prompt_len"])] + [(5000 + 17 * i, L) for i, L in enumerate((33, 64, 41, 57, 36, 49, 62))]
+    seen = []
+    for seed, L in videos:
+        ids, pix = synth.workload_inputs(cfg, rec["frames"], rec["resolution"], L, pix_seed=seed)
+        pix = pix.half().cuda()
+        want = eng.forward(ids, None, [pix])[0].view(-1).clone()
+        got = cache(ids.view(-1), pix).clone()
+        assert torch.isfinite(got).all() and torch.equal(got, want), (seed, L, (got - want).abs().max().item())
+        seen.append(got.float().cpu())
+        del pix
+    assert cache.captures == 1
+    for a in range(len(seen)):                                            # eight different documents, not one replayed eight times
+        for b in range(a + 1, len(seen)):
+            assert not torch.equal(seen[a], seen[b])
+    want = torch.tensor(rec["logits"])
+    ds = (torch.sigmoid(seen[0]) - torch.sigmoid(want)).abs().max().item()
+    _, order = K.rank(seen[0].cuda())
+    print(f"C4 fixture video out of the graph: max|dscore|={ds:.2e}")
+    assert ds <= 1e-3 and sorted(order.cpu().tolist()[:rec["k"]]) == rec["topk"]
+    eng.release_workspace()
+
+
 def test_workspace_is_bounded_over_varying_prompts_and_frame_counts():
     """one buffer per name, grown to the largest shape seen - memory after a sweep over prompt lengths and frame
     counts equals the memory of the largest configuration alone (no per-shape accumulation)."""

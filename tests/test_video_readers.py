@@ -134,3 +134,84 @@ def test_plugin_load_video_uses_decord_then_pyav(fake_decord, fake_av, monkeypat
     imgs2, idx2 = plug.load_video("x.mp4", num_frames=8, target_fps=1)
     assert list(idx2) == want and [im.getpixel((0, 0))[0] for im in imgs2] == [i % 251 for i in want]
     assert fake_av.opened[-1].closed
+
+
+# ---- real files: the built-in reader (videoitg_amd/video_io.py) behind the same entry points, decord absent ------------------------------
+def _clip(T=75, h=36, w=48):
+    """frames whose content says which frame it is: a flat grey level per frame (survives JPEG) + a moving bright block"""
+    fr = np.zeros((T, h, w, 3), np.uint8)
+    for i in range(T):
+        fr[i] = 20 + 3 * (i % 70)
+        fr[i, 4:12, (i % (w - 8)):(i % (w - 8)) + 8] = (250, 40, 40)
+    return fr
+
+
+@pytest.fixture
+def no_decoders(monkeypatch):
+    monkeypatch.setitem(sys.modules, "decord", None)
+    monkeypatch.setitem(sys.modules, "av", None)
+
+
+def test_avi_uncompressed_round_trip_is_exact(tmp_path, no_decoders):
+    from videoitg_amd import video_io
+    clip = _clip(T=33, h=35, w=47)                              # odd sizes: DIB rows are padded to 4 bytes
+    path = str(tmp_path / "clip_raw.avi")
+    video_io.write_avi(path, clip, fps=12.5, codec="DIB ")
+    vr = video_io.VideoReader(path)
+    assert len(vr) == 33 and abs(vr.get_avg_fps() - 12.5) < 1e-6 and (vr.height, vr.width) == (35, 47)
+    assert np.array_equal(vr.get_batch(list(range(33))).asnumpy(), clip)
+    assert np.array_equal(vr[-1].asnumpy(), clip[-1])
+    with pytest.raises(IndexError):
+        vr[33]
+
+
+def test_read_video_decord_on_a_real_mjpeg_avi(tmp_path, no_decoders):
+    """infer.py:44-51 on a REAL file: 300 frames at 29.97 fps, MJPEG in AVI, decord absent -> the built-in reader; the sampled indices are
+    get_frame_indices' and every returned frame is the frame of that index (grey level), within JPEG error"""
+    from videoitg_amd import video_io
+    clip = _clip(T=300)
+    path = str(tmp_path / "clip.avi")
+    video_io.write_avi(path, clip, fps=29.97, codec="MJPG")
+    frames, idx, secs = mm_utils.read_video_decord(path, num_frm=16, target_fps=2)
+    want = mm_utils.get_frame_indices(300, 29.97, 2, 16)
+    assert idx == want and secs == round(300 / 29.97) and frames.shape == (16, 36, 48, 3) and frames.dtype == np.uint8
+    for f, i in zip(frames, idx):
+        assert abs(int(f[30, 5, 0]) - int(clip[i, 30, 5, 0])) <= 3 and abs(int(f[30, 40, 2]) - int(clip[i, 30, 40, 2])) <= 3, i
+        assert np.abs(f.astype(int) - clip[i].astype(int)).mean() < 4.0
+    all_, idx_all, _ = mm_utils.read_video_decord(path, num_frm=512, target_fps=2)           # fewer candidates than asked for
+    assert idx_all == list(range(0, 300, 15)) and len(all_) == 20
+
+
+def test_y4m_round_trip_and_plugin_loader(tmp_path, no_decoders):
+    from videoitg_amd import video_io
+    from videoitg_amd.lmms_plugin.models import videoitg as plug
+    clip = _clip(T=90, h=34, w=46)
+    clip[:, :, :, :] = clip[:, :, :, :1]                       # grey: survives 4:2:0 chroma subsampling and the limited-range round trip to +-2
+    path = str(tmp_path / "clip.y4m")
+    video_io.write_y4m(path, clip, fps=(30000, 1001))
+    vr = video_io.VideoReader(path)
+    assert len(vr) == 90 and abs(vr.get_avg_fps() - 30000 / 1001) < 1e-9
+    got = vr.get_batch([0, 44, 89]).asnumpy()
+    assert np.abs(got.astype(int) - clip[[0, 44, 89]].astype(int)).max() <= 2
+    imgs, idx = plug.load_video(path, num_frames=8, target_fps=1)                            # lmms_eval/models/videoitg.py:95-130
+    assert list(idx) == mm_utils.get_seq_frames(90, 30000 / 1001, 1, 8) and imgs[0].size == (46, 34)
+    assert [abs(im.getpixel((2, 30))[0] - int(clip[i, 30, 2, 0])) <= 2 for im, i in zip(imgs, idx)] == [True] * len(idx)
+
+
+def test_files_that_need_a_codec_still_raise_like_the_reference(tmp_path, no_decoders):
+    from videoitg_amd import video_io
+    with pytest.raises(ImportError):
+        mm_utils.read_video_decord(str(tmp_path / "movie.mp4"), num_frm=4)                   # no decord, not a codec-free container
+    bad = tmp_path / "not_a_video.avi"
+    bad.write_bytes(b"hello, this is not RIFF")
+    with pytest.raises(ValueError):
+        video_io.VideoReader(str(bad))
+    clip = _clip(T=3)
+    path = str(tmp_path / "h264.avi")
+    video_io.write_avi(path, clip, codec="DIB ")
+    raw = bytearray(open(path, "rb").read())
+    k = raw.index(b"strf") + 8 + 16
+    raw[k:k + 4] = b"H264"                                      # a stream that needs a real codec
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="needs a codec"):
+        video_io.VideoReader(path)

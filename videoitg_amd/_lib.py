@@ -21,6 +21,9 @@ if os.environ.get("VITG_LIB_PATH"):
     if os.path.dirname(_alt) != _HERE or not (os.path.basename(_alt).startswith("libvideoitg_hip_exp_") and _alt.endswith(".so")):
         raise ImportError(f"VITG_LIB_PATH must name a libvideoitg_hip_exp_<NAME>.so inside {_HERE} (csrc/build.sh --exp NAME), not {_alt}")
     LIB_PATH = _alt
+    import warnings
+    warnings.warn(f"videoitg_amd: VITG_LIB_PATH is set - loading the experiment build {os.path.basename(_alt)} instead of the product library "
+                  f"(bench.py reports it as library.path)", RuntimeWarning, stacklevel=2)
 
 BF16, F16, F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2

@@ -44,8 +44,8 @@ def load_video(video_path: str, num_frames: int = 64, target_fps: float = 1):
     """videoitg.py:95-130: decord first, PyAV fallback; returns (list of PIL images, sampled frame ids)."""
     from PIL import Image
     try:
-        from decord import VideoReader, cpu
-        vr = VideoReader(video_path, ctx=cpu(0))
+        from ...mm_utils import open_video_reader                # decord; without it, the built-in reader for .avi (MJPEG) / .y4m
+        vr = open_video_reader(video_path, num_threads=1)
         idx = get_seq_frames(int(len(vr)), vr.get_avg_fps(), target_fps, num_frames)
         frames = vr.get_batch(idx).asnumpy()
         return [Image.fromarray(f) for f in frames], idx

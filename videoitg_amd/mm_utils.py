@@ -82,11 +82,23 @@ def pad_sequence(tokenizer, input_ids: Sequence[torch.Tensor], batch_first: bool
     return torch.flip(out, [1]) if left else out
 
 
+def open_video_reader(video_path: str, num_threads: int = 4):
+    """decord.VideoReader(path, ctx=cpu(0)) as the reference opens it (infer.py:45; lmms_eval/models/videoitg.py:98) - or, when decord is
+    not installed AND the file is one of the two container formats that need no codec (MJPEG / uncompressed AVI, YUV4MPEG2), the built-in
+    reader with the same call surface (videoitg_amd.video_io).  Any other file without decord raises the ImportError the reference raises."""
+    try:
+        from decord import VideoReader, cpu
+    except ImportError:
+        from . import video_io
+        if not str(video_path).lower().endswith(video_io.SUFFIXES):
+            raise
+        return video_io.VideoReader(video_path, ctx=None, num_threads=num_threads)
+    return VideoReader(video_path, ctx=cpu(0), num_threads=num_threads)
+
+
 def read_video_decord(video_path: str, num_frm: int = 16, target_fps: float = 2):
     """Row A2 (infer.py:44-51): uint8 [T,H,W,3] frames, their indices, duration in seconds."""
-    from decord import VideoReader, cpu  # not in this image; same ImportError the reference raises
-
-    vr = VideoReader(video_path, ctx=cpu(0), num_threads=4)
+    vr = open_video_reader(video_path, num_threads=4)
     total = len(vr)
     fps = vr.get_avg_fps()
     idx = get_frame_indices(total, fps, target_fps, num_frm)

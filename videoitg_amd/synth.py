@@ -98,8 +98,98 @@ def counter_rows(seed: int, key: str, shape, rows: torch.Tensor, mean: float, st
     return counter_values(seed, key, idx.reshape(-1), mean, std).reshape(rows.numel(), cols)
 
 
-def counter_state_dict(specs, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
-    return {k: counter_tensor(seed, k, s, m, sd, device) for k, s, m, sd in specs}
+def counter_state_dict(specs, seed: int = 0, device="cpu", plan: "HeavyTailPlan | None" = None) -> Dict[str, torch.Tensor]:
+    sd = {k: counter_tensor(seed, k, s, m, sd, device) for k, s, m, sd in specs}
+    return plan.apply(sd) if plan is not None else sd
+
+
+# ---- heavy-tailed variant: outlier channels planted the way trained towers / decoders carry them -----------------------
+# The plain draw above is benign: N(0, 1/fan_in) weights keep every residual stream within +-10, and a 16-bit residual stream is
+# never stressed.  Trained SigLIP / Qwen2 checkpoints are not like that: a handful of hidden channels carry "massive
+# activations" two orders above the rest - a near-constant component written by a bias early in the stack plus a token-dependent
+# one written by a few large rows of the MLP's output projection - and the norm gains hand the following projections inputs of
+# ordinary size again (gain of a planted channel small, the others above one).  `HeavyTailPlan` turns a plain state dict into one
+# with that anatomy, by EXACT operations only (power-of-two row / gain factors, constants that are 16-bit exact), so CPU oracle
+# and GPU engine still share every bit:
+#   tower   : fc2.weight[c, :] x row_gain in every layer, fc2.bias[c] = +-vit_bias in layers `vit_bias_layers`,
+#             layer_norm{1,2}.weight of layer l: planted channels x vit_norm[l][1], every other channel x vit_norm[l][0]
+#   decoder : down_proj.weight[c, :] x row_gain in every layer; the projector's last bias [c] and column c of the embedding table =
+#             +-llm_bias (every token enters the decoder with the constant); input / post-attention RMSNorm gains of layer l x
+#             llm_norm[l][0 | 1], the final norm x final_norm[0 | 1]
+# The per-layer gain pairs are DATA (tests/golden/heavy_tail_plan.json, written by tests/golden/calibrate_heavy_tail.py from a small
+# complete pass): powers of two chosen so that after each norm the ordinary channels have the unit scale of the plain draw and the
+# planted ones ~4x that.  Residual streams reach 10^2 - 10^3 in the planted channels (checks.vit_absmax / llm_absmax of a fixture).
+class HeavyTailPlan:
+    def __init__(self, vit_channels, llm_channels, vit_norm, llm_norm, final_norm, row_gain=64.0, vit_bias=128.0,
+                 vit_bias_layers=(1, 2), llm_bias=1024.0):
+        self.vit_channels, self.llm_channels = tuple(int(c) for c in vit_channels), tuple(int(c) for c in llm_channels)
+        self.vit_norm = [tuple(float(v) for v in p) for p in vit_norm]
+        self.llm_norm = [tuple(float(v) for v in p) for p in llm_norm]
+        self.final_norm = tuple(float(v) for v in final_norm)
+        self.row_gain = float(row_gain)
+        self.vit_bias, self.vit_bias_layers, self.llm_bias = float(vit_bias), tuple(vit_bias_layers), float(llm_bias)
+
+    @staticmethod
+    def channels(cfg: ITGConfig, seed: int = 7, n: int = 4):
+        g = _gen(seed, "heavy_tail_channels")
+        vc = sorted(torch.randperm(cfg.mm_hidden_size, generator=g)[:n].tolist())
+        lc = sorted(torch.randperm(cfg.hidden_size, generator=g)[:n].tolist())
+        return vc, lc
+
+    def to_json(self) -> dict:
+        return dict(vit_channels=list(self.vit_channels), llm_channels=list(self.llm_channels), vit_norm=[list(p) for p in self.vit_norm],
+                    llm_norm=[list(p) for p in self.llm_norm], final_norm=list(self.final_norm), row_gain=self.row_gain,
+                    vit_bias=self.vit_bias, vit_bias_layers=list(self.vit_bias_layers), llm_bias=self.llm_bias)
+
+    @classmethod
+    def from_json(cls, d: dict) -> "HeavyTailPlan":
+        return cls(**d)
+
+    @staticmethod
+    def _signs(n, device):
+        return torch.tensor([1.0 if j % 2 == 0 else -1.0 for j in range(n)], dtype=torch.float32, device=device)
+
+    @staticmethod
+    def _norm_gain(w, chans, pair):
+        out = w * pair[0]
+        idx = torch.tensor(chans, dtype=torch.long, device=w.device)
+        out[idx] = w[idx] * pair[1]
+        return out
+
+    def apply(self, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """in place on the fp32 tensors of a (partial) state dict; keys it does not know pass through"""
+        for k in list(sd):
+            t = sd[k]
+            if k.startswith("vision_model.encoder.layers."):
+                layer = int(k.split(".")[3])
+                idx = torch.tensor(self.vit_channels, dtype=torch.long, device=t.device)
+                if k.endswith("mlp.fc2.weight"):
+                    t[idx] = t[idx] * self.row_gain
+                elif k.endswith("mlp.fc2.bias") and layer in self.vit_bias_layers:
+                    t[idx] = self._signs(len(self.vit_channels), t.device) * self.vit_bias
+                elif (k.endswith("layer_norm1.weight") or k.endswith("layer_norm2.weight")) and layer < len(self.vit_norm):
+                    sd[k] = self._norm_gain(t, self.vit_channels, self.vit_norm[layer])
+            elif k.startswith("model.layers."):
+                layer = int(k.split(".")[2])
+                idx = torch.tensor(self.llm_channels, dtype=torch.long, device=t.device)
+                if k.endswith("mlp.down_proj.weight"):
+                    t[idx] = t[idx] * self.row_gain
+                elif k.endswith("layernorm.weight") and layer < len(self.llm_norm):
+                    sd[k] = self._norm_gain(t, self.llm_channels, self.llm_norm[layer])
+            elif k == "model.norm.weight":
+                sd[k] = self._norm_gain(t, self.llm_channels, self.final_norm)
+            elif k == "model.mm_projector.out_projection.2.bias":
+                idx = torch.tensor(self.llm_channels, dtype=torch.long, device=t.device)
+                t[idx] = self._signs(len(self.llm_channels), t.device) * self.llm_bias
+            elif k == "model.embed_tokens.weight":            # full table, or the gathered rows of a prompt (oracle/fullsize.py)
+                idx = torch.tensor(self.llm_channels, dtype=torch.long, device=t.device)
+                t[:, idx] = self._signs(len(self.llm_channels), t.device) * self.llm_bias
+        return sd
+
+
+def fixture_plan(rec: dict):
+    """the HeavyTailPlan of a complete-pass fixture record, or None for the plain draw"""
+    return HeavyTailPlan.from_json(rec["heavy_tail"]) if rec.get("heavy_tail") else None
 
 
 def llm_param_specs(cfg: ITGConfig) -> Iterator[Tuple[str, tuple, float, float]]:

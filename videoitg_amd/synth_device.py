@@ -15,22 +15,23 @@ from .config import ITGConfig
 from .engine import PackedWeights
 
 
-def _draw(specs, device, seed):
-    return synth.counter_state_dict(specs, seed, device)
+def _draw(specs, device, seed, plan=None):
+    return synth.counter_state_dict(specs, seed, device, plan)
 
 
 def packed_random_weights(cfg: ITGConfig, dtype: torch.dtype, device, seed: int = 0, fp8: bool = False,
-                          vit_dtype=None) -> PackedWeights:
+                          vit_dtype=None, plan: "synth.HeavyTailPlan | None" = None) -> PackedWeights:
+    """`plan`: the heavy-tailed variant (synth.HeavyTailPlan; fixtures carrying a "heavy_tail" record, synth.fixture_plan)"""
     device = torch.device(device)
     pw = PackedWeights(cfg=cfg, dtype=dtype, device=device, fp8=fp8, vit_dtype=vit_dtype)
     vspecs = list(synth.vision_param_specs(cfg))
     lspecs = list(synth.llm_param_specs(cfg))
-    pw.pack_vision_embeddings(_draw([s for s in vspecs if s[0].startswith("vision_model.embeddings.")], device, seed))
+    pw.pack_vision_embeddings(_draw([s for s in vspecs if s[0].startswith("vision_model.embeddings.")], device, seed, plan))
     for i in range(cfg.num_vit_layers_needed()):
         pre = f"vision_model.encoder.layers.{i}."
-        pw.pack_vision_layer(_draw([s for s in vspecs if s[0].startswith(pre)], device, seed), i)
-    pw.pack_projector_and_head(_draw([s for s in lspecs if not s[0].startswith("model.layers.")], device, seed))
+        pw.pack_vision_layer(_draw([s for s in vspecs if s[0].startswith(pre)], device, seed, plan), i)
+    pw.pack_projector_and_head(_draw([s for s in lspecs if not s[0].startswith("model.layers.")], device, seed, plan))
     for i in range(cfg.num_hidden_layers):
         pre = f"model.layers.{i}."
-        pw.pack_llm_layer(_draw([s for s in lspecs if s[0].startswith(pre)], device, seed), i)
+        pw.pack_llm_layer(_draw([s for s in lspecs if s[0].startswith(pre)], device, seed, plan), i)
     return pw

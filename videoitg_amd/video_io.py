@@ -1,0 +1,296 @@
+"""Built-in video reader for the two container formats that need no codec library: MJPEG / uncompressed frames in AVI, and YUV4MPEG2.
+
+Row A2 / N3 of SURVEY.md section 8: the reference decodes with decord (``infer.py:44-51``) or PyAV (``eagle/mm_utils.py:43-103``,
+``lmms_eval/models/videoitg.py:95-130``); neither is in this image, and building a codec is out of scope.  What CAN be done without one is
+to read real files whose frames are individually coded: Motion-JPEG in an AVI (every frame a baseline JPEG - Pillow, already a dependency
+of the image processor, decodes it), uncompressed BGR in an AVI, and raw planar YUV with a YUV4MPEG2 header.  ``VideoReader`` below exposes
+the handful of calls the reference makes on ``decord.VideoReader`` (``len``, ``get_avg_fps``, ``get_batch(idx).asnumpy()``, ``vr[i].asnumpy()``,
+``seek``), so ``read_video_decord`` and ``infer.py --video clip.avi`` run end to end on a real file when decord is absent.
+
+This is host-side file parsing (struct + NumPy); nothing here runs on the GPU and nothing here is needed for the timed path.
+"""
+from __future__ import annotations
+
+import io
+import struct
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+SUFFIXES = (".avi", ".y4m")
+
+
+class _Batch:
+    """what decord hands back from get_batch / __getitem__: an object with .asnumpy()"""
+
+    def __init__(self, arr: np.ndarray):
+        self._arr = arr
+
+    def asnumpy(self) -> np.ndarray:
+        return self._arr
+
+
+def _chunks(buf: memoryview, start: int, end: int):
+    """RIFF chunks in [start, end): (fourcc, payload offset, payload size); chunks are padded to even sizes"""
+    p = start
+    while p + 8 <= end:
+        cc = bytes(buf[p:p + 4])
+        (size,) = struct.unpack_from("<I", buf, p + 4)
+        yield cc, p + 8, size
+        p += 8 + size + (size & 1)
+
+
+class _AviIndex:
+    """frame table of an AVI 1.0 file: offsets / sizes of the video stream's chunks inside LIST 'movi' (file order = frame order)"""
+
+    def __init__(self, data: bytes):
+        buf = memoryview(data)
+        if len(buf) < 12 or bytes(buf[:4]) != b"RIFF" or bytes(buf[8:12]) != b"AVI ":
+            raise ValueError("not a RIFF AVI file")
+        self.frames: List[Tuple[int, int]] = []
+        self.width = self.height = 0
+        self.rate, self.scale, self.usec_per_frame = 0, 1, 0
+        self.handler = self.compression = b""
+        self.bit_count = 24
+        self.top_down = False
+        vid_stream = None
+        n_streams = 0
+        for cc, off, size in _chunks(buf, 12, len(buf)):
+            if cc != b"LIST":
+                continue
+            kind = bytes(buf[off:off + 4])
+            if kind == b"hdrl":
+                for c2, o2, s2 in _chunks(buf, off + 4, off + size):
+                    if c2 == b"avih":
+                        self.usec_per_frame = struct.unpack_from("<I", buf, o2)[0]
+                    elif c2 == b"LIST" and bytes(buf[o2:o2 + 4]) == b"strl":
+                        is_video = False
+                        for c3, o3, s3 in _chunks(buf, o2 + 4, o2 + s2):
+                            if c3 == b"strh":
+                                is_video = bytes(buf[o3:o3 + 4]) == b"vids" and vid_stream is None
+                                if is_video:
+                                    self.handler = bytes(buf[o3 + 4:o3 + 8])
+                                    self.scale, self.rate = struct.unpack_from("<II", buf, o3 + 20)
+                                    vid_stream = n_streams
+                            elif c3 == b"strf" and is_video:
+                                w, h, _planes, bits = struct.unpack_from("<iiHH", buf, o3 + 4)
+                                self.compression = bytes(buf[o3 + 16:o3 + 20])
+                                self.width, self.height, self.bit_count = w, abs(h), bits
+                                self.top_down = h < 0
+                        n_streams += 1
+            elif kind == b"movi":
+                if vid_stream is None:
+                    raise ValueError("AVI: no video stream header before the movi list")
+                tag = b"%02d" % vid_stream
+                for c2, o2, s2 in _chunks(buf, off + 4, off + size):
+                    if c2[:2] == tag and c2[2:] in (b"dc", b"db"):
+                        self.frames.append((o2, s2))
+                    elif c2 == b"LIST" and bytes(buf[o2:o2 + 4]) == b"rec ":
+                        for c3, o3, s3 in _chunks(buf, o2 + 4, o2 + s2):
+                            if c3[:2] == tag and c3[2:] in (b"dc", b"db"):
+                                self.frames.append((o3, s3))
+        if vid_stream is None or not self.width:
+            raise ValueError("AVI: no video stream")
+
+    @property
+    def fps(self) -> float:
+        if self.rate and self.scale:
+            return self.rate / self.scale
+        return 1e6 / self.usec_per_frame if self.usec_per_frame else 0.0
+
+
+def _yuv_to_rgb(y: np.ndarray, u: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """BT.601 limited-range Y'CbCr (what YUV4MPEG2 carries by convention) -> uint8 RGB, round to nearest"""
+    yf = (y.astype(np.float32) - 16.0) * (255.0 / 219.0)
+    uf, vf = u.astype(np.float32) - 128.0, v.astype(np.float32) - 128.0
+    k = 255.0 / 224.0
+    r = yf + 1.402 * k * vf
+    g = yf - (0.344136 * k) * uf - (0.714136 * k) * vf
+    b = yf + 1.772 * k * uf
+    return np.clip(np.rint(np.stack([r, g, b], -1)), 0, 255).astype(np.uint8)
+
+
+class VideoReader:
+    """decord.VideoReader's call surface over .avi (MJPG / uncompressed BGR24) and .y4m (C420*, C422, C444, 8 bit) files"""
+
+    def __init__(self, path: str, ctx=None, num_threads: int = 1):
+        self.path = path
+        with open(path, "rb") as f:
+            self._data = f.read()
+        head = self._data[:10]
+        if head.startswith(b"YUV4MPEG2"):
+            self._init_y4m()
+        elif head[:4] == b"RIFF":
+            self._init_avi()
+        else:
+            raise ValueError(f"{path}: neither a RIFF AVI nor a YUV4MPEG2 file (the built-in reader covers only these; install decord / PyAV for coded video)")
+
+    # ---- AVI ------------------------------------------------------------------------------------------------------------------
+    def _init_avi(self):
+        ix = _AviIndex(self._data)
+        comp = ix.compression.upper()
+        if comp in (b"MJPG", b"JPEG") or ix.handler.upper() in (b"MJPG",) and comp not in (b"\0\0\0\0", b"DIB "):
+            self._kind = "mjpg"
+        elif comp in (b"\0\0\0\0", b"DIB ", b"RGB ") and ix.bit_count == 24:
+            self._kind = "bgr24"
+        else:
+            raise ValueError(f"{self.path}: AVI video stream {ix.compression!r}/{ix.handler!r} ({ix.bit_count} bit) needs a codec; the built-in reader "
+                             f"decodes MJPG and uncompressed 24-bit frames only")
+        self._ix, self._fps = ix, ix.fps
+        self._n, self.width, self.height = len(ix.frames), ix.width, ix.height
+
+    def _avi_frame(self, i: int) -> np.ndarray:
+        off, size = self._ix.frames[i]
+        if self._kind == "mjpg":
+            from PIL import Image
+            if size == 0:                                   # a dropped frame repeats its predecessor (AVI convention)
+                return self._avi_frame(i - 1) if i else np.zeros((self.height, self.width, 3), np.uint8)
+            return np.asarray(Image.open(io.BytesIO(self._data[off:off + size])).convert("RGB"))
+        stride = (self.width * 3 + 3) & ~3                  # DIB rows are padded to 4 bytes, stored bottom-up unless the height is negative
+        rows = np.frombuffer(self._data, np.uint8, stride * self.height, off).reshape(self.height, stride)[:, :self.width * 3]
+        img = rows.reshape(self.height, self.width, 3)[:, :, ::-1]
+        return np.ascontiguousarray(img if self._ix.top_down else img[::-1])
+
+    # ---- YUV4MPEG2 ------------------------------------------------------------------------------------------------------------
+    def _init_y4m(self):
+        end = self._data.index(b"\n")
+        toks = self._data[:end].decode("ascii").split(" ")[1:]
+        self._chroma, num, den = "420jpeg", 25, 1
+        for t in toks:
+            if t[0] == "W":
+                self.width = int(t[1:])
+            elif t[0] == "H":
+                self.height = int(t[1:])
+            elif t[0] == "F":
+                num, den = (int(x) for x in t[1:].split(":"))
+            elif t[0] == "C":
+                self._chroma = t[1:]
+        if self._chroma.startswith("420"):
+            self._cw, self._ch = (self.width + 1) // 2, (self.height + 1) // 2
+        elif self._chroma == "422":
+            self._cw, self._ch = (self.width + 1) // 2, self.height
+        elif self._chroma == "444":
+            self._cw, self._ch = self.width, self.height
+        else:
+            raise ValueError(f"{self.path}: YUV4MPEG2 colour space C{self._chroma} is not covered (8-bit C420* / C422 / C444 are)")
+        self._fps = num / den
+        self._fsize = self.width * self.height + 2 * self._cw * self._ch
+        self._offsets, p = [], end + 1
+        while p < len(self._data):
+            if self._data[p:p + 5] != b"FRAME":
+                raise ValueError(f"{self.path}: YUV4MPEG2 frame marker expected at byte {p}")
+            p = self._data.index(b"\n", p) + 1
+            if p + self._fsize > len(self._data):
+                break                                       # truncated last frame
+            self._offsets.append(p)
+            p += self._fsize
+        self._kind, self._n = "y4m", len(self._offsets)
+
+    def _y4m_frame(self, i: int) -> np.ndarray:
+        p, w, h, cw, ch = self._offsets[i], self.width, self.height, self._cw, self._ch
+        y = np.frombuffer(self._data, np.uint8, w * h, p).reshape(h, w)
+        u = np.frombuffer(self._data, np.uint8, cw * ch, p + w * h).reshape(ch, cw)
+        v = np.frombuffer(self._data, np.uint8, cw * ch, p + w * h + cw * ch).reshape(ch, cw)
+        if (ch, cw) != (h, w):                              # nearest-neighbour chroma upsampling (what a decoder's fast path does)
+            u = np.repeat(np.repeat(u, -(-h // ch), 0), -(-w // cw), 1)[:h, :w]
+            v = np.repeat(np.repeat(v, -(-h // ch), 0), -(-w // cw), 1)[:h, :w]
+        return _yuv_to_rgb(y, u, v)
+
+    # ---- decord's surface -----------------------------------------------------------------------------------------------------
+    def __len__(self) -> int:
+        return self._n
+
+    def get_avg_fps(self) -> float:
+        return float(self._fps)
+
+    def _frame(self, i: int) -> np.ndarray:
+        i = int(i)
+        if not -self._n <= i < self._n:
+            raise IndexError(f"frame {i} of {self._n}")
+        i %= self._n
+        return self._y4m_frame(i) if self._kind == "y4m" else self._avi_frame(i)
+
+    def __getitem__(self, i: int) -> _Batch:
+        return _Batch(self._frame(i))
+
+    def get_batch(self, indices: Sequence[int]) -> _Batch:
+        return _Batch(np.stack([self._frame(i) for i in indices]) if len(indices) else np.zeros((0, self.height, self.width, 3), np.uint8))
+
+    def seek(self, pos: int) -> None:                       # random access needs no state
+        return None
+
+
+def cpu(_index: int = 0):
+    """decord.cpu(0) stand-in (the context argument is ignored: this reader is host code)"""
+    return None
+
+
+# ---- writers: what the tests (and anyone without a video tool) use to make a real file -------------------------------------------------
+def write_avi(path: str, frames: np.ndarray, fps: float = 30.0, codec: str = "MJPG", quality: int = 92) -> None:
+    """uint8 [T, H, W, 3] RGB -> AVI 1.0 with an idx1 index; codec "MJPG" (Pillow's baseline JPEG per frame) or "DIB " (uncompressed BGR24)"""
+    frames = np.asarray(frames, np.uint8)
+    T, H, W, _ = frames.shape
+    payloads = []
+    for fr in frames:
+        if codec == "MJPG":
+            from PIL import Image
+            b = io.BytesIO()
+            Image.fromarray(fr).save(b, "JPEG", quality=quality, subsampling=0)
+            payloads.append(b.getvalue())
+        else:
+            stride = (W * 3 + 3) & ~3
+            rows = np.zeros((H, stride), np.uint8)
+            rows[:, :W * 3] = fr[::-1, :, ::-1].reshape(H, W * 3)
+            payloads.append(rows.tobytes())
+    scale = 1000
+    rate = int(round(fps * scale))
+
+    def chunk(cc: bytes, body: bytes) -> bytes:
+        return cc + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
+
+    def lst(kind: bytes, body: bytes) -> bytes:
+        return b"LIST" + struct.pack("<I", len(body) + 4) + kind + body
+    biggest = max((len(p) for p in payloads), default=0)
+    avih = struct.pack("<14I", int(round(1e6 / fps)), 0, 0, 0x10, T, 0, 1, biggest, W, H, 0, 0, 0, 0)
+    comp = b"MJPG" if codec == "MJPG" else b"\0\0\0\0"
+    strh = b"vids" + (b"MJPG" if codec == "MJPG" else b"DIB ") + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, scale, rate, 0, T, biggest, 0xFFFFFFFF, 0, 0, 0, W, H)
+    strf = struct.pack("<IiiHH", 40, W, H, 1, 24) + comp + struct.pack("<IiiII", biggest if codec == "MJPG" else ((W * 3 + 3) & ~3) * H, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    tag = b"00dc" if codec == "MJPG" else b"00db"
+    movi_body, idx, pos = b"", b"", 4
+    for p in payloads:
+        idx += tag + struct.pack("<III", 0x10, pos, len(p))
+        c = chunk(tag, p)
+        movi_body += c
+        pos += len(c)
+    body = b"AVI " + hdrl + lst(b"movi", movi_body) + chunk(b"idx1", idx)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def rgb_to_yuv420(frame: np.ndarray):
+    """uint8 RGB [H, W, 3] -> BT.601 limited-range planes (Y [H, W], U and V [ceil(H/2), ceil(W/2)], 2x2 box-averaged chroma)"""
+    f = frame.astype(np.float32)
+    r, g, b = f[..., 0], f[..., 1], f[..., 2]
+    y = 16.0 + (65.481 * r + 128.553 * g + 24.966 * b) / 255.0
+    u = 128.0 + (-37.797 * r - 74.203 * g + 112.0 * b) / 255.0
+    v = 128.0 + (112.0 * r - 93.786 * g - 18.214 * b) / 255.0
+    H, W = y.shape
+    Hp, Wp = (H + 1) // 2 * 2, (W + 1) // 2 * 2
+
+    def sub(p):
+        p = np.pad(p, ((0, Hp - H), (0, Wp - W)), mode="edge")
+        return p.reshape(Hp // 2, 2, Wp // 2, 2).mean((1, 3))
+    q = lambda p: np.clip(np.rint(p), 0, 255).astype(np.uint8)      # noqa: E731
+    return q(y), q(sub(u)), q(sub(v))
+
+
+def write_y4m(path: str, frames: np.ndarray, fps: Tuple[int, int] = (30, 1)) -> None:
+    """uint8 [T, H, W, 3] RGB -> YUV4MPEG2, C420jpeg"""
+    frames = np.asarray(frames, np.uint8)
+    T, H, W, _ = frames.shape
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{W} H{H} F{fps[0]}:{fps[1]} Ip A1:1 C420jpeg\n".encode("ascii"))
+        for fr in frames:
+            y, u, v = rgb_to_yuv420(fr)
+            f.write(b"FRAME\n" + y.tobytes() + u.tobytes() + v.tobytes())
