@@ -45,8 +45,9 @@ int vitg_device_info(char* name, int name_len);
 /* Kernel-set selection for cross-check tests; 0 = the measured default everywhere.  FOUR keys, each a choice between the default and one
  * cross-check kernel set; the same values can come from the environment (VITG_<KEY IN CAPS>, read once).  Host-only, no GPU needed.
  *   gemm_tile   128  every GEMM on the 128x128 register-staged kernels (csrc/gemm.hip) | 256  never the 128-tile kernel where a 256-wide one applies
- *   gemm_cfg    2 | 6 | 9 | 10  force ONE shipped 256-wide tile shape (256x128x32 | 256x256x64 | 256x384x64 | 384x256x64) instead of the per-shape
- *               choice (csrc/gemm256.hip: choose_cfg) - lets a test reach every shipped kernel on a small shape
+ *   gemm_cfg    2 | 6 | 9 | 10 | 12  force ONE shipped 256-wide tile shape (256x128x32 | 256x256x64 | 256x384x64 | 384x256x64 | 320x256x64) instead of the
+ *               per-shape choice (csrc/gemm256.hip: choose_cfg) - lets a test reach every shipped kernel on a small shape (12 exists for the SwiGLU and
+ *               fp32-residual GEMMs; other modes run 256x256 under it)
  *   attn_ab     2  head dim 72 on the per-tile kernel (csrc/attention.hip) instead of the half-tile-out-of-phase one (csrc/attention_ab.hip)
  *   attn_sp     2  head dim 128 on the per-tile kernel instead of the software-pipelined one (csrc/attention_sp.hip)
  * Any other key or value returns VITG_ERR_ARG.  These are process-global test hooks: set them before the forward they should apply to, not from a

@@ -131,14 +131,20 @@ def test_heavy_tailed_weights_on_both_tower_streams(golden_dir, name):
     for r16 in (True, False):
         got = gpu_logits(rec, torch.float16, residual16=r16)
         assert torch.isfinite(got).all()
-        ds, dl, same, _ = compare(rec, got)
-        res[r16] = (ds, dl, same)
+        ds, dl, same, order = compare(rec, got)
+        kept = len(set(order[:rec["k"]]) & set(rec["topk"]))
+        res[r16] = (ds, dl, same, kept)
         print(f"heavy-tailed {name} fp16, tower stream {'16-bit' if r16 else 'fp32'}: max|dscore|={ds:.2e} max|dlogit|={dl:.2e} "
-              f"top{rec['k']} equal: {same} (oracle gap {rec['gap_k_k1']})")
-    ds, _, same = res[True]
+              f"top{rec['k']} equal: {same} ({kept} kept; oracle rank-{rec['k']}/{rec['k'] + 1} gap {rec['gap_k_k1']})")
+    ds, dl, same, kept = res[True]
     assert ds <= SCORE_TOL, res
+    # (every logit of these fixtures is below -1.4 - sigmoid slope <= 0.16 - so the score bound alone would be a weak statement: the logits themselves
+    # are held to 1e-2, which is 1.6e-3 in score at the steepest point)
+    assert dl <= 1e-2, res
     if rec["gap_k_k1"] is None or rec["gap_k_k1"] > 2 * SCORE_TOL:
         assert same, res
+    else:           # the oracle's own rank-K / K+1 gap (1.5e-4 at 512 frames) is inside the tolerance: at most the boundary pair may swap
+        assert kept >= rec["k"] - 1, res
 
 
 def test_heavy_tail_plan_is_exact_and_shared_by_both_sides(golden_dir):
@@ -150,7 +156,7 @@ def test_heavy_tail_plan_is_exact_and_shared_by_both_sides(golden_dir):
     rec = json.load(open(os.path.join(golden_dir, "heavy_tail_plan.json")))
     plan = synth.HeavyTailPlan.from_json(rec["plan"])
     assert plan.to_json() == rec["plan"]
-    assert (list(plan.vit_channels), list(plan.llm_channels)) == [list(c) for c in synth.HeavyTailPlan.channels(cfg)]
+    assert [list(plan.vit_channels), list(plan.llm_channels)] == [list(c) for c in synth.HeavyTailPlan.channels(cfg)]
     assert len(plan.vit_norm) == cfg.num_vit_layers_needed() and len(plan.llm_norm) == cfg.num_hidden_layers
     import math
     for pair in plan.vit_norm + plan.llm_norm + [plan.final_norm]:

@@ -33,7 +33,7 @@ def ops():
     return o
 
 
-@pytest.fixture(params=["auto", "tile128", "cfg2_256x128x32", "cfg6_phased", "cfg9_256x384", "cfg10_384x256",
+@pytest.fixture(params=["auto", "tile128", "cfg2_256x128x32", "cfg6_phased", "cfg9_256x384", "cfg10_384x256", "cfg12_320x256",
                         R("cfg6_mi16"), R("cfg9_256x384_mi16"), R("cfg10_384x256_mi16"), R("cfg6_mi32"), R("cfg9_256x384_mi32"), R("cfg10_384x256_mi32"),
                         R("cfg10_384x256_mi16_wm4"), R("cfg10_384x256_mi16_wm2")])
 def gemm_cfg(request, ops):
@@ -46,7 +46,7 @@ def gemm_cfg(request, ops):
     wm4 = {"cfg10_384x256_mi16_wm4": 15, "cfg10_384x256_mi16_wm2": -1}.get(name, 0)
     name_ = name.replace("_wm4", "").replace("_wm2", "")
     tile, cfg, mi = {"auto": (0, 0, 0), "tile128": (128, 0, 0), "cfg2_256x128x32": (256, 2, 0), "cfg6_phased": (256, 6, 0), "cfg9_256x384": (256, 9, 0),
-                     "cfg10_384x256": (256, 10, 0), "cfg6_mi16": (256, 6, 16), "cfg9_256x384_mi16": (256, 9, 16), "cfg10_384x256_mi16": (256, 10, 16),
+                     "cfg10_384x256": (256, 10, 0), "cfg12_320x256": (256, 12, 0), "cfg6_mi16": (256, 6, 16), "cfg9_256x384_mi16": (256, 9, 16), "cfg10_384x256_mi16": (256, 10, 16),
                      "cfg6_mi32": (256, 6, 32), "cfg9_256x384_mi32": (256, 9, 32), "cfg10_384x256_mi32": (256, 10, 32)}[name_]
     ops.set_option("gemm_tile", tile)
     ops.set_option("gemm_cfg", cfg)
@@ -335,7 +335,7 @@ def test_product_library_takes_four_option_keys_and_nothing_else(ops):
     from videoitg_amd._lib import VitgError
     if PROF:
         pytest.skip("the profiling library accepts the research knobs by design")
-    for key, val in (("gemm_tile", 128), ("gemm_tile", 256), ("gemm_cfg", 2), ("gemm_cfg", 6), ("gemm_cfg", 9), ("gemm_cfg", 10), ("attn_ab", 2), ("attn_sp", 2)):
+    for key, val in (("gemm_tile", 128), ("gemm_tile", 256), ("gemm_cfg", 2), ("gemm_cfg", 6), ("gemm_cfg", 9), ("gemm_cfg", 10), ("gemm_cfg", 12), ("attn_ab", 2), ("attn_sp", 2)):
         ops.set_option(key, val)
         ops.set_option(key, 0)
     for key, val in (("gemm_flags", 1 << 27), ("gemm_group", 8), ("gemm_mi", 32), ("gemm_mi_modes", 1), ("gemm_pref", 111), ("gemm_wm4", 15), ("gemm_stagger", 1),
@@ -440,7 +440,8 @@ def test_attention_key_count_from_device_memory(ops, attn_waves, dtype, H, HKV, 
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,splits", [(1660, 3584, 3584, 2), (1660, 3584, 18944, 2), (700, 1024, 4096, 4), (300, 520, 2048, 3)])
+@pytest.mark.parametrize("M,N,K,splits", [(1660, 3584, 3584, 2), (1660, 3584, 18944, 2), (700, 1024, 4096, 4), (300, 520, 2048, 3),
+                                          (1660, 3584, 3584, 3), (1600, 3584, 18944, 3), (1660, 3584, 18944, 3)])   # x3: the 320-row tiles (round 5)
 def test_gemm_splitk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K, splits):
     """split-K (o / down projection of one context-parallel rank): same value as the one-pass fp32-residual GEMM up to fp32
     re-association, bit-identical from run to run (partials are reduced in a fixed order, no atomics)"""
@@ -457,7 +458,7 @@ def test_gemm_splitk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K
     assert torch.equal(outs[0], outs[1])
     assert (outs[0] - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
     sp, nb = ops.gemm_splitk_plan(1660, 3584, 18944)
-    assert sp == 2 and nb == 2 * 1660 * 3584 * 4
+    assert sp == 3 and nb == 3 * 1660 * 3584 * 4
     assert ops.gemm_splitk_plan(12860, 3584, 18944)[0] == 1 and ops.gemm_splitk_plan(1660, 3584, 1152)[0] == 1
 
 
@@ -706,3 +707,41 @@ def test_engine_packs_the_pair_layout_like_the_test_does():
     pw.pack_vision_embeddings(vsd)
     want = pair_layout(vsd["vision_model.embeddings.patch_embedding.weight"].half())
     assert torch.equal(pw.patch_wf.cpu(), want)
+
+
+def test_engine_default_paths_against_their_unfused_forms():
+    """the engine's default-on paths that the tiny goldens cannot reach (their tower is narrower than 256) - the patch embedding with
+    the im2col inside the GEMM's loader, packed by PackedWeights itself, and the fp8 tower on the 16-bit residual stream - each against the
+    path it replaced, on a tower wide enough (Dv = 288 >= 256) to take them."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig, VisionConfig
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    vis = VisionConfig(image_size=112, hidden_size=288, intermediate_size=560, num_hidden_layers=3, num_attention_heads=4)       # head_dim 72
+    cfg = ITGConfig(vocab_size=512, hidden_size=256, intermediate_size=592, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                    mm_hidden_size=288, vision=vis, vision_token_num=256)
+    sd, vsd = synth.synth_llm_state_dict(cfg, 3), synth.synth_vision_state_dict(cfg, 3)
+    pix = synth.synth_pixel_values(6, 112, seed=8).half().cuda()
+    G = 112 // vis.patch_size
+    hw = cfg.pooled_grid(6, G)
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    assert eng.w.patch_wf is not None and eng.residual16 and eng.fuse_patchify
+    assert torch.equal(eng.w.patch_wf.cpu(), pair_layout(vsd["vision_model.embeddings.patch_embedding.weight"].half()))
+    fused = eng.vit_forward(pix, hw)[0].float().clone()
+    assert eng.vit_stream_bytes == 2
+    eng.fuse_patchify = False
+    unfused = eng.vit_forward(pix, hw)[0].float().clone()
+    eng.fuse_patchify = True
+    assert torch.isfinite(fused).all()
+    d = (fused - unfused).abs().max().item()
+    assert d <= 4e-3 * max(1.0, unfused.abs().max().item()), d          # same products, another fp32 summation order in ONE of 3 + 1 GEMM layers
+    # fp8 tower: 16-bit stream (default) against the fp32 stream of round 3
+    eng8 = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0", fp8="vit"))
+    assert eng8.fp8_r16
+    a = eng8.vit_forward(pix, hw)[0].float().clone()
+    assert eng8.vit_stream_bytes == 2
+    eng8.fp8_r16 = False
+    b = eng8.vit_forward(pix, hw)[0].float().clone()
+    assert eng8.vit_stream_bytes == 4
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())
+    # ... and both within the fp8 tier's distance of the 16-bit tower
+    assert (a - fused).abs().max().item() <= 0.25 * max(1.0, fused.abs().max().item())

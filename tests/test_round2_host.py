@@ -21,8 +21,12 @@ def test_prompt_bucket_and_layout_key():
 def test_splitk_plan_only_for_few_tiles_and_long_k():
     from videoitg_amd import ops
     # no GPU here: the plan falls back to 256 CUs
-    assert ops.gemm_splitk_plan(1660, 3584, 18944) == (2, 2 * 1660 * 3584 * 4)     # down projection of one of 8 ranks
-    assert ops.gemm_splitk_plan(1660, 3584, 3584)[0] == 2                          # o projection
+    # round 5: the few-row shapes of a context-parallel rank plan with 320-row tiles - 84 (70) tiles x 3 partials = one round of 252 (210) blocks each
+    # running a third of K, where 98 tiles of 256 rows x 2 ran half of it
+    assert ops.gemm_splitk_plan(1660, 3584, 18944) == (3, 3 * 1660 * 3584 * 4)     # down projection of one of 8 ranks
+    assert ops.gemm_splitk_plan(1660, 3584, 3584)[0] == 3                          # o projection
+    assert ops.gemm_splitk_plan(1600, 3584, 18944)[0] == 3                         # the seven ranks without the prompt
+    assert ops.gemm_splitk_plan(3260, 3584, 18944)[0] == 1                         # four ranks: 13 x 14 tiles of 256 rows already fill 182 of 256 CUs
     assert ops.gemm_splitk_plan(12860, 3584, 18944)[0] == 1                        # the single-GPU shape fills the chip
     assert ops.gemm_splitk_plan(1660, 3584, 1152)[0] == 1                          # short K: not worth a reduction pass
     assert ops.gemm_splitk_plan(100, 3584, 18944)[0] == 1                          # below one tile row: the 128-tile kernel's case

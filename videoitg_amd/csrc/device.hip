@@ -24,7 +24,7 @@ static int env_int(const char* k) { const char* e = getenv(k); return e ? atoi(e
 // values a PRODUCT key may take (the research values of these keys select variants only the profiling library instantiates)
 static bool product_value_ok(const char* key, int v) {
     if (!strcmp(key, "gemm_tile")) return v == 0 || v == 128 || v == 256;
-    if (!strcmp(key, "gemm_cfg")) return v == 0 || v == 2 || v == 6 || v == 9 || v == 10;
+    if (!strcmp(key, "gemm_cfg")) return v == 0 || v == 2 || v == 6 || v == 9 || v == 10 || v == 12;
     if (!strcmp(key, "attn_ab") || !strcmp(key, "attn_sp")) return v == 0 || v == 2;
     return false;
 }

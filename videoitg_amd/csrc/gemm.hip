@@ -327,16 +327,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 }  // namespace vitg
 
+namespace vitg { int splitk_tile_rows(int M, int N, int K, int splits, int cus); }
+
 extern "C" int vitg_gemm_splitk_plan(int M, int N, int K, int* splits, long* workspace_bytes) {
     if (!splits || !workspace_bytes) return VITG_ERR_ARG;
     const int cus = device_cu_count(current_device());
-    const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
-    int sp = 1;
-    // worth it only when one round of 256x256 tiles leaves most of the chip idle and every split still has a real K loop
-    if (M >= 256 && N >= 256 && N % 8 == 0 && tiles * 2 <= cus && K >= 2048) {
-        sp = (int)(cus / tiles);
-        if (sp > 4) sp = 4;
-        while (sp > 1 && K / 64 / sp < 16) --sp;
+    // worth it only when one round of tiles leaves most of the chip idle and every split still has a real K loop.  Planned for both tile heights the
+    // split-K launch can take (256 x 256, 320 x 256 - gemm256.hip splitk_tile_rows makes the same choice at launch time): the cheaper critical path wins
+    auto plan = [&](int bm, double* cost) {
+        const long tiles = (long)ceil_div(M, bm) * ceil_div(N, 256);
+        int s = 1;
+        if (M >= 256 && N >= 256 && N % 8 == 0 && tiles * 2 <= cus && K >= 2048) {
+            s = (int)(cus / tiles);
+            if (s > 4) s = 4;
+            while (s > 1 && K / 64 / s < 16) --s;
+        }
+        *cost = (double)bm * ceil_div(K / 64, s) * ceil_div((int)(tiles * s), cus);
+        return s;
+    };
+    double c256, c320;
+    int sp = plan(256, &c256);
+    if (sp > 1 && M > 256) {
+        const int sp320 = plan(320, &c320);
+        if (sp320 > 1 && c320 < 0.97 * c256 && vitg::splitk_tile_rows(M, N, K, sp320, cus) == 320) sp = sp320;
     }
     *splits = sp;
     *workspace_bytes = sp > 1 ? (long)sp * M * N * 4 : 0;

@@ -923,7 +923,26 @@ static int choose_cfg(const GemmArgs& g, int mode) {
         // 384 but 17 of 256 - 1033 against 1015 TF/s on the tall tile, while qkv, N = 9 x 384, stays on the wide one: 1131 against 1078)
         if (cfg == 9 ? c10 < best : c10 < 0.97 * best) { best = c10; cfg = 10; }
     }
+    if (wide_ok && g.M > 256 && g.M <= 4096 && g.N >= 256 && (mode == MODE_SWIGLU || mode == MODE_F32) && gemm_mi16_selected(mode)) {
+        // 320 x 256 (round 5): few-row shapes whose M pads badly on 256 / 384 rows - one context-parallel rank's 1600 rows are 5 x 320 exactly where
+        // the 384-row tile computes 1920.  Wave tile 160 x 64: between the 128 x 64 of 256 x 256 and the 192 x 64 of 384 x 256 in fragment bytes per flop
+        const double c12 = cost(320, 256, mode == MODE_SWIGLU ? 1.04 : 1.03, 1);
+        if (c12 < 0.97 * best) { best = c12; cfg = 12; }
+    }
     return cfg;
+}
+
+// split-K launches (vitg_gemm_splitk): rows per tile, 256 or 320.  With fewer tiles than CUs the launch is ONE round of (tiles x splits) blocks and its
+// time is one block's K range times its rows: 98 tiles of 256 rows x 2 splits (M = 1660, N = 3584) run K / 2 per block, 84 tiles of 320 rows x 3 splits
+// run K / 3 - 17 % less work on the critical path for 252 of 256 CUs busy instead of 196.
+int splitk_tile_rows(int M, int N, int K, int splits, int cus) {
+    if (M <= 256 || splits < 2 || !gemm_mi16_selected(MODE_F32)) return 256;
+    auto cost = [&](int bm) {
+        const long blocks = (long)ceil_div(M, bm) * ceil_div(N, 256) * splits;
+        const long rounds = (blocks + cus - 1) / cus;
+        return (double)rounds * bm * ceil_div(K / 64, splits);
+    };
+    return cost(320) < 0.97 * cost(256) ? 320 : 256;
 }
 
 int gemm256_pick_cfg(const GemmArgs& g, int mode);
@@ -938,13 +957,14 @@ static int launch256_m(const GemmArgs& g, hipStream_t s) {
         if (cfg == 2 || g.N < 256) return launch256<T, MODE, 128, 4, 3, 32, false, 0, G2_BM, true>(g, s);
         return launch256<T, MODE, 256, 2, 2, 64, false, 1, G2_BM, true>(g, s);
     }
-    if (MODE == MODE_F32 && g.split_k > 1) cfg = 6;           // split-K partials: 256x256 tiles (the plan of vitg_gemm_splitk_plan assumes them)
+    if (MODE == MODE_F32 && g.split_k > 1)                    // split-K partials: 256x256 tiles, or 320x256 where vitg_gemm_splitk_plan planned with them
+        cfg = splitk_tile_rows(g.M, g.N, g.K, g.split_k, device_cu_count(current_device())) == 320 ? 12 : 6;
     // MFMA shape (round 3): the three shipped tile shapes exist on v_mfma_f32_16x16x32 as well (gemm_mi16.hip), which the package power
     // cap lets run 14 % faster than 32x32x16 on real operands (profiles/r03_mfma_shape.md)
     // (the residual forms of the 16-bit-output mode - vitg_gemm_res16 - exist in gemm_mi16.hip and the 128-tile kernel only; gemm_entry
     // never sends them here with the 256x128 tile)
     // (fp32 output WITH an activation - no caller in the engine - stays on this file's kernels: gemm_mi16.hip's fp32 epilogue carries none)
-    if ((cfg == 6 || cfg == 9 || cfg == 10) && !(MODE == MODE_F32 && g.act != VITG_ACT_NONE) &&
+    if ((cfg == 6 || cfg == 9 || cfg == 10 || cfg == 12) && !(MODE == MODE_F32 && g.act != VITG_ACT_NONE) &&
         (gemm_mi16_selected(MODE) || (MODE == MODE_STORE16 && (g.res || g.res16))))
         return launch_gemm_mi16(g, std::is_same<T, bf16_t>::value ? DT_BF16 : DT_F16, MODE, cfg, s);
 #if VITG_PROFILING_BUILD

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     // activation tiles per interval: 4 (16 MFMAs at NT = 4), except the SwiGLU GEMM on the 192-row wave tile, which runs intervals of 6 (24 MFMAs,
     // 8 barriers per K-tile instead of 12): gate/up +4.2 % (1272 -> 1326 TF/s), step +0.3 %; the same on fc1 / o-proj: -1 % / +-0 (tools/r03/ab_mc6.sh)
     // the 96-row wave tile (WM = 4 on 384 rows: MT = 6, NT = 8) runs intervals of 3 activation tiles x 8 weight tiles = 24 MFMAs, 8 barriers per K-tile
-    constexpr int MC = MT == 6 ? 3 : (MODE == MODE_SWIGLU && MT == 12) ? 6 : 4;
+    // the 160-row wave tile (320 x 256, round 5: M = 1600 = 5 x 320 rows of one context-parallel rank): MT = 10 as two chunks of 5 = 20 MFMAs, 8 barriers per K-tile
+    constexpr int MC = MT == 10 ? 5 : MT == 6 ? 3 : (MODE == MODE_SWIGLU && MT == 12) ? 6 : 4;
     constexpr int NC = MT / MC;                          // row chunks per k-step
     constexpr int NI = 2 * NC;                           // intervals pairs per K-tile (2 k-steps of 32)
     constexpr int ROWB = 128;                            // bytes per LDS row: 64 k x 2 B
@@ -538,6 +539,11 @@ static int wm4_modes() {
 
 template <typename T, int MODE>
 static int launch16_m(const GemmArgs& g, int cfg, hipStream_t s) {
+    // 320 x 256 (round 5): the rows of one context-parallel rank (M = 1600 = 5 x 320; 1660 on the rank that carries the prompt) pad to 1920 on the
+    // 384-row tile; gate / up (SwiGLU) and the split-K o / down projections (fp32 residual) take it - choose_cfg / splitk_tile_rows decide
+    if constexpr (MODE == MODE_SWIGLU || MODE == MODE_F32) {
+        if (cfg == 12 && g.M > 256) return launch16<T, MODE, 320, 256>(g, s);
+    }
     if (cfg == 10 && g.M >= 384) {
         // gemm_wm4 (A/B, bit per epilogue mode: 1 16-bit output, 2 fp32 residual, 4 SwiGLU, 8 16-bit residual): the 4 x 2 wave grid (96 x 128 wave tiles)
 #if VITG_PROFILING_BUILD   // (+3.7 % at long K, -1.7 % at K = 1152, nothing in the step: profiling library only)
@@ -560,7 +566,7 @@ static int launch16_t(const GemmArgs& g, int mode, int cfg, hipStream_t s) {
     return launch16_m<T, MODE_STORE16>(g, cfg, s);
 }
 
-// cfg: the tile shape gemm256.hip's choose_cfg picked (6 = 256x256, 9 = 256x384, 10 = 384x256)
+// cfg: the tile shape gemm256.hip's choose_cfg picked (6 = 256x256, 9 = 256x384, 10 = 384x256, 12 = 320x256)
 int launch_gemm_mi16(const GemmArgs& g, int dtype, int mode, int cfg, hipStream_t s) {
     return dtype == DT_BF16 ? launch16_t<bf16_t>(g, mode, cfg, s) : launch16_t<f16_t>(g, mode, cfg, s);
 }
@@ -600,6 +606,8 @@ extern "C" int vitg_patch_embed16(const void* pix, int T, int R, int patch, cons
     const int G = R / patch, P = G * G, pairs = 3 * patch, K = (pairs + 3) / 4 * 64;
     if (N < 256 || (long)T * 3 * R * R * 2 >= (1l << 32) || (long)T * P >= (1l << 31)) return VITG_ERR_SHAPE;
     if (ldw < K || (ldw % 8) || (ldo % 4) || (N % 4) || (pos && (ldp % 4))) return VITG_ERR_ALIGN;
+    if (((uintptr_t)pix & 3) || ((uintptr_t)Wf & 15) || ((uintptr_t)out & 7)) return VITG_ERR_ALIGN;   // the loader's 16-B chunks start on 4-B pixel pairs
+    if (ldo < N || (pos && ldp < N)) return VITG_ERR_SHAPE;                                            // rows of `out` / `pos` hold N values
     GemmArgs g = {};
     g.A = pix; g.lda = 0; g.W = Wf; g.ldw = ldw; g.M = T * P; g.N = N; g.K = K;
     g.bias = bias; g.act = VITG_ACT_NONE; g.out = out; g.ldo = ldo; g.res = pos; g.ldr = ldp; g.res_mod = pos ? P : 0;

@@ -121,6 +121,13 @@ def patch_embed16(pix: torch.Tensor, wf: torch.Tensor, out: torch.Tensor, *, pat
         raise ValueError("pixel_values must be a contiguous [T, 3, R, R] tensor")
     if pos is not None:
         _req(pos, torch.float32)
+    if bias is not None:
+        _req(bias, torch.float32)
+    G = R // patch
+    if out.dim() != 2 or out.shape[0] != T * G * G or out.shape[1] < wf.shape[0] or out.stride(1) != 1:
+        raise ValueError(f"out must be [T * (R // patch)^2 = {T * G * G}, >= {wf.shape[0]}] with unit column stride, got {tuple(out.shape)}")
+    if bias is not None and bias.numel() < wf.shape[0]:
+        raise ValueError("bias shorter than the embedding width")
     _lib.call("vitg_patch_embed16", _ptr(pix), T, R, patch, _ptr(wf), wf.stride(0), wf.shape[0], dt_code(pix.dtype), _ptr(bias), _ptr(out),
               out.stride(0), _ptr(pos), pos.stride(0) if pos is not None else 0, _stream())
     return out
