@@ -742,6 +742,11 @@ def test_engine_default_paths_against_their_unfused_forms():
     eng8.fp8_r16 = False
     b = eng8.vit_forward(pix, hw)[0].float().clone()
     assert eng8.vit_stream_bytes == 4
-    assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())
-    # ... and both within the fp8 tier's distance of the 16-bit tower
-    assert (a - fused).abs().max().item() <= 0.25 * max(1.0, fused.abs().max().item())
+    # two e4m3 towers whose residual streams round differently decorrelate at the tier's own noise level (every downstream quantiser decision can
+    # flip), so they are compared through their distance to the 16-bit tower: the same, within a quarter, on both streams
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    rms = lambda t: t.pow(2).mean().sqrt().item()          # noqa: E731
+    ea, eb = rms(a - fused), rms(b - fused)
+    print(f"fp8 tower vs 16-bit tower: rms error {ea:.3e} on the 16-bit stream, {eb:.3e} on the fp32 stream (signal rms {rms(fused):.3e})")
+    assert ea <= 1.25 * eb and eb <= 1.25 * ea and ea <= 0.1 * rms(fused)
+    assert rms(a - b) <= 1.6 * max(ea, eb)

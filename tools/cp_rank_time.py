@@ -19,7 +19,7 @@ eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev))
 G = R // cfg.vision.patch_size
 hw = cfg.pooled_grid(T, G)
 plan = make_plan(world, T, hw * hw, 0, 60)
-rank = world - 1                                    # the rank that also owns the prompt tokens
+rank = int(os.environ.get("VITG_CP_RANK", world - 1))   # default: the rank that also owns the prompt tokens (the critical one)
 fr = plan.frames[rank]
 pix = (torch.rand((len(fr), 3, R, R), device=dev) * 2 - 1).half()
 kvw = 2 * cfg.num_key_value_heads * cfg.head_dim
