@@ -108,11 +108,22 @@ def _attn(q, k, v, scale, qz: Q, q_chunk=1024):
 
 
 def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tensor], dtype=torch.float16,
-            mode: str = "product", fp8_mx: bool = True):
+            mode: str = "product", fp8_mx: bool = True, frame_chunk: Optional[int] = None):
+    """frame_chunk: run the tower on that many frames at a time (frames are independent; a 512-frame video's attention scores alone
+    would be 34 GB in one piece) - same values, bounded memory (tools/heavy_tail_rounding_model.py at the headline size)"""
     qz = Q(dtype, mode, fp8_mx)
     v = cfg.vision
     images = [im if im.dim() == 4 else im.unsqueeze(0) for im in images]
     pix = qz.mm(torch.cat(list(images), 0).float())
+    if frame_chunk is not None and pix.shape[0] > frame_chunk:
+        x = torch.cat([_tower(cfg, vsd, pix[s:s + frame_chunk], qz) for s in range(0, pix.shape[0], frame_chunk)], 0)
+    else:
+        x = _tower(cfg, vsd, pix, qz)
+    return _after_tower(cfg, sd, x, input_ids, attention_mask, images, qz, mode)
+
+
+def _tower(cfg, vsd, pix, qz: Q):
+    v = cfg.vision
     # ---- tower
     w = vsd["vision_model.embeddings.patch_embedding.weight"]
     x = F.conv2d(pix, w, vsd["vision_model.embeddings.patch_embedding.bias"], stride=v.patch_size)
@@ -131,6 +142,10 @@ def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tens
         h = qz.a_norm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm2.weight"], vsd[p + "layer_norm2.bias"], v.layer_norm_eps))
         f = qz.a_gelu(O.gelu_tanh(qz.every(F.linear(h, qz.w(vsd[p + "mlp.fc1.weight"]), vsd[p + "mlp.fc1.bias"]))))
         x = qz.every(x + qz.every(F.linear(f, qz.w(vsd[p + "mlp.fc2.weight"]), vsd[p + "mlp.fc2.bias"])))
+    return x
+
+
+def _after_tower(cfg, sd, x, input_ids, attention_mask, images, qz: Q, mode: str):
     feats = torch.split(x, [im.shape[0] for im in images], 0)
     # ---- projector
     pre = "model.mm_projector.out_projection."
