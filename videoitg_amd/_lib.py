@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GEMM variants and ablation switches of include/videoitg_hip_profiling.h
 PROFILING = os.environ.get("VITG_PROFILING_LIB", "0") not in ("", "0")
 LIB_PATH = os.path.join(_HERE, "libvideoitg_hip_prof.so" if PROFILING else "libvideoitg_hip.so")
-# A/B measurements of experiment builds (csrc/build.sh --exp NAME; tools/r04): an explicit path to another build of the SAME C ABI.  Still no
+# A/B measurements of experiment builds (csrc/build.sh --exp NAME; tools/archive/r04_calls.sh.txt): an explicit path to another build of the SAME C ABI.  Still no
 # fallback - if the named file is missing, load() raises.
 if os.environ.get("VITG_LIB_PATH"):
     _alt = os.path.abspath(os.environ["VITG_LIB_PATH"])

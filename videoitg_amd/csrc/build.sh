@@ -17,7 +17,7 @@ if [ "${1:-}" = "--profiling" ]; then
   OBJ="$HERE/build_prof"
   DEFS="-DVITG_PROFILING_BUILD=1"
 fi
-# build.sh --exp NAME [defs]: an EXPERIMENT flavour of the product library (libvideoitg_hip_exp_NAME.so, tools/r04 A/B calls load it through
+# build.sh --exp NAME [defs]: an EXPERIMENT flavour of the product library (libvideoitg_hip_exp_NAME.so, the A/B calls of tools/archive/r04_calls.sh.txt load it through
 # VITG_LIB_PATH): the product sources with -DVITG_EXP=1 and the given -D switches; never built by __graft_entry__.build(), never loaded by default
 if [ "${1:-}" = "--exp" ]; then
   NAME="$2"; shift 2

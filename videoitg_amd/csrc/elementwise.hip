@@ -232,7 +232,7 @@ __global__ void ln16_kernel(const T* __restrict__ x, int ldx, const float* __res
 // Round 4: FOUR rows per wave, 16 lanes per row, for D = 128 NC exactly (the tower's 1152 = 9 x 128).  Every load / store instruction moves 4 x 256 B
 // with all 64 lanes (the one-row-per-wave form above runs its third 1-KiB chunk with 16 of 64 lanes) and the row reductions stay inside a DPP row of
 // 16 lanes (4 rotate-adds instead of 6 cross-lane steps); 9 KiB per wave in flight (+ the prefetched next four rows).  Same arithmetic as ln16_kernel
-// (fp32 two-pass statistics, one rounding of the result); the sums run in another order.  Measured (tools/r04/call18.sh, gpurun_out/r04_c18): stand-alone
+// (fp32 two-pass statistics, one rounding of the result); the sums run in another order.  Measured (tools/archive/r04_calls.sh.txt (call18), gpurun_out/r04_c18): stand-alone
 // 465-486 us against 520-545 (5.0-5.2 against 4.4-4.65 TB/s; a torch copy of the same bytes on that box: 443 us = 5.46 TB/s), inside the step 0.443-0.451
 // against 0.502-0.509 ms per launch, +0.45 % frames/s in three alternations.
 __device__ __forceinline__ float row16_sum(float v) {

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     constexpr int MT = BM / WM / 16;                     // 16-row activation tiles per wave (8 or 12)
     constexpr int NT = BN / WN / 16;                     // 16-wide weight tiles per wave (4 or 6)
     // activation tiles per interval: 4 (16 MFMAs at NT = 4), except the SwiGLU GEMM on the 192-row wave tile, which runs intervals of 6 (24 MFMAs,
-    // 8 barriers per K-tile instead of 12): gate/up +4.2 % (1272 -> 1326 TF/s), step +0.3 %; the same on fc1 / o-proj: -1 % / +-0 (tools/r03/ab_mc6.sh)
+    // 8 barriers per K-tile instead of 12): gate/up +4.2 % (1272 -> 1326 TF/s), step +0.3 %; the same on fc1 / o-proj: -1 % / +-0 (tools/archive/r03_calls.sh.txt (ab_mc6))
     // the 96-row wave tile (WM = 4 on 384 rows: MT = 6, NT = 8) runs intervals of 3 activation tiles x 8 weight tiles = 24 MFMAs, 8 barriers per K-tile
     // the 160-row wave tile (320 x 256, round 5: M = 1600 = 5 x 320 rows of one context-parallel rank): MT = 10 as two chunks of 5 = 20 MFMAs, 8 barriers per K-tile
     constexpr int MC = MT == 10 ? 5 : MT == 6 ? 3 : (MODE == MODE_SWIGLU && MT == 12) ? 6 : 4;
