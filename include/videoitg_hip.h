@@ -117,6 +117,11 @@ int vitg_bilinear_pool16(const void* x, int ldx, void* out, int ldo, int T, int 
 int vitg_gemm_splitk_plan(int M, int N, int K, int* splits, long* workspace_bytes);
 int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, float* out,
                      int ldo, const float* res, int ldr, float* workspace, int splits, void* stream);
+/* 16-bit-output form: out16 = round16(partial_0 + ... + bias) - the split-K form of vitg_gemm(mode = VITG_GEMM_STORE16, act = none) for the Q and K|V
+ * projections of one context-parallel rank (q_proj / k_proj / v_proj + bias, [3P] modeling_qwen2 via grounding_qwen2.py:135; 98 / 28 output tiles on 256 CUs
+ * where the plain launch leaves most of the chip idle for a whole K = 3584 tile).  Same plan function, same workspace rule, same fixed summation order. */
+int vitg_gemm_splitk16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, void* out,
+                       int ldo, float* workspace, int splits, void* stream);
 
 /* ---- FP8 weight path (BASELINE.json configs[4]; videoitg_amd/csrc/gemm_fp8.hip) ------------------------------------------------
  * The reference runs fp16 everywhere (/root/reference/eagle/model/builder.py:59), so this is an additional precision tier of the

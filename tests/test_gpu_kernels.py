@@ -462,6 +462,30 @@ def test_gemm_splitk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K
     assert ops.gemm_splitk_plan(12860, 3584, 18944)[0] == 1 and ops.gemm_splitk_plan(1660, 3584, 1152)[0] == 1
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,splits", [(1660, 3584, 3584, 3), (1600, 1024, 3584, 3), (700, 1024, 4096, 4), (300, 520, 2048, 2)])
+def test_gemm_splitk16_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K, splits):
+    """16-bit-output split-K (Q and K|V projections of one context-parallel rank, round 5): the plain 16-bit-output GEMM's value up to fp32 re-association
+    before the one rounding (<= 1 ulp16 apart), bit-identical from run to run, written through a row stride wider than N (the K|V slot of the gather buffer)"""
+    a, w = rnd((M, K), 51, dtype=dtype).to(dtype).cuda(), (rnd((N, K), 52, dtype=dtype) * K ** -0.5).to(dtype).cuda()
+    bias = rnd((N,), 53).cuda()
+    want = torch.empty((M, N), dtype=dtype, device="cuda")
+    ops.gemm(a, w, want, mode=ops.GEMM_STORE16, bias=bias)
+    ws = torch.empty(splits * M * N, dtype=torch.float32, device="cuda")
+    wide = torch.full((M, N + 64), float("nan"), dtype=dtype, device="cuda")
+    outs = []
+    for _ in range(2):
+        ops.gemm_splitk16(a, w, wide[:, :N], ws, splits, bias=bias)
+        outs.append(wide[:, :N].clone())
+    assert torch.equal(outs[0], outs[1]) and torch.isnan(wide[:, N:]).all()
+    d = (outs[0].float() - want.float()).abs()
+    assert (d <= 2 * EPS16[dtype] * want.float().abs() + 1e-6).all(), d.max().item()
+    ref = (a.float() @ w.float().t() + bias).cpu()
+    assert (outs[0].float().cpu() - ref).abs().max().item() <= EPS16[dtype] * ref.abs().max().item() + 1e-3
+    with pytest.raises(Exception):
+        ops.gemm_splitk16(a, w, wide[:, :N], ws, 1, bias=bias)             # one split is the plain GEMM's job: VITG_ERR_ARG
+
+
 # ---- round 3: the tower's 16-bit residual stream (vitg_gemm_res16 / vitg_layernorm16 / vitg_bilinear_pool16) -----------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,P", [(729 * 2, 1152, 640, 729), (100, 144, 192, 16), (513, 256, 256, 0), (1000, 1152, 4352, 0), (3000, 1152, 1152, 0)])

@@ -44,6 +44,7 @@ SIGNATURES = {
     "vitg_patch_embed16": [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _i, _p],
     "vitg_gemm_splitk_plan": [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_long)],
     "vitg_gemm_splitk": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p],
+    "vitg_gemm_splitk16": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p],
     "vitg_quant_rows_fp8": [_p, _l, _i, _p, _l, _p, _l, _i, _p],
     "vitg_norm_quant_fp8": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _f, _p],
     "vitg_gemm_fp8": [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p],

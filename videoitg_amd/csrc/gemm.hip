@@ -325,6 +325,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         *(f32x4*)(out + m * ldo + n) = v;
     }
 }
+// 16-bit output form (round 5: the Q and K|V projections of one context-parallel rank - 98 / 28 tiles on 256 CUs): out16 = round16(partials + bias)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce16_kernel(const float* __restrict__ ws, long split_stride, int splits, int ldw,
+                                                              const float* __restrict__ bias, T* __restrict__ out, int ldo, int N) {
+    const long m = blockIdx.x;
+    for (int n = threadIdx.x * 4; n < N; n += 1024) {
+        f32x4 v = *(const f32x4*)(ws + m * ldw + n);
+        for (int s = 1; s < splits; ++s) v += *(const f32x4*)(ws + s * split_stride + m * ldw + n);
+        if (bias) v += *(const f32x4*)(bias + n);
+        typename T16<T>::vec4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
+        *(typename T16<T>::vec4*)(out + m * ldo + n) = o;
+    }
+}
 }  // namespace vitg
 
 namespace vitg { int splitk_tile_rows(int M, int N, int K, int splits, int cus); }
@@ -375,6 +390,30 @@ extern "C" int vitg_gemm_splitk(const void* A, int lda, const void* W, int ldw, 
     hipStream_t s = (hipStream_t)stream;
     if (launch_gemm256(g, dtype, VITG_GEMM_F32, s) != 0) return VITG_ERR_LAUNCH;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)M), dim3(256), 0, s, workspace, g.split_stride, splits, N, bias, res, ldr, out, ldo, N);
+    return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
+}
+
+// out16[M, N] = round16(A W^T + bias) through `splits` fp32 K-partials in `workspace` (>= splits * M * N floats), fixed summation order: the split-K form of
+// vitg_gemm(mode = VITG_GEMM_STORE16, act = none) for few-tile shapes with a long K (plan: vitg_gemm_splitk_plan).
+extern "C" int vitg_gemm_splitk16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int dtype, const float* bias, void* out,
+                                  int ldo, float* workspace, int splits, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (splits < 2 || !workspace || !out) return VITG_ERR_ARG;
+    if (N % 4 || ldo % 4 || ldo < N || ((uintptr_t)out & 7)) return VITG_ERR_ALIGN;
+    if (K <= 0 || K % BK != 0 || K / BK < splits) return VITG_ERR_SHAPE;
+    if ((lda % 8) || (ldw % 8)) return VITG_ERR_ALIGN;
+    if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
+    set_attrs();
+    GemmArgs g = {};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = nullptr; g.act = VITG_ACT_NONE; g.out = workspace; g.ldo = N; g.res = nullptr; g.ldr = 0; g.res_mod = 0;
+    g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN); g.stagger_ns = 0; g.group_m = 4; g.Wf = nullptr; g.flags = 0;
+    g.split_k = splits; g.split_stride = (long)M * N;
+    if (!gemm256_applicable(g, VITG_GEMM_F32)) return VITG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (launch_gemm256(g, dtype, VITG_GEMM_F32, s) != 0) return VITG_ERR_LAUNCH;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(splitk_reduce16_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, s, workspace, g.split_stride, splits, N, bias, (bf16_t*)out, ldo, N);
+    else hipLaunchKernelGGL(splitk_reduce16_kernel<f16_t>, dim3((unsigned)M), dim3(256), 0, s, workspace, g.split_stride, splits, N, bias, (f16_t*)out, ldo, N);
     return hipGetLastError() == hipSuccess ? 0 : VITG_ERR_LAUNCH;
 }
 

@@ -314,6 +314,9 @@ class SelectorEngine:
         self._ws: Dict[str, torch.Tensor] = {}
         self._poolsrc: Dict[tuple, object] = {}
         self._splitk: Dict[tuple, tuple] = {}        # (M, N, K) -> (splits, workspace bytes) from vitg_gemm_splitk_plan
+        self._splitk16: Dict[tuple, int] = {}        # (M, N, K) -> splits for 16-bit-output GEMMs (vitg_gemm_splitk16)
+        self._ws_tag = ""                             # "_side" while launching on the context-parallel side stream
+        self.splitk16 = os.environ.get("VITG_SPLITK16", "1") not in ("", "0")     # A/B: 0 = plain kernels for the few-tile 16-bit-output GEMMs
         self._side: Optional[torch.cuda.Stream] = None   # context-parallel layers: K|V projection + exchange run here, under the Q projection
         # VITG_CP_OVERLAP=0 (A/B): fused QKV projection and a blocking exchange, as in round 2.  The split costs one rank ~1 ms of compute per step
         # (two sub-round launches instead of one, tools/cp_rank_time.py) and buys the exchange - est. 0.1-0.15 ms x 28 layers - off the critical path
@@ -423,6 +426,18 @@ class SelectorEngine:
             if plan[1] > 1:
                 ws = self._buf("splitk_ws", (plan[1] * M * N,), torch.float32)
                 return K.gemm_splitk(a, w, out, ws, plan[1], bias=kw.get("bias"), res=kw.get("res"))
+        if (kw.get("mode") == K.GEMM_STORE16 and kw.get("act", 0) == 0 and kw.get("res") is None and kw.get("n") is None and kw.get("m") is None
+                and out.dtype == a.dtype and self.splitk16):
+            # round 5: the same for 16-bit outputs - the Q and K|V projections of one context-parallel rank (98 / 28 tiles of 256 x 256 on 256 CUs: the plain
+            # launch runs a whole K = 3584 tile per block with most of the chip idle); one-GPU shapes plan 1 split and take the plain kernel below
+            M, N, Kd = a.shape[0], w.shape[0], w.shape[1]
+            sp = self._splitk16.get((M, N, Kd))
+            if sp is None:
+                sp = self._splitk16[(M, N, Kd)] = K.gemm_splitk_plan(M, N, Kd)[0] if (N % 4 == 0 and out.stride(0) % 4 == 0) else 1
+            if sp > 1:
+                # (the K|V projection runs on the side stream WHILE the Q projection runs on the main one: each stream its own partial buffer)
+                ws = self._buf("splitk_ws" + self._ws_tag, (sp * M * N,), torch.float32)
+                return K.gemm_splitk16(a, w, out, ws, sp, bias=kw.get("bias"))
         return K.gemm(a, w, out, **kw)
 
     # ---- which tokens does the bilinear pool read? (mlp_proj.py:57-68 semantics: align_corners=False) ----------------
@@ -656,7 +671,11 @@ class SelectorEngine:
                     self._side = torch.cuda.Stream(device=self.device)
                 self._side.wait_stream(main)                              # h is ready; the previous layer's attention is done with the buffer
                 with torch.cuda.stream(self._side):
-                    self._gemm(h, lw.qkv_w[kcol:], kv_local, mode=K.GEMM_STORE16, bias=lw.qkv_b[kcol:])
+                    self._ws_tag = "_side"
+                    try:
+                        self._gemm(h, lw.qkv_w[kcol:], kv_local, mode=K.GEMM_STORE16, bias=lw.qkv_b[kcol:])
+                    finally:
+                        self._ws_tag = ""
                     K.rope_(kv_local, cos, sin, nkv, hd)
                     work = kv_gather.start()
                 self._gemm(h, lw.qkv_w[:kcol], qkv[:, :kcol], mode=K.GEMM_STORE16, bias=lw.qkv_b[:kcol])

@@ -192,6 +192,22 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, workspace: 
     return out
 
 
+def gemm_splitk16(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor, splits: int, *,
+                  bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out16 = round16(a @ w.T + bias) through `splits` fp32 K-partials in `workspace` (>= splits*M*N floats), fixed summation order (vitg_gemm_splitk16)"""
+    _req(a)
+    _req(w, a.dtype)
+    _req(out, a.dtype)
+    _req(workspace, torch.float32)
+    M, K, N = a.shape[0], w.shape[1], w.shape[0]
+    assert a.shape[1] == K and out.shape[0] >= M and out.shape[1] >= N and out.stride(1) == 1 and workspace.numel() >= splits * M * N
+    if bias is not None:
+        _req(bias, torch.float32)
+    _lib.call("vitg_gemm_splitk16", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, N, K, dt_code(a.dtype), _ptr(bias), _ptr(out),
+              out.stride(0), _ptr(workspace), splits, _stream())
+    return out
+
+
 def gemm_streamk_plan(M: int, N: int, K: int):
     """-> (blocks, workspace_bytes): blocks == 0 means stream-K does not apply to the shape (vitg_gemm_streamk_plan)"""
     nb_, ws_ = C.c_int(0), C.c_long(0)

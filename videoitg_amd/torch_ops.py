@@ -62,6 +62,9 @@ _def("patch_embed16(Tensor pix, Tensor wf, Tensor(a!) out, int patch, Tensor? bi
      lambda pix, wf, out, patch, bias=None, pos=None: (_raw.patch_embed16(pix, wf, out, patch=patch, bias=bias, pos=pos), None)[1],
      lambda *a, **k: None)
 
+_def("gemm_splitk16(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int splits, Tensor? bias=None) -> ()",
+     lambda a, w, out, workspace, splits, bias=None: (_raw.gemm_splitk16(a, w, out, workspace, splits, bias=bias), None)[1],
+     lambda a, w, out, workspace, splits, bias=None: None)
 _def("gemm_splitk(Tensor a, Tensor w, Tensor(a!) out, Tensor(b!) workspace, int splits, Tensor? bias=None, Tensor? res=None) -> ()",
      lambda a, w, out, workspace, splits, bias=None, res=None: (_raw.gemm_splitk(a, w, out, workspace, splits, bias=bias, res=res), None)[1],
      lambda *a, **k: None)
@@ -199,6 +202,11 @@ class _Namespace:
         return out
 
     @staticmethod
+    def gemm_splitk16(a, w, out, workspace, splits, *, bias=None):
+        _ops.gemm_splitk16(a, w, out, workspace, splits, bias)
+        return out
+
+    @staticmethod
     def gemm_splitk(a, w, out, workspace, splits, *, bias=None, res=None):
         _ops.gemm_splitk(a, w, out, workspace, splits, bias, res)
         return out
@@ -320,6 +328,6 @@ class _Namespace:
 
 
 K = _Namespace()
-OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
+OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "gemm_splitk16", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
                        "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx",
                        "gemm_res16", "layernorm16", "bilinear_pool16", "patch_embed16", "norm_quant_fp8_16", "gemm_fp8_res16"] + (["gemm_streamk"] if _raw._lib.PROFILING else [])
