@@ -70,6 +70,25 @@ def test_context_parallel_full_size_meets_oracle(world, case):
         assert forms["n_local"] == [1600] * 7 + [1660]
 
 
+def test_context_parallel_on_heavy_tailed_weights():
+    """round 5: the 8-way split on the heavy-tailed twin of the headline video (tests/golden/full_c2o_512x448.json: massive-activation channels, |x| ~ 10^3
+    in both residual streams).  Sharding only re-partitions fp32 sums (tile shapes, split-K), but on these weights every such re-association is amplified like the
+    16-bit operand noise is (35x in logits), so the gathered logits are held to 1e-2 of the ONE-GPU forward (measured 2.6e-3; the benign bound is 4e-3) and to the fixture's stated
+    bounds against the oracle (tests/test_fullsize_parity.py: HEAVY)."""
+    mod = _mod()
+    case = "c2o_512x448"
+    rec = mod.load_case(case)
+    ref1 = single_gpu(case)
+    torch.cuda.empty_cache()
+    got, forms = mod.run(8, case, port=29575)
+    rep = mod.report(case, got, ref1)
+    print(f"context-parallel x8 on {case} (heavy-tailed weights): {rep}")
+    assert got.shape == (rec["frames"],) and torch.isfinite(got).all()
+    assert rep["max_abs_dscore_vs_oracle"] <= 5e-3 and rep["max_abs_dlogit_vs_oracle"] <= 1.2e-1, rep
+    assert rep[f"top{rec['k']}_kept"] >= rec["k"] - 1, rep
+    assert rep["max_abs_dlogit_vs_single_gpu"] <= 1e-2, rep
+
+
 def test_context_parallel_full_size_fp8_llm_mlp():
     """configs[4] names the fp8 weight path at 1 AND 8 GPUs: the named fp8 tier (decoder gate/up + down on e4m3, MX hand-over) through the
     8-way context-parallel forward against the oracle at the tier's own bound, and against the same tier on one GPU."""

@@ -50,7 +50,7 @@ def worker(rank: int, world: int, port: int, case: str, fp8, q) -> None:
         rec = load_case(case)
         cfg = ITGConfig()
         dev = torch.device("cuda:0")
-        eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=parse_fp8(fp8)))
+        eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=parse_fp8(fp8), plan=synth.fixture_plan(rec)))
         ids, pix = synth.fixture_inputs(cfg, rec)
         T = rec["frames"]
         cp = ContextParallel(rank, world)
@@ -97,7 +97,7 @@ def single_gpu_logits(case: str = "c2_512x448", fp8=None) -> torch.Tensor:
     rec = load_case(case)
     cfg = ITGConfig()
     dev = torch.device("cuda:0")
-    eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=parse_fp8(fp8)))
+    eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=parse_fp8(fp8), plan=synth.fixture_plan(rec)))
     ids, pix = synth.fixture_inputs(cfg, rec)
     out = eng.forward(ids, None, [pix.to(torch.float16).to(dev)])[0].view(-1).float().cpu()
     torch.cuda.synchronize()
