@@ -453,6 +453,7 @@ static int launch_attn(AttnArgs a, int batch, int heads, hipStream_t s) {
 
 int attention_sp_dispatch(const AttnArgs& a, int batch, int heads, int head_dim, int dtype, int nw, bool pv16, hipStream_t s);   // attention_sp.hip
 int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, bool qs, hipStream_t s);                 // attention_ab.hip
+int attention_w4_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int form, hipStream_t s);                                      // attention_w4.hip
 
 }  // namespace vitg
 
@@ -517,6 +518,10 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
 #endif
+    if (tr && head_dim == 128 && !a.ablate && (tuning().attn_sp == 4 || tuning().attn_sp == 5 || tuning().attn_sp >= 100)) {      // one wave per SIMD, 64 queries per wave
+        rc = attention_w4_dispatch(a, batch, heads, dtype, tuning().attn_sp >= 100 ? tuning().attn_sp : tuning().attn_sp == 5 ? 3 : 2, s);
+        return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+    }
 #define GO(T, D) (!tr ? launch_attn<T, D, false, 4>(a, batch, heads, s) : nw == 4 ? launch_attn<T, D, true, 4>(a, batch, heads, s) : launch_attn<T, D, true, 8>(a, batch, heads, s))
 #if !VITG_PROFILING_BUILD
     // PRODUCT library: the measured defaults plus ONE cross-check set (attn_sp = 2 / attn_ab = 2: the per-tile kernels of this file).

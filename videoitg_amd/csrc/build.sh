@@ -6,7 +6,7 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS="device gemm gemm256 gemm_mi16 gemm_fp8 attention attention_sp attention_ab elementwise preprocess probe"
+SRCS="device gemm gemm256 gemm_mi16 gemm_fp8 attention attention_sp attention_ab attention_w4 elementwise preprocess probe"
 OUT="$HERE/../libvideoitg_hip.so"
 OBJ="$HERE/build"
 DEFS=""
@@ -36,7 +36,9 @@ for f in $SRCS; do
   [ -f "$src" ] || continue
   objs+=("$obj")
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/gemm_common.h" -nt "$obj" ] || [ "$HERE/attn_common.h" -nt "$obj" ] || [ "$HERE/../../include/videoitg_hip.h" -nt "$obj" ]; then
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC $DEFS -c "$src" -o "$obj" "$@" &
+    extra=""
+    [ "$f" = "attention_w4" ] && extra="-fno-slp-vectorize"      # its VALU stream is hand-placed in single-issue forms (see st_scale in the file)
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC $DEFS $extra -c "$src" -o "$obj" "$@" &
     pids+=($!)
     compiled="$compiled $f"
   else
