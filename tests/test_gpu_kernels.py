@@ -62,8 +62,8 @@ def gemm_cfg(request, ops):
 
 
 # (attn_waves, attn_pipe, attn_dma, attn_sp, attn_ab).  Product: the defaults (hd 72: half-tile-out-of-phase kernel when 256-query blocks fill the
-# chip, else the per-tile loop with LDS-DMA staging; hd 128: software-pipelined loop) and the cross-check set (per-tile kernels for both head sizes).
-@pytest.fixture(params=[pytest.param((0, 0, 0, 0, 0), id="auto"), pytest.param((0, 0, 0, 2, 2), id="per_tile_kernels"),
+# chip, else the per-tile loop with LDS-DMA staging; hd 128: one-wave-per-SIMD kernel for 256-query blocks, else the 8-wave software-pipelined loop) and the cross-check sets (per-tile kernels for both head sizes).
+@pytest.fixture(params=[pytest.param((0, 0, 0, 0, 0), id="auto"), pytest.param((0, 0, 0, 2, 2), id="per_tile_kernels"), pytest.param((0, 0, 0, 4, 0), id="swpipe_8_waves"),
                         R((4, 0, 2, 2, 2), id="waves4_reg"), R((8, 0, 2, 2, 2), id="waves8_reg"), R((4, 1, 2, 2, 2), id="waves4_pipelined"),
                         R((4, 0, 1, 2, 2), id="waves4_dma"), R((8, 0, 1, 2, 2), id="waves8_dma"), R((4, 0, 0, 1, 2), id="waves4_swpipe"),
                         R((8, 0, 0, 1, 2), id="waves8_swpipe"), R((0, 0, 0, 2, 1), id="half_tile_out_of_phase"),
@@ -226,6 +226,27 @@ def test_attention_spiked_key_forces_rescale(ops, attn_waves, dtype, D):
     assert (o.float().cpu() - want[0, 0]).abs().max().item() <= 6 * EPS16[dtype] * v.abs().max().item()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,Sk,D", [(300, 300, 128), (70, 1, 128), (256, 190, 128), (523, 1000, 128), (300, 300, 72), (100, 131, 72)])
+def test_attention_never_uses_rows_past_the_last_key(ops, attn_waves, dtype, S, Sk, D):
+    """The rows behind the last key (the tail of the last 64-key tile, and whole tiles a staging stream runs ahead by) hold NaN in the same
+    allocation: whatever a kernel stages from there (clamped rows, or zeros from a buffer descriptor's range check - csrc/attention_w4.hip) must
+    not reach the result.  Reference analogue: flash-attn's varlen kernels on packed sequences (eagle/model/.../grounding_qwen2.py:45-53)."""
+    H = 2
+    q, k, v = rnd((1, H, S, D), 50, dtype=dtype), rnd((1, H, Sk, D), 51, dtype=dtype), rnd((1, H, Sk, D), 52, dtype=dtype)
+    want = ref_attention(q, k, v, D ** -0.5)
+    qf = q.permute(0, 2, 1, 3).reshape(S, H * D).to(dtype).cuda().contiguous()
+    rows = Sk + 192                                                  # three tiles of poison behind the keys
+    kv = torch.full((rows, 2 * H * D), float("nan"), dtype=dtype, device="cuda")
+    kv[:Sk] = torch.cat([k.permute(0, 2, 1, 3).reshape(Sk, H * D), v.permute(0, 2, 1, 3).reshape(Sk, H * D)], -1).to(dtype).cuda()
+    o = torch.zeros((S, H * D), dtype=dtype, device="cuda")
+    ops.attention(qf, kv, kv[:, H * D:], o, batch=1, heads=H, kv_heads=H, seq=S, kv_seq=Sk, head_dim=D, q_strides=(0, H * D, D),
+                  k_strides=(0, 2 * H * D, D), v_strides=(0, 2 * H * D, D), o_strides=(0, H * D, D), scale=D ** -0.5)
+    got = o.float().cpu().view(1, S, H, D).permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 6 * EPS16[dtype] * v.abs().max().item()
+
+
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("M,D", [(1000, 1152), (37, 144), (515, 3584), (64, 256)])
 def test_layernorm_rmsnorm(ops, out_dtype, M, D):
@@ -335,12 +356,12 @@ def test_product_library_takes_four_option_keys_and_nothing_else(ops):
     from videoitg_amd._lib import VitgError
     if PROF:
         pytest.skip("the profiling library accepts the research knobs by design")
-    for key, val in (("gemm_tile", 128), ("gemm_tile", 256), ("gemm_cfg", 2), ("gemm_cfg", 6), ("gemm_cfg", 9), ("gemm_cfg", 10), ("gemm_cfg", 12), ("attn_ab", 2), ("attn_sp", 2)):
+    for key, val in (("gemm_tile", 128), ("gemm_tile", 256), ("gemm_cfg", 2), ("gemm_cfg", 6), ("gemm_cfg", 9), ("gemm_cfg", 10), ("gemm_cfg", 12), ("attn_ab", 2), ("attn_sp", 2), ("attn_sp", 4)):
         ops.set_option(key, val)
         ops.set_option(key, 0)
     for key, val in (("gemm_flags", 1 << 27), ("gemm_group", 8), ("gemm_mi", 32), ("gemm_mi_modes", 1), ("gemm_pref", 111), ("gemm_wm4", 15), ("gemm_stagger", 1),
                      ("attn_waves", 4), ("attn_dma", 1), ("attn_pipe", 1), ("gemm_cfg", 13), ("gemm_cfg", 3), ("gemm_tile", 64), ("attn_ab", 4), ("attn_ab", 1),
-                     ("attn_sp", 3), ("attn_sp", 1), ("no_such_key", 1)):
+                     ("attn_sp", 3), ("attn_sp", 1), ("attn_sp", 5), ("attn_sp", 104), ("no_such_key", 1)):
         with pytest.raises(VitgError):
             ops.set_option(key, val)
     # the ablation bits of the attention entry (variant >> 4) are refused as before

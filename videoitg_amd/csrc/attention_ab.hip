@@ -121,8 +121,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
             if (ii < K_CPR) {
                 const unsigned off = tail ? dma_src(ii, K_CPR, a.k_rs, true, a.Sk - 1 - kt * ATT_BK) : dk_off[i];
                 if (!dk_pad[i])
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + off),
-                                                     (__attribute__((address_space(3))) void*)(kb + ii * 1024), 16, 0, 0);
+                    lds_dma16(Kt, off, kb + ii * 1024);
             }
         }
     };
@@ -136,8 +135,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
             if (ii < V_CPR) {
                 const unsigned off = tail ? dma_src(ii, V_CPR, a.v_rs, false, a.Sk - 1 - kt * ATT_BK) : dv_off[i];
                 if (!dv_pad[i])              // (the LDS side of the DMA is lane-linear whatever EXEC is: masked lanes leave their 16 B untouched)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + off),
-                                                     (__attribute__((address_space(3))) void*)(vb + ii * 1024), 16, 0, 0);
+                    lds_dma16(Vt, off, vb + ii * 1024);
             }
         }
     };
@@ -326,7 +324,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     }
     issue_k(0, 0);
     issue_v(0, 0);
-    __syncthreads();
+    { lds_dma_drain(); __syncthreads(); }
     // Two separate loops (not one loop with a role branch inside): with the branch inside, the register allocator keeps both
     // roles' accumulator assignments alive across the back edge (247 VGPRs instead of 131).  Both loops execute the same
     // number of barriers.  (sched_barriers: the phases must not be interleaved by the compiler - overlapping QK^T(t) with the
@@ -349,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             pv_mfma(vb_cur, p);
             vb_cur = vb_next;
-            __syncthreads();                               // drains vmcnt too: tile t+1 has landed
+            { lds_dma_drain(); __syncthreads(); }                               // drains vmcnt too: tile t+1 has landed
         }
     } else {
         int vb_prev = 0, vb_cur = 0;
@@ -366,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
             mask_tail(t, s);
             vb_prev = vb_cur;
             vb_cur = vb_next;
-            __syncthreads();
+            { lds_dma_drain(); __syncthreads(); }
         }
         softmax(s, p);                                     // finish the last tile (V(nkt-1) is still resident: nothing was issued after it)
         __builtin_amdgcn_sched_barrier(0);

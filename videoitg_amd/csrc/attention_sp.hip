@@ -111,8 +111,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
             const int ii = wave_u + NW * i;
             if (ii < K_CPR) {
                 const unsigned off = tail ? dma_src(ii, K_CPR, a.k_rs, true, a.Sk - 1 - kt * ATT_BK) : dk_off[i];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + off),
-                                                 (__attribute__((address_space(3))) void*)(kb + ii * 1024), 16, 0, 0);
+                lds_dma16(Kt, off, kb + ii * 1024);
             }
         }
     };
@@ -125,8 +124,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
             const int ii = wave_u + NW * i;
             if (ii < V_CPR) {
                 const unsigned off = tail ? dma_src(ii, V_CPR, a.v_rs, false, a.Sk - 1 - kt * ATT_BK) : dv_off[i];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + off),
-                                                 (__attribute__((address_space(3))) void*)(vb + ii * 1024), 16, 0, 0);
+                lds_dma16(Vt, off, vb + ii * 1024);
             }
         }
     };
@@ -346,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
             m_run = m_new;
         }
         l_run += psum2[0] + psum2[1];
-        __syncthreads();                                   // drains vmcnt too: K(t+2) / V(t) have landed, K(t+1)/V(t-1) reads are done
+        { lds_dma_drain(); __syncthreads(); }                                   // drains vmcnt too: K(t+2) / V(t) have landed, K(t+1)/V(t-1) reads are done
     };
 
     typedef std::integral_constant<int, 0> I0;
@@ -357,11 +355,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     // ---- prologue: K(0), K(1) in flight; S(0) computed without overlap ----------------------------------------------------
     issue_k(0, 0);
     if (nkt > 1) issue_k(1, 1);
-    __syncthreads();
+    { lds_dma_drain(); __syncthreads(); }
     f32x16 sA[2], sB[2];
     vec8 pA[4], pB[4];
     qk_mfma(0, sA);
-    __syncthreads();                                       // every wave is done with K(0) before interval 0 refills buffer 0
+    { lds_dma_drain(); __syncthreads(); }                                       // every wave is done with K(0) before interval 0 refills buffer 0
     // Even intervals: S(t) in sA, P(t) -> pA; odd intervals: sB / pB.  The loop body is a fixed (odd, even) pair so that no
     // register set changes role across the back edge.
     if (nkt == 1) {

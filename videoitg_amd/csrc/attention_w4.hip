@@ -53,12 +53,12 @@ template <> struct W4Mfma<bf16_t> {
 };
 // The settle statements NAME the registers they guard: the MFMA statements are not volatile (hipcc may move them), and only a data dependence keeps
 // every producer above the pad and every reader below it (a bare s_nop was passed by the last MFMA of the prologue in the first build).
-__device__ __forceinline__ void settle_s(f32x16 (&s)[2][2]) { asm volatile("s_nop 15" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1])); }
+__device__ __forceinline__ void settle_s(f32x16 (&s0)[2], f32x16 (&s1)[2]) { asm volatile("s_nop 15" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s1[0]), "+v"(s1[1])); }
 __device__ __forceinline__ void settle_o(f32x16 (&o)[2][4]) {
     asm volatile("s_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
 }
 
-template <typename T, int PF, int ABL = 0>      // ABL: timing ablations (WRONG results; profiling build only): 1 no exponent stream, 2 no K/V staging, 4 no MFMAs, 8 no fragment reads, 16 no barrier
+template <typename T, int PF, int ABL = 0, bool PP = true, int DMA0 = 8>      // DMA0: first step that issues a staging piece; PP: the tt = 1 score tiles ping-pong between two register sets (see interval); ABL: timing ablations (WRONG results; profiling build only): 1 no exponent stream, 2 no K/V staging, 4 no MFMAs, 8 no fragment reads, 16 no barrier
 __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
     adopt_device_key_count(a);
     constexpr int D = 128, NW = 4, QB = 2;
@@ -136,19 +136,14 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
     // count these loads; the interval ends with an explicit vmcnt(0) in front of its barrier (dma_drain).
     const unsigned lds_k0 = (unsigned)(uintptr_t)smem + wave_u * 1024u, lds_v0 = lds_k0 + V_BASE;
     auto dma16 = [&](const u32x4& rsrc, unsigned lds_dst, int voff, int soff) {
-#ifdef W4_DMA_BUILTIN
-        const uintptr_t pb = ((uintptr_t)rsrc[1] << 32) | rsrc[0];
-        const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, (int)rsrc[2], 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (__attribute__((address_space(3))) void*)(uintptr_t)lds_dst, 16, voff, soff, 0, 0);
-        return;
-#endif
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                      :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     };
     auto dma_drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     auto issue_piece = [&](int j, int vt, int kt, int buf) {
-        if (j < V_PW) dma16(v_rsrc, lds_v0 + buf * VT_BYTES + NW * j * 1024, dv_off[j], vt * v_tile_bytes);
-        else dma16(k_rsrc, lds_k0 + buf * KT_BYTES + NW * (j - V_PW) * 1024, dk_off[j - V_PW], kt * k_tile_bytes);
+        // the tile offset rides in the VGPR offset: the hardware's range check covers voffset (+ the immediate), NOT soffset
+        if (j < V_PW) dma16(v_rsrc, lds_v0 + buf * VT_BYTES + NW * j * 1024, dv_off[j] + vt * v_tile_bytes, 0);
+        else dma16(k_rsrc, lds_k0 + buf * KT_BYTES + NW * (j - V_PW) * 1024, dk_off[j - V_PW] + kt * k_tile_bytes, 0);
     };
     constexpr int NPIECE = K_PW + V_PW;
     auto issue_k = [&](int kt, int buf) {
@@ -188,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
         return bitcast<vec8>(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     // S = K Q^T for one 64-key tile (prologue only: no overlap)
-    auto qk_mfma = [&](int kbuf, f32x16 (&s)[QB][2]) {
+    auto qk_mfma = [&](int kbuf, f32x16 (&s0)[QB], f32x16 (&s1)[QB]) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -196,11 +191,12 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
                 const vec8 kf = k_frag(kbuf, tt, ks);
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
-                    if (ks == 0) W4Mfma<T>::s_init_pad(s[u][tt], kf, qf[u][0]);
-                    else W4Mfma<T>::s_acc_pad(s[u][tt], kf, qf[u][ks]);
+                    f32x16& d = tt == 0 ? s0[u] : s1[u];
+                    if (ks == 0) W4Mfma<T>::s_init_pad(d, kf, qf[u][0]);
+                    else W4Mfma<T>::s_acc_pad(d, kf, qf[u][ks]);
                 }
             }
-        settle_s(s);
+        settle_s(s0, s1);
     };
     // O += V^T P^T for one tile (drain after the last interval)
     auto pv_mfma = [&](int vbuf, vec8 (&p)[QB][4]) {
@@ -220,7 +216,11 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
     // (u, tt) = (0,0) (1,0) (0,1) (1,1) and is done with both tt = 0 tiles before step 16, with the tt = 1 tiles before step 24 - exactly
     // when the QK^T steps of S(t+1) start writing those registers.  At no point are two score tiles alive, which is what keeps scores + P
     // + fragments inside the arch VGPRs (a second score array put the allocator 60 registers over: first build of this kernel).
-    auto interval = [&](int t, auto par_c, auto qk_c, auto pv_c, auto pad_c, f32x16 (&s)[QB][2], vec8 (&p_cur)[QB][4], vec8 (&p_prv)[QB][4]) {
+    auto interval = [&](int t, auto par_c, auto qk_c, auto pv_c, auto pad_c, f32x16 (&s0)[QB], f32x16 (&s1c)[QB], f32x16 (&s1n)[QB], vec8 (&p_cur)[QB][4],
+                        vec8 (&p_prv)[QB][4]) {
+        // S(t) tile (u, tt): tt = 0 -> s0[u] (overwritten in place by S(t+1)), tt = 1 -> s1c[u]; S(t+1)'s tt = 1 tiles go to s1n[u] (PP: the other
+        // register set, so the exponents of the tt = 1 tiles may run until the interval's last step; !PP: the same registers)
+        auto sc = [&](int u, int tt) -> f32x16& { return tt == 0 ? s0[u] : s1c[u]; };
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool PAD = decltype(pad_c)::value;      // outside the main loop: padded MFMA statements (see W4Mfma)
         constexpr bool HAS_QK = decltype(qk_c)::value, HAS_PV = decltype(pv_c)::value;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (t * ATT_BK + tt * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= a.Sk) s[u][tt][r] = -INFINITY;
+                        if (t * ATT_BK + tt * 32 + 8 * (r >> 2) + 4 * h + (r & 3) >= a.Sk) sc(u, tt)[r] = -INFINITY;
         }
         constexpr int NQK = HAS_QK ? 2 * KS : 0, NPV = HAS_PV ? 4 * DT : 0, NM = NQK + NPV;
         auto frag = [&](int i) -> vec8 {
@@ -250,12 +250,13 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
                 const int j = i - NPV, tt = j / KS, ks = j % KS;
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
+                    f32x16& d = tt == 0 ? s0[u] : s1n[u];
                     if constexpr (PAD) {
-                        if (ks == 0) W4Mfma<T>::s_init_pad(s[u][tt], f, qf[u][0]);
-                        else W4Mfma<T>::s_acc_pad(s[u][tt], f, qf[u][ks]);
+                        if (ks == 0) W4Mfma<T>::s_init_pad(d, f, qf[u][0]);
+                        else W4Mfma<T>::s_acc_pad(d, f, qf[u][ks]);
                     } else {
-                        if (ks == 0) W4Mfma<T>::s_init(s[u][tt], f, qf[u][0]);
-                        else W4Mfma<T>::s_acc(s[u][tt], f, qf[u][ks]);
+                        if (ks == 0) W4Mfma<T>::s_init(d, f, qf[u][0]);
+                        else W4Mfma<T>::s_acc(d, f, qf[u][ks]);
                     }
                 }
             }
@@ -266,9 +267,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
 #pragma unroll
         for (int u = 0; u < QB; ++u) { m_use[u] = m_run[u]; grew[u] = 0; psum[u][0] = psum[u][1] = 0.f; mx[u] = 0.f; }
         auto row_max = [&](int u, int half) {
-            if (half == 0) mx[u] = s[u][0][0];
+            if (half == 0) mx[u] = s0[u][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx[u] = fmaxf(mx[u], s[u][half][r]);
+            for (int r = 0; r < 16; ++r) mx[u] = fmaxf(mx[u], sc(u, half)[r]);
             if (half == 1) {
                 const u32x2 sw = __builtin_amdgcn_permlane32_swap(bitcast<uint32_t>(mx[u]), bitcast<uint32_t>(mx[u]), false, false);
                 const float m = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1])) * a.scale_log2e;      // scale > 0
@@ -288,8 +289,8 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
             // instruction needs a wait state, and an asm v_add_f32 placed straight behind its v_exp_f32 read stale lanes (second build of this
             // pipeline).  The single-issue forms the stream wants beside MFMAs (MI355X_MICROARCH.md "price of one filler": v_pk_fma_f32 /
             // v_pk_add_f32 cost more than the two plain instructions they replace) come from building this file with -fno-slp-vectorize.
-            xs[e][0] = __builtin_fmaf(s[u][tt][r], a.scale_log2e, -m_use[u]);
-            xs[e][1] = __builtin_fmaf(s[u][tt][r + 1], a.scale_log2e, -m_use[u]);
+            xs[e][0] = __builtin_fmaf(sc(u, tt)[r], a.scale_log2e, -m_use[u]);
+            xs[e][1] = __builtin_fmaf(sc(u, tt)[r + 1], a.scale_log2e, -m_use[u]);
         };
         auto st_exp = [&](int e) {
             xs[e][0] = __builtin_amdgcn_exp2f(xs[e][0]);
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
             const int u = (e >> 3) & 1, tt = e >> 4, r = (e & 7) * 2;
             psum[u][0] += xs[e][0];
             psum[u][1] += xs[e][1];
+            asm volatile("" : "+v"(psum[u][0]), "+v"(psum[u][1]));      // opaque: left alone, hipcc sinks all 64 row-sum adds below the last MFMA of the interval
             p_cur[u][tt * 2 + (r >> 3)][r & 7] = T16<T>::from_f32(xs[e][0]);
             p_cur[u][tt * 2 + (r >> 3)][(r & 7) + 1] = T16<T>::from_f32(xs[e][1]);
             if ((e & 3) == 3) asm volatile("" : "+v"(p_cur[u][tt * 2 + (r >> 3)]));   // opaque use: keeps the stream inside its slices
@@ -306,18 +308,21 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
         constexpr int NSM = QB * 2, NE = 16 * QB;
         // full interval: the pairs are spread over slices NSM .. EXP_END-1 (their scale stage runs one slice earlier, their pack stage one
         // later); EXP_END = the step at which the tt = 1 tiles are overwritten
-        constexpr int EXP_END = (NPV > 0 && NQK > 0) ? NPV + KS : NM;
-        auto exp_hi = [&](int i) { return i < NSM ? 0 : i >= EXP_END ? NE : (i + 1 - NSM) * NE / (EXP_END - NSM); };
-        if constexpr (NPV > 0 && NQK > 0) {
+        constexpr bool FULL = NPV > 0 && NQK > 0;
+        constexpr int EXP_END = (FULL && !PP) ? NPV + KS : NM;
+        // pairs retired through slice i.  Full interval: the tt = 0 tiles (pairs 0..15) go over the PV steps - they must be gone when the first
+        // QK^T step overwrites them - and the tt = 1 tiles over the QK^T steps (PP) or up to the step that overwrites them (!PP)
+        auto exp_hi = [&](int i) {
+            if (i < NSM) return 0;
+            if (i >= EXP_END) return NE;
+            if (FULL && PP) return i < NPV ? (i + 1 - NSM) * (NE / 2) / (NPV - NSM) : NE / 2 + (i + 1 - NPV) * (NE / 2) / (NM - NPV);
+            return (i + 1 - NSM) * NE / (EXP_END - NSM);
+        };
+        if constexpr (FULL && !PP) {
             static_assert((NPV - NSM) * NE / (EXP_END - NSM) >= NE / 2, "both tt = 0 tiles must be retired before the first QK^T step");
         }
         auto valu_slice = [&](int i) {
             if (i < NSM) row_max(i >> 1, i & 1);
-#ifdef W4_NO_VPIPE
-#pragma unroll
-            for (int e = exp_hi(i - 1); e < exp_hi(i); ++e) { st_scale(e); st_exp(e); st_pack(e); }
-            return;
-#endif
 #pragma unroll
             for (int e = exp_hi(i); e < exp_hi(i + 1); ++e) st_scale(e);
 #pragma unroll
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
             for (int e = 0; e < NE; ++e) { st_scale(e); st_exp(e); st_pack(e); }
             if constexpr (HAS_QK) {
                 __builtin_amdgcn_sched_barrier(0);
-                qk_mfma(PAR ^ 1, s);
+                qk_mfma(PAR ^ 1, s0, s1n);
             }
         } else {
             vec8 fr[PF + 1];
@@ -345,14 +350,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
             for (int i = 0; i < PF && i < NM; ++i) fr[i] = frag(i);
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
-#ifdef W4_DMA_HEAD
-                if (i == 0 && !(ABL & 2)) {
-#pragma unroll
-                    for (int j = 0; j < NPIECE; ++j) issue_piece(j, t, t + 2, PAR);
-                }
-#else
-                if (i < NPIECE && !(ABL & 2)) issue_piece(i, t, t + 2, PAR);       // V(t), K(t+2): read in interval t+1
-#endif
+                if (i >= (FULL ? DMA0 : 0) && i < (FULL ? DMA0 : 0) + NPIECE && !(ABL & 2)) issue_piece(i - (FULL ? DMA0 : 0), t, t + 2, PAR);       // V(t), K(t+2): read in interval t+1
                 if (i + PF < NM && !((ABL & 8) && i + PF > PF + 1)) fr[(i + PF) % (PF + 1)] = frag(i + PF);
                 if (!(ABL & 4)) mfma_step(i, fr[i % (PF + 1)]);
                 else asm volatile("" :: "v"(fr[i % (PF + 1)]));
@@ -401,27 +399,29 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
     issue_k(1, 1);                                     // (zeros when there is no second tile)
     dma_drain();
     __syncthreads();
-    f32x16 s[QB][2];
+    f32x16 s0[QB], s1A[QB];
+    f32x16 s1B_[PP ? QB : 1];
+    f32x16 (&s1B)[QB] = *reinterpret_cast<f32x16 (*)[QB]>(PP ? (void*)&s1B_ : (void*)&s1A);      // !PP: one register set, in place
     vec8 pA[QB][4], pB[QB][4];
-    qk_mfma(0, s);
+    qk_mfma(0, s0, s1A);
     __syncthreads();
     // even intervals write P into pA, odd ones into pB; the loop body is a fixed (odd, even) pair so that no register set changes role
     if (nkt == 1) {
-        interval(0, I0{}, N{}, N{}, Y{}, s, pA, pB);
+        interval(0, I0{}, N{}, N{}, Y{}, s0, s1A, s1B, pA, pB);
         pv_mfma(0, pA);
     } else {
-        interval(0, I0{}, Y{}, N{}, Y{}, s, pA, pB);
+        interval(0, I0{}, Y{}, N{}, Y{}, s0, s1A, s1B, pA, pB);
         int t = 1;
         for (; t + 2 < nkt; t += 2) {
-            interval(t, I1{}, Y{}, Y{}, N{}, s, pB, pA);
-            interval(t + 1, I0{}, Y{}, Y{}, N{}, s, pA, pB);
+            interval(t, I1{}, Y{}, Y{}, N{}, s0, s1B, s1A, pB, pA);
+            interval(t + 1, I0{}, Y{}, Y{}, N{}, s0, s1A, s1B, pA, pB);
         }
         if (t + 1 < nkt) {
-            interval(t, I1{}, Y{}, Y{}, Y{}, s, pB, pA);
-            interval(t + 1, I0{}, N{}, Y{}, Y{}, s, pA, pB);
+            interval(t, I1{}, Y{}, Y{}, Y{}, s0, s1B, s1A, pB, pA);
+            interval(t + 1, I0{}, N{}, Y{}, Y{}, s0, s1A, s1B, pA, pB);
             pv_mfma(0, pA);
         } else {
-            interval(t, I1{}, N{}, Y{}, Y{}, s, pB, pA);
+            interval(t, I1{}, N{}, Y{}, Y{}, s0, s1B, s1A, pB, pA);
             pv_mfma(1, pB);
         }
     }
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, int PF, int ABL = 0>
+template <typename T, int PF, int ABL = 0, bool PP = true, int DMA0 = 8>
 static int launch_w4(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, 256);
     typedef AttnCfg<128> C;
@@ -455,32 +455,37 @@ static int launch_w4(AttnArgs a, int batch, int heads, hipStream_t s) {
     static std::atomic<unsigned> done_mask{0};
     const int cur_dev = current_device();
     if (!device_done(done_mask, cur_dev)) {
-        (void)hipFuncSetAttribute((const void*)attn_w4_kernel<T, PF, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_w4_kernel<T, PF, ABL, PP, DMA0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         mark_device_done(done_mask, cur_dev);
     }
-    hipLaunchKernelGGL((attn_w4_kernel<T, PF, ABL>), dim3(a.nqb * heads * batch), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attn_w4_kernel<T, PF, ABL, PP, DMA0>), dim3(a.nqb * heads * batch), dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
 
-// called by vitg_attention (attention.hip): head dim 128, 256-query blocks.  form = fragment prefetch distance in steps (2 or 3)
+// called by vitg_attention (attention.hip): head dim 128, 256-query blocks.  form 0 = the shipped kernel (fragments requested 2 steps ahead, tt = 1
+// score tiles ping-pong, staging pieces from step 8 on); profiling library: 5 in-place score tiles | 6 / 7 staging from step 0 / 16 | 100 + bits
+// timing ablations (tools/r05/attn_w4_ablate.py)
 int attention_w4_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int form, hipStream_t s) {
 #if VITG_PROFILING_BUILD
-    if (form >= 100 && dtype == DT_F16) {                 // timing ablations (tools/r05/attn_w4_ab.py): form = 100 + bits
+    if (form >= 100 && dtype == DT_F16) {
         switch (form - 100) {
-            case 1: return launch_w4<f16_t, 2, 1>(a, batch, heads, s);
-            case 2: return launch_w4<f16_t, 2, 2>(a, batch, heads, s);
-            case 4: return launch_w4<f16_t, 2, 4>(a, batch, heads, s);
-            case 8: return launch_w4<f16_t, 2, 8>(a, batch, heads, s);
-            case 16: return launch_w4<f16_t, 2, 16>(a, batch, heads, s);
-            case 18: return launch_w4<f16_t, 2, 18>(a, batch, heads, s);
-            case 5: return launch_w4<f16_t, 2, 5>(a, batch, heads, s);
-            case 19: return launch_w4<f16_t, 2, 19>(a, batch, heads, s);
+            case 1: return launch_w4<f16_t, 2, 1, true, 8>(a, batch, heads, s);
+            case 2: return launch_w4<f16_t, 2, 2, true, 8>(a, batch, heads, s);
+            case 4: return launch_w4<f16_t, 2, 4, true, 8>(a, batch, heads, s);
+            case 8: return launch_w4<f16_t, 2, 8, true, 8>(a, batch, heads, s);
+            case 16: return launch_w4<f16_t, 2, 16, true, 8>(a, batch, heads, s);
+            case 18: return launch_w4<f16_t, 2, 18, true, 8>(a, batch, heads, s);
+            case 5: return launch_w4<f16_t, 2, 5, true, 8>(a, batch, heads, s);
+            case 19: return launch_w4<f16_t, 2, 19, true, 8>(a, batch, heads, s);
             default: return -1;
         }
     }
+    if (form == 5) return dtype == DT_BF16 ? launch_w4<bf16_t, 2, 0, false, 8>(a, batch, heads, s) : launch_w4<f16_t, 2, 0, false, 8>(a, batch, heads, s);
+    if (form == 6) return dtype == DT_BF16 ? launch_w4<bf16_t, 2, 0, true, 0>(a, batch, heads, s) : launch_w4<f16_t, 2, 0, true, 0>(a, batch, heads, s);
+    if (form == 7) return dtype == DT_BF16 ? launch_w4<bf16_t, 2, 0, true, 16>(a, batch, heads, s) : launch_w4<f16_t, 2, 0, true, 16>(a, batch, heads, s);
 #endif
-    if (dtype == DT_BF16) return form == 3 ? launch_w4<bf16_t, 3>(a, batch, heads, s) : launch_w4<bf16_t, 2>(a, batch, heads, s);
-    return form == 3 ? launch_w4<f16_t, 3>(a, batch, heads, s) : launch_w4<f16_t, 2>(a, batch, heads, s);
+    (void)form;
+    return dtype == DT_BF16 ? launch_w4<bf16_t, 2, 0, true, 8>(a, batch, heads, s) : launch_w4<f16_t, 2, 0, true, 8>(a, batch, heads, s);
 }
 
 }  // namespace vitg

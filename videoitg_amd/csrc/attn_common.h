@@ -24,6 +24,29 @@ __device__ __forceinline__ void adopt_device_key_count(AttnArgs& a) {
     if (a.sk_dev) a.Sk = min(a.Sk, max(1, __builtin_amdgcn_readfirstlane(*a.sk_dev)));
 }
 
+// One LDS-DMA piece: 64 lanes x 16 B from (wave-uniform base + per-lane byte offset) to 1 KiB of LDS at a wave-uniform address.
+// VITG_ASM_DMA = 1 (default since round 5: +0.7 % hd 72, +1 % hd 128 in same-call alternation, gpurun_out/r05_dma_1): issued from inline assembly, which hipcc does not count - the caller drains with lds_dma_drain() in front of the barrier that
+// publishes the tile.  Why: hipcc orders every LDS read it cannot disambiguate behind a pending LDS-DMA builtin (s_waitcnt vmcnt(0) in front of the
+// first V^T read of an interval, in the middle of the interleaved stream - profiles/r05_attention_w4.md), i.e. a wave waits for its staging of the
+// NEXT tile before it reads THIS one.  VITG_ASM_DMA = 0: the builtin, hipcc's own waits.
+#ifndef VITG_ASM_DMA
+#define VITG_ASM_DMA 1
+#endif
+__device__ __forceinline__ void lds_dma16(const char* base_uniform, unsigned off, char* lds_dst_uniform) {
+#if VITG_ASM_DMA
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"((unsigned)(uintptr_t)lds_dst_uniform), "v"(off), "s"(base_uniform) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_uniform + off),
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ void lds_dma_drain() {
+#if VITG_ASM_DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 constexpr int ATT_BK = 64;
 // NW waves per block, 32 queries per wave: BQ = 32*NW queries share one K/V staging stream (NW = 8: 256 queries, 1 block/CU;
 // NW = 4: 128 queries, 2 blocks/CU)

@@ -126,7 +126,7 @@ struct Tuning {
     int gemm_tile;     // 0 auto | 128 the 128x128 register-staged kernels everywhere (cross-check set) | 256 never the 128-tile kernel where a 256-wide one applies
     int gemm_cfg;      // 0 auto (choose_cfg per shape) | 2 256x128x32 | 6 256x256x64 | 9 256x384x64 | 10 384x256x64 | 12 320x256x64 (SwiGLU / fp32-residual GEMMs; others fall to 256x256) : forces ONE shipped tile shape (tests reach every shipped kernel on small shapes)
     int attn_ab;       // hd 72: 0 auto (half-tile-out-of-phase kernel when 256-query blocks fill the chip) | 2 off (per-tile kernel: cross-check)
-    int attn_sp;       // hd 128: 0 auto (software-pipelined kernel) | 2 off (per-tile kernel: cross-check)
+    int attn_sp;       // hd 128: 0 auto (one-wave-per-SIMD kernel for 256-query blocks, else the 8-wave software-pipelined kernel) | 4 the 8-wave software-pipelined kernel | 2 per-tile kernel (cross-checks)
     // ---- research knobs: libvideoitg_hip_prof.so only (include/videoitg_hip_profiling.h) -------------------------------------
     int gemm_flags;    // A/B and ablation bits (see the kernels)
     int gemm_stagger;  // fp32-residual GEMMs in the tile loop: start the tile groups a third of a tile period apart (0 off, 1 = estimated period, > 1 = ns);
@@ -141,7 +141,7 @@ struct Tuning {
     int gemm_wm4;      // 384x256 tile of gemm_mi16.hip as a 4 x 2 wave grid (96 x 128 wave tiles): 0 library default | -1 never | bit mask of epilogue modes
                        // (+3.7 % at long K, -1.7 % at K = 1152, nothing in the step)
     // research VALUES of the product keys (profiling library only): gemm_cfg 1/3/4/5/7/8/11/13; attn_ab 1 forced on | 3 16 waves per block | 4 PV on 32x32x16 |
-    // 5 VALU row sums | 6 pre-scaled Q without the shift column; attn_sp 1 forced on for both head sizes | 3 hd 128 with PV on 16x16x32 (3-4 % slower)
+    // 5 VALU row sums | 6 pre-scaled Q without the shift column; attn_sp 1 8-wave kernel forced on for both head sizes | 3 hd 128 with PV on 16x16x32 (3-4 % slower) | 5 / 6 / 7 / 100+ research forms of attention_w4.hip
 };
 Tuning& tuning();
 #if VITG_PROFILING_BUILD
