@@ -49,7 +49,8 @@ int vitg_device_info(char* name, int name_len);
  *               per-shape choice (csrc/gemm256.hip: choose_cfg) - lets a test reach every shipped kernel on a small shape (12 exists for the SwiGLU and
  *               fp32-residual GEMMs; other modes run 256x256 under it)
  *   attn_ab     2  head dim 72 on the per-tile kernel (csrc/attention.hip) instead of the half-tile-out-of-phase one (csrc/attention_ab.hip)
- *   attn_sp     4  head dim 128 on the 8-wave software-pipelined kernel (csrc/attention_sp.hip) instead of the one-wave-per-SIMD one (csrc/attention_w4.hip) | 2  on the per-tile kernel (csrc/attention.hip)
+ *   attn_sp     4  head dim 128 on the one-wave-per-SIMD kernel (csrc/attention_w4.hip: +5 % in isolation, -4 % inside the step - opt-in) instead of the 8-wave
+ *               software-pipelined one (csrc/attention_sp.hip) | 2  on the per-tile kernel (csrc/attention.hip)
  * Any other key or value returns VITG_ERR_ARG.  These are process-global test hooks: set them before the forward they should apply to, not from a
  * second thread while one runs.  tests/test_gpu_e2e.py::test_full_size_invariants runs the same video through (gemm_tile 128, attn_ab 2, attn_sp 2)
  * and through the defaults.

@@ -128,7 +128,7 @@ def test_attention_loop_structures_agree(golden_dir, name):
     from videoitg_amd import ops
     tol = GOLDEN_TOL[torch.float16].get(name, SCORE_TOL)
     outs = []
-    for sp in (2, 4, 0):               # 2 = per-tile kernels, 4 = 8-wave software-pipelined loop, 0 = the default (one-wave-per-SIMD kernel where 256-query blocks fill the chip)
+    for sp in (2, 4, 0):               # 2 = per-tile kernels, 4 = one-wave-per-SIMD kernel (hd 128), 0 = the default (software-pipelined 8-wave loop for hd 128)
         ops.set_option("attn_sp", sp)
         try:
             z, got, T = run_case(golden_dir, name, torch.float16, variant=0)

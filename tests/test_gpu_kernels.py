@@ -62,8 +62,8 @@ def gemm_cfg(request, ops):
 
 
 # (attn_waves, attn_pipe, attn_dma, attn_sp, attn_ab).  Product: the defaults (hd 72: half-tile-out-of-phase kernel when 256-query blocks fill the
-# chip, else the per-tile loop with LDS-DMA staging; hd 128: one-wave-per-SIMD kernel) and the cross-check sets (per-tile kernels for both head sizes).
-@pytest.fixture(params=[pytest.param((0, 0, 0, 0, 0), id="auto"), pytest.param((0, 0, 0, 2, 2), id="per_tile_kernels"), pytest.param((0, 0, 0, 4, 0), id="swpipe_8_waves"),
+# chip, else the per-tile loop with LDS-DMA staging; hd 128: 8-wave software-pipelined loop; attn_sp = 4: the one-wave-per-SIMD kernel) and the cross-check sets (per-tile kernels for both head sizes).
+@pytest.fixture(params=[pytest.param((0, 0, 0, 0, 0), id="auto"), pytest.param((0, 0, 0, 2, 2), id="per_tile_kernels"), pytest.param((0, 0, 0, 4, 0), id="hd128_one_wave_per_simd"),
                         R((4, 0, 2, 2, 2), id="waves4_reg"), R((8, 0, 2, 2, 2), id="waves8_reg"), R((4, 1, 2, 2, 2), id="waves4_pipelined"),
                         R((4, 0, 1, 2, 2), id="waves4_dma"), R((8, 0, 1, 2, 2), id="waves8_dma"), R((4, 0, 0, 1, 2), id="waves4_swpipe"),
                         R((8, 0, 0, 1, 2), id="waves8_swpipe"), R((0, 0, 0, 2, 1), id="half_tile_out_of_phase"),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""hd-128 attention: the one-wave-per-SIMD kernel (attention_w4.hip: attn_sp = 0, the default since round 5; research forms 5 in-place score
-tiles, 6 / 7 staging from step 0 / 16 - profiling library) against the 8-wave software-pipelined kernel (attn_sp = 4), same call, alternating.  Correctness first (fp64 reference at small S incl. ragged tails; default kernel at the LLM shape)."""
+"""hd-128 attention: the one-wave-per-SIMD kernel (attention_w4.hip: attn_sp = 4; research forms 5 in-place score
+tiles, 6 / 7 staging from step 0 / 16 - profiling library) against the 8-wave software-pipelined kernel (attn_sp = 0, the default), same call, alternating.  Correctness first (fp64 reference at small S incl. ragged tails; default kernel at the LLM shape)."""
 import os, sys, torch
 os.environ.setdefault("VITG_PROFILING_LIB", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -30,7 +30,7 @@ def main():
             qkv = (torch.randn((B * S, (H + 2 * HKV) * D), device="cuda") * scale).to(dt)
             r = ref(qkv, B, H, HKV, S, D)
             errs = []
-            for sp in (4, 0, 0):
+            for sp in (0, 4, 4):
                 o = torch.full((B * S, H * D), float("nan"), dtype=dt, device="cuda")
                 run(qkv, o, B, H, HKV, S, D, sp)
                 errs.append((o.double() - r).abs().max().item())
@@ -44,7 +44,7 @@ def main():
     for dt in (torch.float16,):
         qkv = torch.randn((B * S, (H + 2 * HKV) * D), device="cuda").to(dt)
         outs = {}
-        for sp in (4, 0, 0):
+        for sp in (0, 4, 4):
             o = torch.empty((B * S, H * D), dtype=dt, device="cuda")
             run(qkv, o, B, H, HKV, S, D, sp)
             outs[sp] = o.float()
@@ -52,7 +52,7 @@ def main():
         o = torch.empty((B * S, H * D), dtype=dt, device="cuda")
         for rnd in range(4):
             line = []
-            for sp in (4, 0, 5, 6, 7):
+            for sp in (0, 4, 5, 6, 7):
                 for _ in range(2):
                     run(qkv, o, B, H, HKV, S, D, sp)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Is the one-wave-per-SIMD hd-128 kernel (attn_sp = 0) bit-identical to the 8-wave software-pipelined one (attn_sp = 4)?  Per key count."""
+"""Is the one-wave-per-SIMD hd-128 kernel (attn_sp = 4) bit-identical to the 8-wave software-pipelined one (attn_sp = 0)?  Per key count."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from attn_w4_ab import run
@@ -9,7 +9,7 @@ for dt in (torch.float16, torch.bfloat16):
         torch.manual_seed(S)
         qkv = torch.randn((B * S, (H + 2 * HKV) * D), device="cuda").to(dt)
         outs = []
-        for sp in (4, 0):
+        for sp in (0, 4):
             o = torch.zeros((B * S, H * D), dtype=dt, device="cuda")
             run(qkv, o, B, H, HKV, S, D, sp)
             outs.append(o.float())
@@ -22,7 +22,7 @@ for S in (63, 64, 300, 2049):
     torch.manual_seed(S)
     qkv = torch.randn((B * S, (H + 2 * HKV) * D), device="cuda").half()
     outs = []
-    for sp in (4, 0):
+    for sp in (0, 4):
         o = torch.zeros((B * S, H * D), dtype=torch.float16, device="cuda")
         run(qkv, o, B, H, HKV, S, D, sp)
         outs.append(o.float().view(S, H, D))

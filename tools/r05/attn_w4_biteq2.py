@@ -4,7 +4,7 @@ from attn_w4_ab import run
 B, H, HKV, D, S = 1, 4, 2, 128, 4096
 def count(qkv, tag):
     outs = []
-    for sp in (4, 0, 4, 0):
+    for sp in (0, 4, 0, 4):
         o = torch.zeros((B * S, H * D), dtype=torch.float16, device="cuda")
         run(qkv, o, B, H, HKV, S, D, sp)
         outs.append(o.float())

@@ -7,7 +7,7 @@ for S in (2048, 2049, 2112, 2176, 2304, 2305, 2111):
     torch.manual_seed(1)
     qkv = torch.randn((B * S, (H + 2 * HKV) * D), device="cuda").half()
     outs = {}
-    for tag, sp, nw in (("sp8", 4, 8), ("sp4", 4, 4), ("w4", 0, 0), ("pertile", 2, 0)):
+    for tag, sp, nw in (("sp8", 0, 8), ("sp4", 0, 4), ("w4", 4, 0), ("pertile", 2, 0)):
         ops.set_option("attn_waves", nw)
         o = torch.zeros((B * S, H * D), dtype=torch.float16, device="cuda")
         run(qkv, o, B, H, HKV, S, D, sp)

@@ -518,27 +518,25 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
 #endif
-    // hd 128: the one-wave-per-SIMD kernel (attention_w4.hip; +5 % over the 8-wave software-pipelined kernel in same-call alternation,
-    // profiles/r05_attention_w4.md) at EVERY size - not only where 256-query blocks fill the chip: a captured graph runs the padded prompt bucket and the
-    // eager forward the exact length, and the two must pick the same arithmetic (the two kernels agree to the last bit in bf16 and in all but ~3e-5 of
-    // the fp16 elements, where they round a tie apart: tests/test_gpu_graphs.py holds replay == eager bit for bit).  attn_sp = 4 pins the 8-wave kernel (cross-check), 2 the per-tile kernel; 5 / 6 / 7 / 100+ are research forms
-    // of the w4 kernel (profiling library).
+    // hd 128: attn_sp = 4 selects the one-wave-per-SIMD kernel (attention_w4.hip) - +4.9 % over the 8-wave software-pipelined kernel when the two
+    // alternate in isolation, but 3.7 % SLOWER inside the step (2.49 against 2.40 ms per launch, step 635.1 against 630.9 ms in same-call alternation of
+    // bench.py, gpurun_out/r05_step_ab): the default stays the 8-wave kernel.  5 / 6 / 7 / 100+ are research forms of the w4 kernel (profiling library).
     {
         const int sp = tuning().attn_sp;
         const bool w4_research = VITG_PROFILING_BUILD && (sp == 5 || sp == 6 || sp == 7 || sp >= 100);
-        if (tr && head_dim == 128 && !a.ablate && (sp == 0 || w4_research)) {
-            rc = attention_w4_dispatch(a, batch, heads, dtype, sp, s);
+        if (tr && head_dim == 128 && !a.ablate && (sp == 4 || w4_research)) {
+            rc = attention_w4_dispatch(a, batch, heads, dtype, sp == 4 ? 0 : sp, s);
             return rc == 0 ? 0 : VITG_ERR_LAUNCH;
         }
     }
 #define GO(T, D) (!tr ? launch_attn<T, D, false, 4>(a, batch, heads, s) : nw == 4 ? launch_attn<T, D, true, 4>(a, batch, heads, s) : launch_attn<T, D, true, 8>(a, batch, heads, s))
 #if !VITG_PROFILING_BUILD
     // PRODUCT library: the measured defaults plus ONE cross-check set (attn_sp = 2 / attn_ab = 2: the per-tile kernels of this file).
-    //   hd 128 -> one-wave-per-SIMD kernel (attention_w4.hip);
+    //   hd 128 -> software-pipelined 8-wave loop (attention_sp.hip; 1023 vs 916 TF/s on the LLM shape against the per-tile loop);
     //   hd 72  -> half-tile-out-of-phase kernel (attention_ab.hip) when 256-query blocks fill the chip, else the per-tile loop with LDS-DMA staging.
     // The variants that lost their A/B (hd-72 cross-tile pipelined loop, hd-72 software-pipelined loop, DMA staging at hd 128, 16-wave blocks, PV on
     // 32x32x16, VALU row sums, hd-128 PV on 16x16x32) are instantiated in the profiling library only.
-    if (tr && head_dim == 128 && (tuning().attn_sp == 0 || tuning().attn_sp == 4)) {
+    if (tr && head_dim == 128 && tuning().attn_sp == 0) {
         rc = attention_sp_dispatch(a, batch, heads, head_dim, dtype, nw, false, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
@@ -557,7 +555,7 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     // equal to the plain loop (549 vs 555 TF/s, profiles/r01_attention.md), so it is opt-in: attn_pipe = 1
     // Software-pipelined loop (attention_sp.hip): default for hd 128 (LLM shape 1023 vs 916 TF/s); for hd 72 the per-tile
     // kernel at 4 waves/SIMD is still ahead (630 vs 597 TF/s), profiles/r01_attention.md.  attn_sp = 1 / 2 pins it on / off.
-    if (tr && (tuning().attn_sp == 1 || ((tuning().attn_sp == 0 || tuning().attn_sp == 3 || tuning().attn_sp == 4) && head_dim == 128 && !a.ablate))) {
+    if (tr && (tuning().attn_sp == 1 || ((tuning().attn_sp == 0 || tuning().attn_sp == 3) && head_dim == 128 && !a.ablate))) {
         rc = attention_sp_dispatch(a, batch, heads, head_dim, dtype, nw, tuning().attn_sp == 3, s);
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }

@@ -20,7 +20,11 @@
 
 namespace vitg {
 
-constexpr float W4_LAZY_RESCALE_LOG2 = 8.0f;
+// Lazy rescale threshold: the running max moves only when some query of the block saw it grow by more than 2^12 (the 8-wave kernel: 2^8).  P <= 2^12 is
+// exact in real arithmetic and well inside fp16 / bf16 range; the rescale is the one thing this kernel does much worse than the 8-wave one (O lives in the
+// accumulator file: read, multiply, write back = 384 instructions per query block with nobody else on the SIMD), and on peaky scores it fired often
+// enough to turn +5 % into -9 % (tools/r05/attn_data_dep.py).
+constexpr float W4_LAZY_RESCALE_LOG2 = 12.0f;
 
 // The MFMAs are inline assembly so that their register FILES are this file's choice: with 512 registers per wave hipcc selects the
 // accumulator-file form for every MFMA builtin, i.e. the score tiles would land in AGPRs and be copied out for the softmax (64

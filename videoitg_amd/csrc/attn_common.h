@@ -34,8 +34,12 @@ __device__ __forceinline__ void adopt_device_key_count(AttnArgs& a) {
 #endif
 __device__ __forceinline__ void lds_dma16(const char* base_uniform, unsigned off, char* lds_dst_uniform) {
 #if VITG_ASM_DMA
+    // both are wave-uniform by contract; readfirstlane makes that provable where the value travelled through a lane-dependent-looking path (free otherwise)
+    const unsigned ldsu = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst_uniform);
+    const uintptr_t pb = (uintptr_t)base_uniform;
+    const char* bu = (const char*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pb >> 32)) << 32) | (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pb));      // (unsigned): the builtin returns int
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :: "s"((unsigned)(uintptr_t)lds_dst_uniform), "v"(off), "s"(base_uniform) : "memory");
+                 :: "s"(ldsu), "v"(off), "s"(bu) : "memory");
 #else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_uniform + off),
                                      (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
