@@ -111,7 +111,44 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         dv_off[i] = dma_src(wave_u + NW * i, V_CPR, a.v_rs, false, ATT_BK - 1);
         dv_pad[i] = LSUM && ((wave_u + NW * i) * 64 + lane) % V_CPR >= C::CH;
     }
+#ifndef VITG_AB_BUF_DMA
+#define VITG_AB_BUF_DMA 1      // inside the step: 2.957 -> 2.932 ms per launch (+0.9 %), three alternations (gpurun_out/r05_abbuf); the kernel is VALU-bound
+#endif
+    // VITG_AB_BUF_DMA: staging through buffer descriptors whose extent ends with the last key row (attn_common.h: lds_dma16_buf; rows past it read as
+    // zeros) - no row clamp, no tail branch: three instructions per piece where the clamped global form took ~15
+    constexpr bool BUF_DMA = VITG_AB_BUF_DMA && VITG_ASM_DMA;
+    u32x4 k_rsrc = {}, v_rsrc = {};
+    int dk_offb[K_PW], dv_offb[V_PW];
+    unsigned lds_w = 0;
+    int k_tile_bytes = 0, v_tile_bytes = 0;
+    if constexpr (BUF_DMA) {
+        k_rsrc = lds_dma_rsrc(K, ((long)(a.Sk - 1) * a.k_rs + D) * 2);
+        v_rsrc = lds_dma_rsrc(V, ((long)(a.Sk - 1) * a.v_rs + D) * 2);
+        auto src = [&](int ii, int cpr, int rs, bool is_k) -> int {
+            const int j = ii * 64 + lane;
+            const int row = j / cpr;
+            int c = j % cpr;
+            if (D == 128) c = is_k ? (c ^ (row & 15)) : (c ^ ((row & 3) << 2));
+            else c = min(c, C::CH - 1);
+            return (row * rs + c * 8) * 2;
+        };
+#pragma unroll
+        for (int i = 0; i < K_PW; ++i) dk_offb[i] = src(wave_u + NW * i, K_CPR, a.k_rs, true);
+#pragma unroll
+        for (int i = 0; i < V_PW; ++i) dv_offb[i] = src(wave_u + NW * i, V_CPR, a.v_rs, false);
+        lds_w = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem) + wave_u * 1024u;
+        k_tile_bytes = ATT_BK * a.k_rs * 2;
+        v_tile_bytes = ATT_BK * a.v_rs * 2;
+    }
     auto issue_k = [&](int kt, int buf) {
+        if constexpr (BUF_DMA) {
+#pragma unroll
+            for (int i = 0; i < K_PW; ++i)
+                if (wave_u + NW * i < K_CPR) {
+                    if (!dk_pad[i]) lds_dma16_buf(k_rsrc, lds_w + buf * KT_BYTES + NW * i * 1024, dk_offb[i] + kt * k_tile_bytes);
+                }
+            return;
+        }
         char* kb = smem + buf * KT_BYTES;
         const char* Kt = (const char*)(K + (long)kt * ATT_BK * a.k_rs);
         const bool tail = kt * ATT_BK + ATT_BK > a.Sk;          // wave-uniform: clamp rows past the last key
@@ -126,6 +163,14 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         }
     };
     auto issue_v = [&](int kt, int buf) {
+        if constexpr (BUF_DMA) {
+#pragma unroll
+            for (int i = 0; i < V_PW; ++i)
+                if (wave_u + NW * i < V_CPR) {
+                    if (!dv_pad[i]) lds_dma16_buf(v_rsrc, lds_w + V_BASE + buf * VT_BYTES + NW * i * 1024, dv_offb[i] + kt * v_tile_bytes);
+                }
+            return;
+        }
         char* vb = smem + V_BASE + buf * VT_BYTES;
         const char* Vt = (const char*)(V + (long)kt * ATT_BK * a.v_rs);
         const bool tail = kt * ATT_BK + ATT_BK > a.Sk;

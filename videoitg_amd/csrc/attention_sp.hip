@@ -102,7 +102,41 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
     for (int i = 0; i < K_PW; ++i) dk_off[i] = dma_src(wave_u + NW * i, K_CPR, a.k_rs, true, ATT_BK - 1);
 #pragma unroll
     for (int i = 0; i < V_PW; ++i) dv_off[i] = dma_src(wave_u + NW * i, V_CPR, a.v_rs, false, ATT_BK - 1);
+#ifndef VITG_SP_BUF_DMA
+#define VITG_SP_BUF_DMA 1      // inside the step: 2.404 -> 2.298 ms per launch (+4.6 %), step 631.1 -> 628.3 ms, three alternations (gpurun_out/r05_spbuf)
+#endif
+    // hd 128, VITG_SP_BUF_DMA: staging through buffer descriptors whose extent ends with the last key row (attn_common.h: lds_dma16_buf) - no row clamp, no
+    // tail branch, three instructions per piece at the head of the interval instead of ~15 (the one-wave-per-SIMD kernel's staging, csrc/attention_w4.hip)
+    constexpr bool BUF_DMA = VITG_SP_BUF_DMA && VITG_ASM_DMA && D == 128;
+    u32x4 k_rsrc = {}, v_rsrc = {};
+    int dk_offb[K_PW], dv_offb[V_PW];
+    unsigned lds_w = 0;
+    int k_tile_bytes = 0, v_tile_bytes = 0;
+    if constexpr (BUF_DMA) {
+        k_rsrc = lds_dma_rsrc(K, ((long)(a.Sk - 1) * a.k_rs + D) * 2);
+        v_rsrc = lds_dma_rsrc(V, ((long)(a.Sk - 1) * a.v_rs + D) * 2);
+        auto src = [&](int ii, int cpr, int rs, bool is_k) -> int {
+            const int j = ii * 64 + lane;
+            const int row = j / cpr;
+            int c = j % cpr;
+            c = is_k ? (c ^ (row & 15)) : (c ^ ((row & 3) << 2) ^ (PV16 ? (((row >> 2) & 1) << 1) : 0));
+            return (row * rs + c * 8) * 2;
+        };
+#pragma unroll
+        for (int i = 0; i < K_PW; ++i) dk_offb[i] = src(wave_u + NW * i, K_CPR, a.k_rs, true);
+#pragma unroll
+        for (int i = 0; i < V_PW; ++i) dv_offb[i] = src(wave_u + NW * i, V_CPR, a.v_rs, false);
+        lds_w = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem) + wave_u * 1024u;
+        k_tile_bytes = ATT_BK * a.k_rs * 2;
+        v_tile_bytes = ATT_BK * a.v_rs * 2;
+    }
     auto issue_k = [&](int kt, int buf) {
+        if constexpr (BUF_DMA) {
+#pragma unroll
+            for (int i = 0; i < K_PW; ++i)
+                if (wave_u + NW * i < K_CPR) lds_dma16_buf(k_rsrc, lds_w + buf * KT_BYTES + NW * i * 1024, dk_offb[i] + kt * k_tile_bytes);
+            return;
+        }
         char* kb = smem + buf * KT_BYTES;
         const char* Kt = (const char*)(K + (long)kt * ATT_BK * a.k_rs);
         const bool tail = kt * ATT_BK + ATT_BK > a.Sk;          // wave-uniform: clamp rows past the last key
@@ -116,6 +150,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_sp_kernel(AttnArgs a) {
         }
     };
     auto issue_v = [&](int kt, int buf) {
+        if constexpr (BUF_DMA) {
+#pragma unroll
+            for (int i = 0; i < V_PW; ++i)
+                if (wave_u + NW * i < V_CPR) lds_dma16_buf(v_rsrc, lds_w + V_BASE + buf * VT_BYTES + NW * i * 1024, dv_offb[i] + kt * v_tile_bytes);
+            return;
+        }
         char* vb = smem + V_BASE + buf * VT_BYTES;
         const char* Vt = (const char*)(V + (long)kt * ATT_BK * a.v_rs);
         const bool tail = kt * ATT_BK + ATT_BK > a.Sk;

@@ -45,6 +45,20 @@ __device__ __forceinline__ void lds_dma16(const char* base_uniform, unsigned off
                                      (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
 #endif
 }
+// The same piece through a BUFFER descriptor (base, extent in bytes): offsets at or past the extent read as zeros in hardware, so a staging stream needs
+// neither row clamps nor a tail branch.  The range check covers the VGPR offset (and the immediate), NOT soffset: the whole offset rides in `off`.
+__device__ __forceinline__ u32x4 lds_dma_rsrc(const void* base_uniform, long bytes) {
+    const uintptr_t pb = (uintptr_t)base_uniform;
+    u32x4 r;
+    r[0] = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pb);
+    r[1] = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pb >> 32)) & 0xffffu;
+    r[2] = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void lds_dma16_buf(const u32x4& rsrc, unsigned lds_dst_uniform, int off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst_uniform), "v"(off), "s"(rsrc) : "memory");
+}
 __device__ __forceinline__ void lds_dma_drain() {
 #if VITG_ASM_DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
