@@ -194,7 +194,9 @@ int vitg_rope(void* qkv, int ld, const float* cos_t, const float* sin_t, long N,
               void* stream);
 
 /* Non-causal softmax(QK^T * scale) V, fp32 softmax, GQA (heads % kv_heads == 0), head_dim 72 or 128.
- * S queries attend to Sk keys (Sk == S on one GPU; Sk = all-gathered keys in the context-parallel LLM).
+ * S queries attend to Sk keys (Sk == S on one GPU; Sk = all-gathered keys in the context-parallel LLM).  One (batch, kv head) slice of K / V must end
+ * below 4 GiB - ((Sk - 1) * row stride + head_dim) * 2 bytes < 2^32, else VITG_ERR_SHAPE: the kernels stage it through 32-bit buffer descriptors, whose
+ * range check turns the rows past the last key into zeros.
  * Strides in elements: *_bs batch, *_rs token row, *_hs head.  variant bit 0 = cross-check path that reads V from LDS with scalar
  * loads instead of ds_read_b64_tr_b16; variant bit 1 (value 2) = q already holds Q * scale * log2(e) (the producing projection carries the
  * factor in its q rows - what the engine does for the SigLIP tower): scores are exponentiated in base 2 with no further scaling, which lets

@@ -470,6 +470,8 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     if ((q_rs | k_rs | v_rs | o_rs | q_hs | k_hs | v_hs | o_hs) % 4) return VITG_ERR_ALIGN;
     if ((q_rs | k_rs | v_rs | q_hs | k_hs | v_hs) % 8 || (q_bs | k_bs | v_bs) % 8) return VITG_ERR_ALIGN;
     if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
+    // the shipped kernels stage K / V through 32-bit buffer descriptors (csrc/attn_common.h: lds_dma_rsrc): one (batch, kv head) slice must end below 4 GiB
+    if ((((long)(Sk - 1) * (k_rs > v_rs ? k_rs : v_rs) + head_dim) * 2) >= (1L << 32)) return VITG_ERR_SHAPE;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.o = o;
     a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
