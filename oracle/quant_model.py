@@ -35,18 +35,21 @@ from . import videoitg_oracle as O
 
 
 class Q:
-    def __init__(self, dtype: Optional[torch.dtype], mode: str, fp8_mx: bool = True):
+    def __init__(self, dtype: Optional[torch.dtype], mode: str, fp8_mx: bool = True, exact=()):
         self.dtype, self.mode, self.fp8_mx = dtype, mode, fp8_mx
+        # rounding sites carried at (hi + lo) split precision instead of one 16-bit value: modelled as exact (22 of fp32's 24 bits).
+        # names: norm1 norm2 qkv p attn_out act pool proj (tools/split_site_model.py; the product's `operand_split` tier)
+        self.exact = frozenset(exact)
 
-    def mm(self, t):       # MFMA-input rounding (both modes)
-        return t if self.dtype is None else t.to(self.dtype).float()
+    def mm(self, t, site=None):       # MFMA-input rounding (both modes)
+        return t if (self.dtype is None or site in self.exact) else t.to(self.dtype).float()
 
     def every(self, t):    # op-output rounding (reference16 only)
         return self.mm(t) if self.mode == "reference16" else t
 
     # ---- fp8 weight path: operands of the layer GEMMs -------------------------------------------------------------------
-    def a_norm(self, t):   # a norm output as GEMM operand
-        return q8_rows(t) if self.mode == "fp8" else self.mm(t)
+    def a_norm(self, t, site=None):   # a norm output as GEMM operand
+        return q8_rows(t) if self.mode == "fp8" else self.mm(t, site)
 
     def a_act(self, t):    # an already 16-bit-rounded activation as GEMM operand
         return q8_rows(t) if self.mode == "fp8" else t
@@ -54,12 +57,12 @@ class Q:
     def a_gelu(self, t):   # the tower's GELU output (fp32 in) as fc2's operand
         if self.mode == "fp8":
             return q8_mx_rows(t) if self.fp8_mx else q8_rows(self.mm(t))
-        return self.mm(t)
+        return self.mm(t, "act")
 
     def a_swiglu(self, t):  # the decoder's silu(gate) * up (fp32 in) as down's operand
         if self.mode == "fp8":
             return q8_mx_rows(t) if self.fp8_mx else q8_rows(self.mm(t))
-        return self.mm(t)
+        return self.mm(t, "act")
 
     def w(self, t):        # a layer GEMM weight (rows = output channels)
         return q8_rows(t) if self.mode == "fp8" else t
@@ -103,15 +106,15 @@ def _attn(q, k, v, scale, qz: Q, q_chunk=1024):
         m = sc.max(-1, keepdim=True).values
         p = torch.exp(sc - m)
         l = p.sum(-1, keepdim=True)                         # fp32 row sum of the unrounded p (as the kernel does)
-        out[:, :, s:s + q_chunk] = torch.matmul(qz.mm(p), v) / l
+        out[:, :, s:s + q_chunk] = torch.matmul(qz.mm(p, "p"), v) / l
     return out
 
 
 def forward(cfg, sd, vsd, input_ids, attention_mask, images: Sequence[torch.Tensor], dtype=torch.float16,
-            mode: str = "product", fp8_mx: bool = True, frame_chunk: Optional[int] = None):
+            mode: str = "product", fp8_mx: bool = True, frame_chunk: Optional[int] = None, exact=()):
     """frame_chunk: run the tower on that many frames at a time (frames are independent; a 512-frame video's attention scores alone
     would be 34 GB in one piece) - same values, bounded memory (tools/heavy_tail_rounding_model.py at the headline size)"""
-    qz = Q(dtype, mode, fp8_mx)
+    qz = Q(dtype, mode, fp8_mx, exact)
     v = cfg.vision
     images = [im if im.dim() == 4 else im.unsqueeze(0) for im in images]
     pix = qz.mm(torch.cat(list(images), 0).float())
@@ -134,12 +137,12 @@ def _tower(cfg, vsd, pix, qz: Q):
     n_run = v.num_hidden_layers + 1 + cfg.mm_vision_select_layer
     for i in range(n_run):
         p = f"vision_model.encoder.layers.{i}."
-        h = qz.a_norm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm1.weight"], vsd[p + "layer_norm1.bias"], v.layer_norm_eps))
-        q, k, vv = (qz.mm(F.linear(h, qz.w(vsd[p + f"self_attn.{n}_proj.weight"]), vsd[p + f"self_attn.{n}_proj.bias"]))
+        h = qz.a_norm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm1.weight"], vsd[p + "layer_norm1.bias"], v.layer_norm_eps), "norm1")
+        q, k, vv = (qz.mm(F.linear(h, qz.w(vsd[p + f"self_attn.{n}_proj.weight"]), vsd[p + f"self_attn.{n}_proj.bias"]), "qkv")
                     .view(T, -1, H, hd).transpose(1, 2) for n in "qkv")
-        o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz)).transpose(1, 2).reshape(T, -1, Dv)
+        o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz), "attn_out").transpose(1, 2).reshape(T, -1, Dv)
         x = qz.every(x + qz.every(F.linear(qz.a_act(o), qz.w(vsd[p + "self_attn.out_proj.weight"]), vsd[p + "self_attn.out_proj.bias"])))
-        h = qz.a_norm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm2.weight"], vsd[p + "layer_norm2.bias"], v.layer_norm_eps))
+        h = qz.a_norm(F.layer_norm(x, (Dv,), vsd[p + "layer_norm2.weight"], vsd[p + "layer_norm2.bias"], v.layer_norm_eps), "norm2")
         f = qz.a_gelu(O.gelu_tanh(qz.every(F.linear(h, qz.w(vsd[p + "mlp.fc1.weight"]), vsd[p + "mlp.fc1.bias"]))))
         x = qz.every(x + qz.every(F.linear(f, qz.w(vsd[p + "mlp.fc2.weight"]), vsd[p + "mlp.fc2.bias"])))
     return x
@@ -152,8 +155,8 @@ def _after_tower(cfg, sd, x, input_ids, attention_mask, images, qz: Q, mode: str
     visual = []
     for f in feats:
         hw = O.pooled_grid(f.shape[0], int(f.shape[1] ** 0.5), cfg.vision_token_num)
-        pl = qz.mm(O.bilinear_pool(f, hw))
-        g = qz.mm(F.gelu(qz.every(F.linear(pl, sd[pre + "0.weight"], sd[pre + "0.bias"]))))
+        pl = qz.mm(O.bilinear_pool(f, hw), "pool")
+        g = qz.mm(F.gelu(qz.every(F.linear(pl, sd[pre + "0.weight"], sd[pre + "0.bias"]))), "proj")
         visual.append(qz.every(F.linear(g, sd[pre + "2.weight"], sd[pre + "2.bias"])).flatten(0, 1))
     xs, mask, tts = O.splice(input_ids, attention_mask, visual, sd, max_length=cfg.tokenizer_model_max_length,
                              padding_side=cfg.tokenizer_padding_side)
@@ -170,15 +173,15 @@ def _after_tower(cfg, sd, x, input_ids, attention_mask, images, qz: Q, mode: str
             cos, sin = qz.mm(cos), qz.mm(sin)            # HF casts the tables to the activation dtype
         for i in range(cfg.num_hidden_layers):
             p = f"model.layers.{i}."
-            h = qz.a_norm(O.rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps))
-            q = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.q_proj.weight"]), sd[p + "self_attn.q_proj.bias"])).view(1, N, nq, hd).transpose(1, 2)
-            k = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.k_proj.weight"]), sd[p + "self_attn.k_proj.bias"])).view(1, N, nkv, hd).transpose(1, 2)
-            vv = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.v_proj.weight"]), sd[p + "self_attn.v_proj.bias"])).view(1, N, nkv, hd).transpose(1, 2)
-            q = qz.mm(q * cos + O.rotate_half(q) * sin)
-            k = qz.mm(k * cos + O.rotate_half(k) * sin)
-            o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz)).transpose(1, 2).reshape(1, N, D)
+            h = qz.a_norm(O.rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps), "norm1")
+            q = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.q_proj.weight"]), sd[p + "self_attn.q_proj.bias"]), "qkv").view(1, N, nq, hd).transpose(1, 2)
+            k = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.k_proj.weight"]), sd[p + "self_attn.k_proj.bias"]), "qkv").view(1, N, nkv, hd).transpose(1, 2)
+            vv = qz.mm(F.linear(h, qz.w(sd[p + "self_attn.v_proj.weight"]), sd[p + "self_attn.v_proj.bias"]), "qkv").view(1, N, nkv, hd).transpose(1, 2)
+            q = qz.mm(q * cos + O.rotate_half(q) * sin, "qkv")
+            k = qz.mm(k * cos + O.rotate_half(k) * sin, "qkv")
+            o = qz.mm(_attn(q, k, vv, hd ** -0.5, qz), "attn_out").transpose(1, 2).reshape(1, N, D)
             x = qz.every(x + qz.every(F.linear(qz.a_act(o), qz.w(sd[p + "self_attn.o_proj.weight"]))))
-            h = qz.a_norm(O.rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
+            h = qz.a_norm(O.rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps), "norm2")
             g = qz.every(F.linear(h, qz.w(sd[p + "mlp.gate_proj.weight"])))
             u = qz.every(F.linear(h, qz.w(sd[p + "mlp.up_proj.weight"])))
             f = qz.a_swiglu(qz.every(F.silu(g)) * u)

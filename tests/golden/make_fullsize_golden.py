@@ -45,6 +45,9 @@ CASES = {
     # DECIDABLE for the lower-precision tiers (SURVEY.md section 7 hard part 2 iii).  c2p = the bench workload's size
     "c2p_512x448": (512, 448, 60, 0, 1234, 32),
     "depth16p_224": (16, 224, 60, 0, 1234, 4),
+    # round 6: planted twins of the reference-native shape and of the decoder-heavy 64-frame video
+    "b0p_512x384": (512, 384, 60, 0, 1234, 32),
+    "c1p_64x384": (64, 384, 60, 0, 1234, 32),
 }
 # heavy-tailed weights (videoitg_amd.synth.HeavyTailPlan: outlier channels planted through fc2 / down rows, biases and norm gains the
 # way trained towers carry them).  Same sizes, inputs and base draw as the case without the "o".

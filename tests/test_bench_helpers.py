@@ -175,3 +175,36 @@ def test_hwmon_sampler_is_silent_without_a_gpu():
         s.start(); time.sleep(0.2)
         r = s.stop()
         assert r is None or (r["power_w"] > 0 and r["samples"] >= 1)
+
+
+def test_printed_line_stays_under_four_kilobytes(tmp_path, monkeypatch, capsys):
+    """r05's 21 KB line came back from the driver as `parsed: null`.  The printed line is the contract keys + roofline + cpu_baseline +
+    parity, every string bounded, < 4096 bytes whatever the run measured; everything else goes to bench_full.json, which the line names."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_v6b_fp16_driver_style.json")))      # a real 21 KB record of the default run
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full, "bench_full.json")
+    blob = json.dumps(line)
+    assert len(blob) < bench.LINE_LIMIT == 4096
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("512 frames x 448^2") and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > r["traffic_algorithmic"] > 0
+    assert r["launches"] and r["avg_launch_ms"] and "gemm16_kernel" in r["kernel"] and r["power_clock"]["sclk_ghz"]
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 32 and c["unit"] == "frames/s" and 0 < len(c["sample"]) <= 200
+    assert line["parity"]["pass"] is True and line["parity"]["top32_set_match"] is True and line["parity"]["max_abs_dscore"] < 1e-3
+    assert line["speedup_vs_cpu_baseline"] > 50 and line["full_record"] == "bench_full.json"
+    assert set(line["roofline_other"]) >= {"attention_hd72", "attention_hd128", "layernorm"}
+    # strings a future run could blow up are clipped, and an oversized extra block is dropped rather than breaking the contract
+    fat = dict(full, data="x" * 5000, config=dict(full["config"], workload="w" * 5000))
+    fat["cpu_baseline"] = dict(full["cpu_baseline"], sample="s" * 9000, sample_short=None)
+    fat["secondary"] = {f"tier_{i:03d}_with_a_long_name": {"value": 1.0 * i} for i in range(200)}
+    thin = bench.compact_line(fat, "bench_full.json")
+    assert len(json.dumps(thin)) < 4096 and "secondary_frames_per_s" not in thin and "roofline" in thin and "cpu_baseline" in thin
+    # emit(): full record on disk, ONE line on stdout
+    monkeypatch.setenv("VITG_BENCH_FULL", str(tmp_path / "full.json"))
+    bench.emit(full)
+    out = capsys.readouterr().out
+    assert out.count("\n") == 1 and len(out) < 4097
+    assert json.loads(out)["value"] == full["value"] and json.load(open(tmp_path / "full.json"))["secondary"].keys() == full["secondary"].keys()

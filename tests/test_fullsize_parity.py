@@ -18,9 +18,15 @@ import torch
 
 SCORE_TOL = 1e-3
 TOL = {torch.float16: SCORE_TOL, torch.bfloat16: 2.5e-3}
+# Top-K identity: asserted whenever the oracle's own rank-K / K+1 gap exceeds twice the path's error CEILING on this fixture class -
+# a stated number per dtype (fp16 on the benign N(0, 1/fan_in) draws: 4e-4, the worst ever measured is 3.4e-4), itself asserted below, or this run's
+# measured max error if that is larger.  With 2 x 1e-3 as the threshold (rounds 2-5) the reference-native 512 x 384^2 video (gap 1.35e-3) and the
+# headline video (1.56e-3) never had their Top-32 set checked here.
+CEIL = {torch.float16: 4e-4, torch.bfloat16: 2.5e-3}
 CASES = ["depth16_224", "depth16_224_s1", "depth24_280_s2", "c1_64x384", "b0_512x384", "c2_512x448",
          # planted per-frame signal (synth.planted_inputs): the oracle's Top-k is the planted set behind a wide gap
-         "depth16p_224", "c2p_512x448"]
+         "depth16p_224", "c2p_512x448", "b0p_512x384", "c1p_64x384"]
+MUST_MATCH_TOPK_FP16 = {"b0_512x384", "c2_512x448", "c1_64x384", "c2p_512x448", "b0p_512x384", "c1p_64x384", "depth16p_224"}
 # heavy-tailed weights (synth.HeavyTailPlan): planted channels 10^2 - 10^3 in both residual streams.  Their own test and their own
 # STATED bounds below: with massive-activation channels every 16-bit-operand implementation - the reference's own model.half() arithmetic included -
 # sits above north_star's 1e-3 at the headline size (profiles/r05_heavy_tail.md: the norm statistics are dominated by the planted channels, so their
@@ -108,8 +114,13 @@ def test_full_depth_matches_oracle(golden_dir, name, dtype):
           f"(oracle rank-{rec['k']}/{rec['k'] + 1} gap {gap})")
     tol = TOL[dtype]
     assert ds <= tol, (name, dtype, ds)
-    # the Top-K SET is decidable only if the oracle's own rank-K/K+1 gap exceeds twice the score tolerance
-    if gap is None or gap > 2 * tol:
+    if dtype == torch.float16:
+        assert ds <= CEIL[dtype], (name, ds)             # the stated ceiling of the headline dtype on benign draws (Top-K decidability rests on it)
+    # the Top-K SET cannot have changed by rounding alone if the oracle's own rank-K/K+1 gap exceeds twice the path's error
+    if gap is None or gap > 2 * max(ds, CEIL[dtype]):
+        assert same_topk, (name, dtype)
+    if dtype == torch.float16 and name in MUST_MATCH_TOPK_FP16:
+        assert gap is None or gap > 2 * CEIL[dtype], (name, gap)      # these fixtures ARE decidable: the branch above ran
         assert same_topk, (name, dtype)
     # every pair of frames the oracle separates by more than 2 x tol must be ordered the same way
     want = torch.sigmoid(torch.tensor(rec["logits"]))

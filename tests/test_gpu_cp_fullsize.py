@@ -58,7 +58,9 @@ def test_context_parallel_full_size_meets_oracle(world, case):
     gap = rec["gap_k_k1"]
     # the headline video: Top-32 set identical (holds because the error is 3e-4 against a rank-32/33 gap of 1.56e-3); the other
     # fixtures: identical wherever the oracle's own rank-K / K+1 gap exceeds twice the tolerance, else at most one frame swapped at the boundary
-    if case == CASE or gap is None or gap > 2 * SCORE_TOL:
+    # round 6: decidable = gap above twice the fp16 path's stated error ceiling on benign draws (4e-4, tests/test_fullsize_parity.py
+    # CEIL) or this run's own error - so the reference-native 512 x 384^2 video (gap 1.35e-3) has its Top-32 set asserted at 8 ranks too
+    if case == CASE or gap is None or gap > 2 * max(4e-4, rep["max_abs_dscore_vs_oracle"]):
         assert rep[f"top{rec['k']}_set_match"], rep
     else:
         assert rep[f"top{rec['k']}_kept"] >= rec["k"] - 1, rep

@@ -215,3 +215,44 @@ def test_files_that_need_a_codec_still_raise_like_the_reference(tmp_path, no_dec
     open(path, "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="needs a codec"):
         video_io.VideoReader(path)
+
+
+def test_opendml_avix_segments_are_read_not_truncated(tmp_path, no_decoders):
+    """AVIs over 1 GiB are OpenDML files - a 'RIFF AVI ' segment followed by 'RIFF AVIX' segments with their own movi lists.  The
+    reader walks every segment (it used to stop after the first and return a truncated frame list without an error)."""
+    import struct
+    from videoitg_amd import video_io
+    clip = _clip(T=21, h=20, w=24)
+    first, rest = str(tmp_path / "a.avi"), str(tmp_path / "b.avi")
+    video_io.write_avi(first, clip[:9], fps=10.0, codec="DIB ")
+    video_io.write_avi(rest, clip[9:], fps=10.0, codec="DIB ")
+    raw = open(rest, "rb").read()
+    k = raw.index(b"movi") - 8                                   # the second file's LIST 'movi' becomes the body of a continuation segment
+    (lsize,) = struct.unpack_from("<I", raw, k + 4)
+    movi = raw[k:k + 8 + lsize]
+    path = str(tmp_path / "opendml.avi")
+    with open(path, "wb") as f:
+        f.write(open(first, "rb").read() + b"RIFF" + struct.pack("<I", 4 + len(movi)) + b"AVIX" + movi)
+    vr = video_io.VideoReader(path)
+    assert len(vr) == 21
+    assert np.array_equal(vr.get_batch(list(range(21))).asnumpy(), clip)
+
+
+def test_avi_with_a_real_codec_falls_through_to_pyav(tmp_path, fake_av, monkeypatch):
+    """without decord, *.avi goes to the built-in reader, which raises ValueError for a stream that needs a codec; the plugin's
+    loader must then try PyAV like the reference's bare `except:` does (lmms_eval/models/videoitg.py:95-130) - and, with PyAV absent too, raise the
+    first reader's error, not a misleading ImportError about `av`."""
+    from videoitg_amd import video_io
+    from videoitg_amd.lmms_plugin.models import videoitg as plug
+    monkeypatch.setitem(sys.modules, "decord", None)
+    path = str(tmp_path / "h264.avi")
+    video_io.write_avi(path, _clip(T=3), codec="DIB ")
+    raw = bytearray(open(path, "rb").read())
+    k = raw.index(b"strf") + 8 + 16
+    raw[k:k + 4] = b"H264"
+    open(path, "wb").write(bytes(raw))
+    imgs, idx = plug.load_video(path, num_frames=8, target_fps=1)          # PyAV (the fake: 900 frames at 30 fps) got its chance
+    assert list(idx) == mm_utils.get_seq_frames(900, 30.0, 1, 8) and len(imgs) == 8 and fake_av.opened[-1].closed
+    monkeypatch.setitem(sys.modules, "av", None)
+    with pytest.raises(ValueError, match="needs a codec"):
+        plug.load_video(path, num_frames=8, target_fps=1)

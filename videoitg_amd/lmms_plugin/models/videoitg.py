@@ -41,28 +41,35 @@ except Exception:                      # pragma: no cover
 
 
 def load_video(video_path: str, num_frames: int = 64, target_fps: float = 1):
-    """videoitg.py:95-130: decord first, PyAV fallback; returns (list of PIL images, sampled frame ids)."""
+    """videoitg.py:95-130: decord first, PyAV fallback on ANY failure of the first reader (the reference's bare `except:` - an AVI that carries a
+    real codec makes the built-in reader raise ValueError, a broken file makes decord raise DECORDError; PyAV gets its chance either way);
+    returns (list of PIL images, sampled frame ids).  If PyAV is not installed either, the FIRST reader's error is the one raised."""
     from PIL import Image
+    first_error = None
     try:
         from ...mm_utils import open_video_reader                # decord; without it, the built-in reader for .avi (MJPEG) / .y4m
         vr = open_video_reader(video_path, num_threads=1)
         idx = get_seq_frames(int(len(vr)), vr.get_avg_fps(), target_fps, num_frames)
         frames = vr.get_batch(idx).asnumpy()
         return [Image.fromarray(f) for f in frames], idx
-    except ImportError:
+    except Exception as e:                                        # noqa: BLE001 - as the reference: whatever the first reader raised
+        first_error = e
+    try:
         import av
-        container = av.open(video_path)
-        stream = container.streams.video[0]
-        fps = float(stream.average_rate)
-        total = stream.frames
-        if not total or "webm" in video_path or "mkv" in video_path:
-            total = sum(1 for p in container.demux(video=0) for _ in p.decode())
-            container.seek(0)
-        idx = get_seq_frames(int(total), fps, target_fps, num_frames)
-        want = set(idx)
-        frames = [fr.to_ndarray(format="rgb24") for i, fr in enumerate(container.decode(video=0)) if i in want]
-        container.close()
-        return [Image.fromarray(f) for f in frames], idx
+    except ImportError:
+        raise first_error
+    container = av.open(video_path)
+    stream = container.streams.video[0]
+    fps = float(stream.average_rate)
+    total = stream.frames
+    if not total or "webm" in video_path or "mkv" in video_path:
+        total = sum(1 for p in container.demux(video=0) for _ in p.decode())
+        container.seek(0)
+    idx = get_seq_frames(int(total), fps, target_fps, num_frames)
+    want = set(idx)
+    frames = [fr.to_ndarray(format="rgb24") for i, fr in enumerate(container.decode(video=0)) if i in want]
+    container.close()
+    return [Image.fromarray(f) for f in frames], idx
 
 
 @register_model("videoitg")

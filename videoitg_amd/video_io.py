@@ -41,7 +41,8 @@ def _chunks(buf: memoryview, start: int, end: int):
 
 
 class _AviIndex:
-    """frame table of an AVI 1.0 file: offsets / sizes of the video stream's chunks inside LIST 'movi' (file order = frame order)"""
+    """frame table of an AVI file (AVI 1.0, or OpenDML with 'RIFF AVIX' continuation segments): offsets / sizes of the video stream's chunks inside
+    the LIST 'movi' of every segment (file order = frame order)"""
 
     def __init__(self, data: bytes):
         buf = memoryview(data)
@@ -53,9 +54,20 @@ class _AviIndex:
         self.handler = self.compression = b""
         self.bit_count = 24
         self.top_down = False
-        vid_stream = None
-        n_streams = 0
-        for cc, off, size in _chunks(buf, 12, len(buf)):
+        st = {"vid_stream": None, "n_streams": 0}
+        # top level: the 'RIFF AVI ' segment, then - in OpenDML files, i.e. anything over 1 GiB - any number of 'RIFF AVIX' segments, each with
+        # its own LIST 'movi' holding the following frames (file order = frame order)
+        for rcc, roff, rsize in _chunks(buf, 0, len(buf)):
+            if rcc != b"RIFF" or bytes(buf[roff:roff + 4]) not in (b"AVI ", b"AVIX"):
+                continue
+            self._segment(buf, roff + 4, min(roff + rsize, len(buf)), st)
+        vid_stream = st["vid_stream"]
+        if vid_stream is None or not self.width:
+            raise ValueError("AVI: no video stream")
+
+    def _segment(self, buf, start, end, st):
+        """one RIFF segment's children: the header list (first segment only) and the movi list(s)"""
+        for cc, off, size in _chunks(buf, start, end):
             if cc != b"LIST":
                 continue
             kind = bytes(buf[off:off + 4])
@@ -67,30 +79,28 @@ class _AviIndex:
                         is_video = False
                         for c3, o3, s3 in _chunks(buf, o2 + 4, o2 + s2):
                             if c3 == b"strh":
-                                is_video = bytes(buf[o3:o3 + 4]) == b"vids" and vid_stream is None
+                                is_video = bytes(buf[o3:o3 + 4]) == b"vids" and st["vid_stream"] is None
                                 if is_video:
                                     self.handler = bytes(buf[o3 + 4:o3 + 8])
                                     self.scale, self.rate = struct.unpack_from("<II", buf, o3 + 20)
-                                    vid_stream = n_streams
+                                    st["vid_stream"] = st["n_streams"]
                             elif c3 == b"strf" and is_video:
                                 w, h, _planes, bits = struct.unpack_from("<iiHH", buf, o3 + 4)
                                 self.compression = bytes(buf[o3 + 16:o3 + 20])
                                 self.width, self.height, self.bit_count = w, abs(h), bits
                                 self.top_down = h < 0
-                        n_streams += 1
+                        st["n_streams"] += 1
             elif kind == b"movi":
-                if vid_stream is None:
+                if st["vid_stream"] is None:
                     raise ValueError("AVI: no video stream header before the movi list")
-                tag = b"%02d" % vid_stream
-                for c2, o2, s2 in _chunks(buf, off + 4, off + size):
+                tag = b"%02d" % st["vid_stream"]
+                for c2, o2, s2 in _chunks(buf, off + 4, min(off + size, end)):
                     if c2[:2] == tag and c2[2:] in (b"dc", b"db"):
                         self.frames.append((o2, s2))
                     elif c2 == b"LIST" and bytes(buf[o2:o2 + 4]) == b"rec ":
                         for c3, o3, s3 in _chunks(buf, o2 + 4, o2 + s2):
                             if c3[:2] == tag and c3[2:] in (b"dc", b"db"):
                                 self.frames.append((o3, s3))
-        if vid_stream is None or not self.width:
-            raise ValueError("AVI: no video stream")
 
     @property
     def fps(self) -> float:
