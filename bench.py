@@ -88,6 +88,8 @@ def compact_line(full: dict, full_path=None) -> dict:
     sec = full.get("secondary")
     if sec:                                        # one number per secondary measurement; their parity blocks / rooflines are in the full record
         line["secondary_frames_per_s"] = {k: v["value"] for k, v in sec.items() if isinstance(v, dict) and isinstance(v.get("value"), (int, float))}
+    if isinstance(full.get("top32"), list):
+        line["top32"] = full["top32"][:32]                # the selected frames (sorted ids of the Top-32): BASELINE.json's "Top-32 index match"
     if full.get("fp8"):
         line["fp8"] = _pick(full["fp8"], ("policy", "gemms_on_fp8"))
     if full_path:

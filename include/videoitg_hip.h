@@ -260,6 +260,32 @@ int vitg_preprocess_tmp_bytes(int T, int H, int W, int S, long* bytes);
 int vitg_preprocess_u8(const void* frames, int T, int H, int W, long frame_stride, int row_stride, void* out, int S,
                        int out_dtype, void* tmp, long tmp_bytes, void* stream);
 
+/* ---- Operand-split precision tier (round 6; videoitg_amd/csrc/split.hip, engine option `operand_split`) ------------------------------
+ * north_star compares with the reference's fp32 CPU path (|dscore| <= 1e-3); the reference's GPU path rounds every activation to fp16
+ * (model.half(), /root/reference/eagle/model/builder.py:59) and so does the default path here.  On weights with massive-activation channels
+ * 11-bit operands miss 1e-3 (profiles/r05_heavy_tail.md), so this tier carries every MFMA operand as a PAIR of fp16 values x = hi + lo
+ * (hi = fp16(x), lo = fp16(x - hi): 22 bits; fp16 x fp16 products are exact in the fp32 accumulator).  A split operand of padded width Dp is one
+ * fp16 matrix [M, >= 2 Dp]: hi in columns [0, Dp), lo in [lo_off, lo_off + Dp), pad columns zero; a GEMM consumes it through vitg_gemm with
+ * K = 2 Dp against the weight laid twice side by side.  fp16 only.
+ *
+ * vitg_norm_split: LayerNorm (b != NULL) / RMSNorm (b == NULL) of fp32 rows -> split rows ([3P] SigLIP layer_norm1/2, Qwen2RMSNorm; the call
+ *   sites vitg_layernorm / vitg_rmsnorm replace).  lo_off = padded payload width (multiple of 4, >= D), ldo >= 2 lo_off.
+ * vitg_rope_split: vitg_rope on split q | k heads, in place (hi + lo is rotated in fp32 and split again).
+ * vitg_bilinear_pool_split: vitg_bilinear_pool (mlp_proj.py:57-68) of dense fp32 features -> split rows.
+ * vitg_gemm_split16: vitg_gemm's 16-bit-output modes (STORE16 with bias / activation, SWIGLU) writing (hi, lo) pairs: out[m, n] and
+ *   out[m, n + lo_off]; N % 8 == 0, lo_off % 8 == 0, lo_off >= output width, ldo >= lo_off + output width.
+ * vitg_attention_split: vitg_attention on split Q / K / V (lo planes at element offsets q_lo / k_lo / v_lo from the hi planes, same strides),
+ *   S = Qh Kh^T + Qh Kl^T + Ql Kh^T, P split after the fp32 softmax, O = (Ph Vh + Ph Vl + Pl Vh) / l written as a split pair (o, o + o_lo).
+ *   Replaces flash-attn at clip_encoder.py:117 / grounding_qwen2.py:45-53 for this tier; head_dim 72 or 128, GQA, non-causal. */
+int vitg_norm_split(const float* x, int ldx, const float* w, const float* b, void* out, int ldo, int lo_off, long M, int D, float eps, void* stream);
+int vitg_rope_split(void* qkv, int ld, long lo_off, const float* cos_t, const float* sin_t, long N, int heads, int head_dim, void* stream);
+int vitg_bilinear_pool_split(const float* x, int ldx, void* out, int ldo, int lo_off, int T, int G, int HW, int D, void* stream);
+int vitg_gemm_split16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int mode, const float* bias, int act, void* out,
+                      int ldo, long lo_off, void* stream);
+int vitg_attention_split(const void* q, const void* k, const void* v, void* o, long q_lo, long k_lo, long v_lo, long o_lo, int batch, int heads,
+                         int kv_heads, int S, int Sk, int head_dim, long q_bs, long k_bs, long v_bs, long o_bs, int q_rs, int k_rs, int v_rs,
+                         int o_rs, int q_hs, int k_hs, int v_hs, int o_hs, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS="device gemm gemm256 gemm_mi16 gemm_fp8 attention attention_sp attention_ab attention_w4 elementwise preprocess probe"
+SRCS="device gemm gemm256 gemm_mi16 gemm_fp8 attention attention_sp attention_ab attention_w4 elementwise preprocess probe split"
 OUT="$HERE/../libvideoitg_hip.so"
 OBJ="$HERE/build"
 DEFS=""

@@ -46,6 +46,7 @@ struct GemmArgs {
     // [T, 3, R, R] (16-bit, NCHW), row m = (frame, py, px) reads its p x p x 3 patch straight from there
     int pt_R, pt_G, pt_P;     // image side, patches per side (R / p), patches per frame (G * G); pt_R == 0: off
     int pt_p, pt_pairs;       // patch side p (8..16), (channel, ky) pairs = 3 p
+    long split_off;           // SPLIT instantiations of gemm_mi16.hip (vitg_gemm_split16): element offset of the lo plane in `out`
 };
 
 enum { MODE_STORE16 = 0, MODE_F32 = 1, MODE_SWIGLU = 2 };

@@ -51,9 +51,13 @@ constexpr int MODE_RES16 = 3;      // internal: MODE_STORE16 with a residual pre
 // global_load_lds_dwordx4 source - and the second chunk of a pair re-reads kx p-8..7, whose weight slots are zero: no chunk ever crosses the
 // end of its pixel row, so nothing is read outside the tensor and no value depends on what lies behind a patch.  The per-lane source offset
 // is (row's pixel base) + (pair's row/channel offset, recomputed per K-tile: ~7 VALU per DMA instruction on a GEMM of 11 K-tiles).
-template <typename T, int MODE, int BM, int BN, bool SK = false, int WM = 2, bool PATCH = false>
+// SPLIT (round 6, vitg_gemm_split16: the operand-split precision tier, csrc/split.hip): the 16-bit-output epilogues write every value as a PAIR
+// hi = fp16(v) at out[m, n] and lo = fp16(v - hi) at out[m, n + split_off] - the A operand of the next GEMM in K-concatenated form.  Two passes of
+// the same stage loop (the activation is recomputed); the main loop is the same code.  Separate instantiations: the default kernels do not carry it.
+template <typename T, int MODE, int BM, int BN, bool SK = false, int WM = 2, bool PATCH = false, bool SPLIT = false>
 __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     static_assert(!SK || MODE == MODE_F32, "stream-K partials are fp32 tiles");
+    static_assert(!SPLIT || MODE == MODE_STORE16 || MODE == MODE_SWIGLU, "split pairs are a 16-bit-output form");
     static_assert(!PATCH || !SK, "the patch loader is not combined with stream-K");
     typedef typename T16<T>::vec8 vec8;
     GemmArgs g = g_;
@@ -390,7 +394,8 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
             }
         }
         const bool has_bias = EMODE != MODE_SWIGLU && g.bias != nullptr && !(MODE == MODE_STORE16 && bias_init) && !res_bias_done;      // a bias is still to be added here
-        auto stages = [&](auto act_c, auto in_c, auto bias_c) {
+        auto stages_hl = [&](auto act_c, auto in_c, auto bias_c, auto lo_c) {
+        constexpr bool LO = decltype(lo_c)::value;           // SPLIT: the pass that writes lo = fp16(v - fp16(v)) to out + split_off
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool IN = decltype(in_c)::value;           // interior tile: no bounds predicates
         constexpr int BIAS = decltype(bias_c)::value;        // 1 / 0: a bias is / is not added here (interior forms); -1: tested per quad (edge tiles)
@@ -438,10 +443,14 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                     typename T16<T>::vec4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
+                    if constexpr (LO) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e] - T16<T>::to_f32(o[e]));
+                    }
                     const int row = h * 16 + r16, c = nt * 2 + (fq >> 1);
                     *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4) + (fq & 1) * 8) = o;
                 }
-            char* const ob = (char*)((T*)g.out + (size_t)(mw + mp * 32) * g.ldo + n_out);
+            char* const ob = (char*)((T*)g.out + (LO ? (size_t)g.split_off : (size_t)0) + (size_t)(mw + mp * 32) * g.ldo + n_out);
 #pragma unroll
             for (int i = 0; i < 32 * CH / 64; ++i) {
                 const int idx = i * 64 + lane;
@@ -455,7 +464,11 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                 }
             }
         }
-        };   // stages
+        };   // stages_hl
+        auto stages = [&](auto act_c, auto in_c, auto bias_c) {
+            stages_hl(act_c, in_c, bias_c, std::false_type{});
+            if constexpr (SPLIT) stages_hl(act_c, in_c, bias_c, std::true_type{});
+        };
         typedef std::true_type IY;
         typedef std::false_type IN_;
         typedef std::integral_constant<int, 1> B1;
@@ -483,14 +496,14 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
     }   // tile loop
 }
 
-template <typename T, int MODE, int BM, int BN, int WM = 2>
+template <typename T, int MODE, int BM, int BN, int WM = 2, bool SPLIT = false>
 static int launch16(GemmArgs g, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * 128;
     static int done_dev[16] = {0};                       // per device: the attribute belongs to the device's copy of the kernel
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     if (cur_dev >= 16 || !done_dev[cur_dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm16_kernel<T, MODE, BM, BN, false, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm16_kernel<T, MODE, BM, BN, false, WM, false, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (cur_dev < 16) done_dev[cur_dev] = 1;
     }
     g.tiles_m = ceil_div(g.M, BM);
@@ -506,8 +519,14 @@ static int launch16(GemmArgs g, hipStream_t s) {
     // one block per CU walking the tile list when there are at least two tiles per CU (gemm256.hip: "software relaunch")
     const bool loop = nwg >= 2 * cus && !(RESEARCH(gemm_flags) & 0x1000000);
     const int splits = (MODE == MODE_F32 && g.split_k > 1) ? g.split_k : 1;
-    hipLaunchKernelGGL((gemm16_kernel<T, MODE, BM, BN, false, WM>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G16_THREADS), lds, s, g);
+    hipLaunchKernelGGL((gemm16_kernel<T, MODE, BM, BN, false, WM, false, SPLIT>), dim3(loop && splits == 1 ? cus : nwg, splits), dim3(G16_THREADS), lds, s, g);
     return (int)hipGetLastError();
+}
+
+// the operand-split tier's 16-bit-output GEMMs (fp16 only): one tile shape per epilogue mode and shape class
+int launch_gemm_mi16_split(const GemmArgs& g, int mode, hipStream_t s) {
+    if (mode == MODE_SWIGLU) return g.M >= 384 ? launch16<f16_t, MODE_SWIGLU, 384, 256, 2, true>(g, s) : launch16<f16_t, MODE_SWIGLU, 256, 256, 2, true>(g, s);
+    return g.N >= 384 ? launch16<f16_t, MODE_STORE16, 256, 384, 2, true>(g, s) : launch16<f16_t, MODE_STORE16, 256, 256, 2, true>(g, s);
 }
 
 #if VITG_PROFILING_BUILD   // stream-K lost its A/B against split-K x2 on the per-rank shapes (profiles/r03_context_parallel.md): profiling library only
@@ -590,6 +609,29 @@ static int launch16_patch(GemmArgs g, hipStream_t s) {
 }
 
 }  // namespace vitg
+
+// Operand-split precision tier (csrc/split.hip): out[m, n] = hi, out[m, n + lo_off] = lo of v = act(A W^T + bias) (mode STORE16) or of
+// silu(gate) * up (mode SWIGLU, N = 2 x output width), v = hi + lo to 22 bits.  A / W are ordinary fp16 operands - a split A operand arrives
+// K-concatenated ([hi | lo], K = 2 Kp) against W laid twice side by side, which this entry neither knows nor checks.  fp16 only.
+extern "C" int vitg_gemm_split16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int mode, const float* bias, int act,
+                                 void* out, int ldo, long lo_off, void* stream) {
+    using namespace vitg;
+    if (M <= 0 || N <= 0) return 0;
+    if (!A || !W || !out) return VITG_ERR_ARG;
+    if (K <= 0 || K % 64) return VITG_ERR_SHAPE;
+    if (mode != VITG_GEMM_STORE16 && mode != VITG_GEMM_SWIGLU) return VITG_ERR_ARG;
+    if (act != VITG_ACT_NONE && act != VITG_ACT_GELU_TANH && act != VITG_ACT_GELU_ERF) return VITG_ERR_ARG;
+    if (mode == VITG_GEMM_SWIGLU && (N % 64 || act != VITG_ACT_NONE || bias)) return VITG_ERR_SHAPE;
+    if ((lda % 8) || (ldw % 8) || (N % 8) || (ldo % 8) || (lo_off % 8)) return VITG_ERR_ALIGN;
+    if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return VITG_ERR_ALIGN;
+    const int n_out = mode == VITG_GEMM_SWIGLU ? N / 2 : N;
+    if (lo_off < n_out || ldo < lo_off + n_out) return VITG_ERR_SHAPE;       // the two planes of a row must not overlap
+    GemmArgs g = {};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.act = act; g.out = out; g.ldo = ldo; g.split_k = 1; g.split_off = lo_off;
+    const int rc = launch_gemm_mi16_split(g, mode, (hipStream_t)stream);
+    return rc == 0 ? 0 : VITG_ERR_LAUNCH;
+}
 
 // x[T * P, N] (16-bit) = im2col(pixel_values) @ Wf^T + bias + pos[(m % P), :]   - SigLIP's patch_embedding + position table
 // ([3P] SiglipVisionEmbeddings, reached from /root/reference/eagle/model/multimodal_encoder/clip_encoder.py:146) with the im2col done by the

@@ -257,8 +257,8 @@ class PackedWeights:
 
     @staticmethod
     def from_state_dicts(cfg: ITGConfig, sd: SD, vsd: SD, dtype: torch.dtype, device, fp8: "bool | str" = False,
-                         vit_dtype: Optional[torch.dtype] = None) -> "PackedWeights":
-        pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device(device), fp8=fp8, vit_dtype=vit_dtype)
+                         vit_dtype: Optional[torch.dtype] = None, vit_q_prescaled: Optional[bool] = None) -> "PackedWeights":
+        pw = PackedWeights(cfg=cfg, dtype=dtype, device=torch.device(device), fp8=fp8, vit_dtype=vit_dtype, vit_q_prescaled=vit_q_prescaled)
         pw.pack_vision_embeddings(vsd)
         for i in range(cfg.num_vit_layers_needed()):
             pw.pack_vision_layer(vsd, i)
@@ -266,6 +266,12 @@ class PackedWeights:
         for i in range(cfg.num_hidden_layers):
             pw.pack_llm_layer(sd, i)
         return pw
+
+    def doubled(self) -> "SplitWeights":
+        """the [W | W] copies the operand-split tier multiplies K-concatenated (hi | lo) operands with (built once, on first use)"""
+        if getattr(self, "_doubled", None) is None:
+            self._doubled = SplitWeights(self)
+        return self._doubled
 
     def pos_table(self, grid: int) -> torch.Tensor:
         """fp32 [grid*grid, Dv]; bicubic resample of the native table when the input side is not the native one
@@ -281,11 +287,38 @@ class PackedWeights:
         return self.pos_cache[grid]
 
 
+def _dbl(w: torch.Tensor) -> torch.Tensor:
+    return torch.cat([w, w], 1).contiguous()
+
+
+class SplitWeights:
+    """Operand-split tier (csrc/split.hip): a split A operand arrives as [hi | lo] with K = 2 Kp, so the weight of every GEMM that consumes one is laid
+    twice side by side, [N, 2 Kp] = [W | W] - sum_k hi_k w_k + sum_k lo_k w_k in one accumulator, through the unchanged GEMM main loop.  The patch
+    embedding is not here: its operand is the 16-bit-exact pixel tensor itself."""
+
+    def __init__(self, pw: PackedWeights):
+        if pw.fp8 is not False:
+            raise ValueError("the operand-split tier multiplies 16-bit-exact weights; it does not combine with the fp8 weight path")
+        if pw.dtype != torch.float16 or pw.vit_dtype != torch.float16:
+            raise ValueError("the operand-split tier splits into fp16 pairs (11 + 11 bits): load the weights as torch.float16")
+        if pw.vit_q_prescaled:
+            raise ValueError("PackedWeights(vit_q_prescaled=True) rounds (scale * W_q) to 16 bits - a deviation of 2^-12 per weight from the checkpoint "
+                             "that the operand-split tier exists to avoid; build the weights with vit_q_prescaled=False")
+        self.vit = [dict(qkv=_dbl(l.qkv_w), out=_dbl(l.out_w), fc1=_dbl(l.fc1_w), fc2=_dbl(l.fc2_w)) for l in pw.vit]
+        self.proj0, self.proj2 = _dbl(pw.proj0_w), _dbl(pw.proj2_w)
+        self.llm = [dict(qkv=_dbl(l.qkv_w), o=_dbl(l.o_w), gu=_dbl(l.gu_w), down=_dbl(l.down_w)) for l in pw.llm]
+
+
 class SelectorEngine:
     """Runs the forward.  One instance per process / GPU."""
 
-    def __init__(self, weights: PackedWeights, attn_variant: int = 0):
+    def __init__(self, weights: PackedWeights, attn_variant: int = 0, operand_split: bool = False):
         self.w = weights
+        # operand-split precision tier (round 6; csrc/split.hip): every MFMA operand as an fp16 (hi, lo) pair - fp32-grade GEMMs and attention at
+        # 2 x / 3 x the MFMA work, for weights on which 11-bit operands miss north_star's 1e-3 (massive-activation channels, profiles/r05_heavy_tail.md).
+        # fp32 residual streams, every tower layer on all tokens, eager launches on one GPU (no graph capture, no context parallelism).
+        self.operand_split = bool(operand_split)
+        self.sw = weights.doubled() if self.operand_split else None
         self.cfg = weights.cfg
         self.dtype = weights.dtype                # LLM / projector MFMA input type
         self.vdtype = weights.vit_dtype           # tower MFMA input type
@@ -468,6 +501,8 @@ class SelectorEngine:
         cmap is None.  With a pooled grid, the LAST needed layer computes K/V for all tokens but queries, out-proj and MLP
         only for the Pc tokens the pool reads (their outputs are the only ones anything downstream consumes), and features
         are compact [T*Pc, Dv] with cmap: token -> compact row."""
+        if self.operand_split:
+            return self.vit_forward_split(pix)
         cfg, v, w = self.cfg, self.cfg.vision, self.w
         T, _, R, _ = pix.shape
         G = R // v.patch_size
@@ -618,11 +653,84 @@ class SelectorEngine:
         cfg, w = self.cfg, self.w
         Dv, Dvp, Dp = cfg.vision.hidden_size, pad64(cfg.vision.hidden_size), pad64(cfg.hidden_size)
         nv = T * hw * hw
+        if self.operand_split:
+            if cmap is not None or feats.dtype != torch.float32:
+                raise ValueError("the operand-split tier pools dense fp32 tower features")
+            pooled2 = self._buf("pooled2", (nv, 2 * Dvp), torch.float16, zero=True)
+            K.bilinear_pool_split(feats, pooled2, T, G, hw, Dv)
+            g2 = self._buf("proj_g2", (nv, 2 * Dp), torch.float16)
+            K.gemm_split16(pooled2, self.sw.proj0, g2, mode=K.GEMM_STORE16, lo_off=Dp, bias=w.proj0_b, act=K.ACT_GELU_ERF)
+            self._gemm(g2, self.sw.proj2, dst_rows, mode=K.GEMM_F32, bias=w.proj2_b)
+            return
         pooled = self._buf("pooled", (nv, Dvp), self.dtype)
         (K.bilinear_pool if feats.dtype == torch.float32 else K.bilinear_pool16)(feats, pooled, T, G, hw, Dv, cmap, pc)   # (16-bit tower stream)
         g = self._buf("proj_g", (nv, Dp), self.dtype)
         K.gemm(pooled, w.proj0_w, g, mode=K.GEMM_STORE16, bias=w.proj0_b, act=K.ACT_GELU_ERF)
         K.gemm(g, w.proj2_w, dst_rows, mode=K.GEMM_F32, bias=w.proj2_b)
+
+    # ---- operand-split tier (csrc/split.hip): the same forward with every MFMA operand as an fp16 (hi, lo) pair --------------------------------
+    def vit_forward_split(self, pix: torch.Tensor):
+        """A7 on split operands -> (dense fp32 features [T*P, Dv], G, None, 0).  fp32 residual stream, every layer on all tokens; LayerNorm writes
+        [hi | lo] rows, the qkv / fc1 GEMMs write (hi, lo) pairs from their epilogues, attention runs the 3-term products, out-proj / fc2 add into the
+        fp32 stream.  The patch embedding takes the 16-bit pixel tensor as it is (pixels and weights are 16-bit exact: nothing to split)."""
+        v, w, sw = self.cfg.vision, self.w, self.sw
+        T, _, R, _ = pix.shape
+        G = R // v.patch_size
+        P = G * G
+        M = T * P
+        Dv, Dvp, Fvp = v.hidden_size, pad64(v.hidden_size), pad64(v.intermediate_size)
+        H, hd, eps = v.num_attention_heads, v.head_dim, v.layer_norm_eps
+        f16 = torch.float16
+        if pix.dtype != f16:
+            raise ValueError("the operand-split tier takes fp16 pixel_values (what infer.py:55 hands the model)")
+        self.vit_stream_bytes = 4
+        x = self._buf("vit_x", (M, Dv), torch.float32)
+        a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], f16)
+        self._gemm(a0, w.patch_w, x, mode=K.GEMM_F32, bias=w.patch_b, res=w.pos_table(G), res_mod=P)
+        del a0
+        h = self._buf("vit_h2", (M, 2 * Dvp), f16, zero=True)
+        qkv = self._buf("vit_qkv2", (M, 6 * Dv), f16)                     # [q k v hi | q k v lo]
+        o = self._buf("vit_o2", (M, 2 * Dvp), f16, zero=True)
+        f = self._buf("vit_f2", (M, 2 * Fvp), f16)
+        st = (P * 6 * Dv, 6 * Dv, hd)
+        for lw, l2 in zip(w.vit, sw.vit):
+            K.norm_split(x, lw.ln1_w, lw.ln1_b, h, Dv, eps)
+            K.gemm_split16(h, l2["qkv"], qkv, mode=K.GEMM_STORE16, lo_off=3 * Dv, bias=lw.qkv_b)
+            K.attention_split(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, lo=(3 * Dv, 3 * Dv, 3 * Dv, Dvp), batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
+                              q_strides=st, k_strides=st, v_strides=st, o_strides=(P * 2 * Dvp, 2 * Dvp, hd), scale=hd ** -0.5)
+            self._gemm(o, l2["out"], x, mode=K.GEMM_F32, bias=lw.out_b, res=x)
+            K.norm_split(x, lw.ln2_w, lw.ln2_b, h, Dv, eps)
+            K.gemm_split16(h, l2["fc1"], f, mode=K.GEMM_STORE16, lo_off=Fvp, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
+            self._gemm(f, l2["fc2"], x, mode=K.GEMM_F32, bias=lw.fc2_b, res=x)
+        return x, G, None, 0
+
+    def llm_forward_split(self, x: torch.Tensor) -> torch.Tensor:
+        """A11 on split operands: fp32 x [N, D] (in place) -> final-normed fp32"""
+        cfg, w, sw = self.cfg, self.w, self.sw
+        N, D = x.shape
+        Dp, Fp = pad64(D), pad64(cfg.intermediate_size)
+        nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        qkv_n, op = (nq + 2 * nkv) * hd, pad64(nq * hd)
+        f16 = torch.float16
+        h = self._buf("llm_h2", (N, 2 * Dp), f16, zero=True)
+        qkv = self._buf("llm_qkv2", (N, 2 * qkv_n), f16)
+        o = self._buf("llm_o2", (N, 2 * op), f16, zero=True)
+        f = self._buf("llm_f2", (N, 2 * Fp), f16)
+        cos, sin = self.rope_tables(N)
+        st = (0, 2 * qkv_n, hd)
+        for lw, l2 in zip(w.llm, sw.llm):
+            K.norm_split(x, lw.in_ln, None, h, D, cfg.rms_norm_eps)
+            K.gemm_split16(h, l2["qkv"], qkv, mode=K.GEMM_STORE16, lo_off=qkv_n, bias=lw.qkv_b)
+            K.rope_split_(qkv, cos, sin, nq + nkv, hd, qkv_n)
+            K.attention_split(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, lo=(qkv_n, qkv_n, qkv_n, op), batch=1, heads=nq, kv_heads=nkv, seq=N,
+                              head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=(0, 2 * op, hd), scale=hd ** -0.5)
+            self._gemm(o, l2["o"], x, mode=K.GEMM_F32, res=x)
+            K.norm_split(x, lw.post_ln, None, h, D, cfg.rms_norm_eps)
+            K.gemm_split16(h, l2["gu"], f, mode=K.GEMM_SWIGLU, lo_off=Fp)
+            self._gemm(f, l2["down"], x, mode=K.GEMM_F32, res=x)
+        out = self._buf("llm_out", (N, D), torch.float32)
+        K.rmsnorm(x, w.norm_w, out, D, cfg.rms_norm_eps)
+        return out
 
     def rope_tables(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """fp32 cos/sin [n, hd/2], inv_freq = theta^(-2i/hd), positions 0..n-1 ([3P] Qwen2RotaryEmbedding;
@@ -641,6 +749,10 @@ class SelectorEngine:
         position of row 0, total = global token count, kv_gather(local K|V rows) -> all K|V rows.
         kv_len (int32 device scalar, single-GPU path): only the first kv_len rows are real tokens - the rest is bucket padding
         that no query may attend to (a captured graph serves every prompt length of its bucket)."""
+        if self.operand_split:
+            if kv_gather is not None or kv_len is not None or pos0 != 0 or (total is not None and total != x.shape[0]):
+                raise NotImplementedError("the operand-split tier runs the eager one-GPU forward (no context parallelism, no bucketed graph capture)")
+            return self.llm_forward_split(x)
         cfg, w = self.cfg, self.w
         N, D = x.shape
         total = N if total is None else total

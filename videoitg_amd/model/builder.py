@@ -130,6 +130,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     if model_base is not None:
         raise NotImplementedError("LoRA / projector-only checkpoints (model_base) are not part of the selector path")
     dtype = kwargs.pop("torch_dtype", torch.float16)                       # builder.py:59
+    operand_split = kwargs.pop("operand_split", None)                     # (this build's precision tier: EagleQwenG.operand_split)
     if device_map in (None, "auto"):
         dev = device if device != "cuda" else "cuda"
     elif isinstance(device_map, dict):
@@ -145,6 +146,8 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         from transformers import AutoTokenizer
         tokenizer = AutoTokenizer.from_pretrained(model_path)              # builder.py:118
     model = EagleQwenG(cfg, sd, vsd, torch_dtype=dtype, device=dev)
+    if operand_split is not None:
+        model.operand_split = bool(operand_split)
     # builder.py:155-161 — special tokens (the embedding table is not grown: the ITG prompt never uses them)
     if getattr(cfg, "mm_use_im_patch_token", True):
         tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)

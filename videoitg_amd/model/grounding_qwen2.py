@@ -98,6 +98,10 @@ class EagleQwenG(nn.Module):
         # opt-in fp8 weight path (BASELINE.json configs[4]): tower / decoder GEMM weights as e4m3fn + per-channel scales, per-token
         # fp8 activations into those GEMMs.  VITG_FP8=1 or model.fp8 = True before the first forward.
         self.fp8 = os.environ.get("VITG_FP8", "0") not in ("", "0")
+        # opt-in operand-split precision tier (round 6, csrc/split.hip): every MFMA operand as an fp16 (hi, lo) pair - the tier that holds north_star's
+        # 1e-3 against the fp32 CPU reference on checkpoints with massive-activation channels, at ~2.5x the step time.  VITG_OPERAND_SPLIT=1,
+        # load_pretrained_model(..., operand_split=True) or model.operand_split = True before the first forward.
+        self.operand_split = os.environ.get("VITG_OPERAND_SPLIT", "0") not in ("", "0")
         self._graphs = None
 
     # ---- chaining the callers do ---------------------------------------------------------------
@@ -170,8 +174,9 @@ class EagleQwenG(nn.Module):
                                    "there is no CPU path")
             sd, vsd = self._src
             with torch.cuda.device(self._device):
-                pw = PackedWeights.from_state_dicts(self.config, sd, vsd, self._dtype, self._device, fp8=self.fp8)
-            self._engine = SelectorEngine(pw)
+                pw = PackedWeights.from_state_dicts(self.config, sd, vsd, self._dtype, self._device, fp8=self.fp8,
+                                                    vit_q_prescaled=False if self.operand_split else None)
+                self._engine = SelectorEngine(pw, operand_split=self.operand_split)
             if not keep_source:
                 self._src = None
         return self._engine
@@ -192,7 +197,7 @@ class EagleQwenG(nn.Module):
             single = len(images) == 1 and (input_ids.dim() == 1 or input_ids.shape[0] == 1) and \
                 (attention_mask is None or bool(attention_mask.all()))
             # (never in training mode: the captured forward pools with the eval rule and would not consume the reference's random-grid draws)
-            if self.use_graphs and single and grounding_labels is None and not self.training:
+            if self.use_graphs and single and grounding_labels is None and not self.training and not self.operand_split:
                 if self._graphs is None or self._graphs.eng is not eng:
                     from ..engine import GraphCache
                     self._graphs = GraphCache(eng)

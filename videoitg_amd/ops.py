@@ -545,3 +545,49 @@ def bce_loss(logits: torch.Tensor, labels: torch.Tensor):
     out = torch.empty(2, dtype=torch.float32, device=logits.device)
     _lib.call("vitg_bce_loss", _ptr(logits.contiguous()), _ptr(labels.contiguous()), logits.numel(), _ptr(out), _stream())
     return out[0], out[1]
+
+
+# ---- operand-split precision tier (csrc/split.hip): split operands are fp16 [M, 2 * Dp] = [hi | lo] ------------------------------------------
+def norm_split(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, d: int, eps: float) -> torch.Tensor:
+    """LayerNorm (b given) / RMSNorm of fp32 rows -> out fp16 [M, 2 * Dp]: hi in [:, :Dp], lo in [:, Dp:] (vitg_norm_split)"""
+    _req(x, torch.float32); _req(out, torch.float16)
+    lo = out.shape[1] // 2
+    _lib.call("vitg_norm_split", _ptr(x), x.stride(0), _ptr(_req(w, torch.float32)), _ptr(b), _ptr(out), out.stride(0), lo, x.shape[0], d, float(eps),
+              _stream())
+    return out
+
+
+def rope_split_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, head_dim: int, lo_off: int) -> torch.Tensor:
+    _req(qkv, torch.float16)
+    _lib.call("vitg_rope_split", _ptr(qkv), qkv.stride(0), lo_off, _ptr(_req(cos, torch.float32)), _ptr(_req(sin, torch.float32)), qkv.shape[0], heads,
+              head_dim, _stream())
+    return qkv
+
+
+def bilinear_pool_split(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d: int) -> torch.Tensor:
+    _req(x, torch.float32); _req(out, torch.float16)
+    _lib.call("vitg_bilinear_pool_split", _ptr(x), x.stride(0), _ptr(out), out.stride(0), out.shape[1] // 2, T, G, HW, d, _stream())
+    return out
+
+
+def gemm_split16(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int, lo_off: int, bias: Optional[torch.Tensor] = None,
+                 act: int = ACT_NONE) -> torch.Tensor:
+    """out[:, n] / out[:, lo_off + n] = (hi, lo) of epilogue(a @ w.T) - vitg_gemm's 16-bit-output modes writing split pairs (vitg_gemm_split16)"""
+    _req(a, torch.float16); _req(w, torch.float16); _req(out, torch.float16)
+    M, Kd = a.shape
+    assert w.shape[1] == Kd and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    if bias is not None:
+        _req(bias, torch.float32)
+    _lib.call("vitg_gemm_split16", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, w.shape[0], Kd, mode, _ptr(bias), act, _ptr(out), out.stride(0),
+              lo_off, _stream())
+    return out
+
+
+def attention_split(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, *, lo, batch: int, heads: int, kv_heads: int, seq: int,
+                    head_dim: int, q_strides, k_strides, v_strides, o_strides, scale: float, kv_seq: Optional[int] = None) -> torch.Tensor:
+    """q/k/v/o: base tensors of the hi planes; lo = (q_lo, k_lo, v_lo, o_lo) element offsets of the lo planes; *_strides = (batch, row, head)"""
+    _req(q, torch.float16); _req(o, torch.float16)
+    _lib.call("vitg_attention_split", _ptr(q), _ptr(k), _ptr(v), _ptr(o), lo[0], lo[1], lo[2], lo[3], batch, heads, kv_heads, seq,
+              seq if kv_seq is None else kv_seq, head_dim, q_strides[0], k_strides[0], v_strides[0], o_strides[0], q_strides[1], k_strides[1],
+              v_strides[1], o_strides[1], q_strides[2], k_strides[2], v_strides[2], o_strides[2], float(scale), _stream())
+    return o

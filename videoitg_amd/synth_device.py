@@ -20,10 +20,11 @@ def _draw(specs, device, seed, plan=None):
 
 
 def packed_random_weights(cfg: ITGConfig, dtype: torch.dtype, device, seed: int = 0, fp8: bool = False,
-                          vit_dtype=None, plan: "synth.HeavyTailPlan | None" = None) -> PackedWeights:
-    """`plan`: the heavy-tailed variant (synth.HeavyTailPlan; fixtures carrying a "heavy_tail" record, synth.fixture_plan)"""
+                          vit_dtype=None, plan: "synth.HeavyTailPlan | None" = None, vit_q_prescaled=None) -> PackedWeights:
+    """`plan`: the heavy-tailed variant (synth.HeavyTailPlan; fixtures carrying a "heavy_tail" record, synth.fixture_plan);
+    vit_q_prescaled=False: the q projection keeps the checkpoint's own 16-bit weights (what the operand-split tier needs)"""
     device = torch.device(device)
-    pw = PackedWeights(cfg=cfg, dtype=dtype, device=device, fp8=fp8, vit_dtype=vit_dtype)
+    pw = PackedWeights(cfg=cfg, dtype=dtype, device=device, fp8=fp8, vit_dtype=vit_dtype, vit_q_prescaled=vit_q_prescaled)
     vspecs = list(synth.vision_param_specs(cfg))
     lspecs = list(synth.llm_param_specs(cfg))
     pw.pack_vision_embeddings(_draw([s for s in vspecs if s[0].startswith("vision_model.embeddings.")], device, seed, plan))

@@ -100,6 +100,23 @@ _def("rope_(Tensor(a!) qkv, Tensor cos, Tensor sin, int heads, int head_dim) -> 
      lambda qkv, cos, sin, heads, head_dim: (_raw.rope_(qkv, cos, sin, heads, head_dim), None)[1],
      lambda qkv, cos, sin, heads, head_dim: None)
 
+# ---- operand-split precision tier (csrc/split.hip)
+_def("norm_split(Tensor x, Tensor w, Tensor? b, Tensor(a!) out, int d, float eps) -> ()",
+     lambda x, w, b, out, d, eps: (_raw.norm_split(x, w, b, out, d, eps), None)[1], lambda *a, **k: None)
+_def("rope_split_(Tensor(a!) qkv, Tensor cos, Tensor sin, int heads, int head_dim, int lo_off) -> ()",
+     lambda qkv, cos, sin, heads, head_dim, lo_off: (_raw.rope_split_(qkv, cos, sin, heads, head_dim, lo_off), None)[1], lambda *a, **k: None)
+_def("bilinear_pool_split(Tensor x, Tensor(a!) out, int T, int G, int HW, int d) -> ()",
+     lambda x, out, T, G, HW, d: (_raw.bilinear_pool_split(x, out, T, G, HW, d), None)[1], lambda *a, **k: None)
+_def("gemm_split16(Tensor a, Tensor w, Tensor(a!) out, int mode, int lo_off, Tensor? bias=None, int act=0) -> ()",
+     lambda a, w, out, mode, lo_off, bias=None, act=0: (_raw.gemm_split16(a, w, out, mode=mode, lo_off=lo_off, bias=bias, act=act), None)[1],
+     lambda *a, **k: None)
+_def("attention_split(Tensor q, Tensor k, Tensor v, Tensor(a!) o, int[] lo, int batch, int heads, int kv_heads, int seq, int head_dim, "
+     "int[] q_strides, int[] k_strides, int[] v_strides, int[] o_strides, float scale, int? kv_seq=None) -> ()",
+     lambda q, k, v, o, lo, batch, heads, kv_heads, seq, head_dim, q_strides, k_strides, v_strides, o_strides, scale, kv_seq=None:
+         (_raw.attention_split(q, k, v, o, lo=lo, batch=batch, heads=heads, kv_heads=kv_heads, seq=seq, head_dim=head_dim, q_strides=q_strides,
+                               k_strides=k_strides, v_strides=v_strides, o_strides=o_strides, scale=scale, kv_seq=kv_seq), None)[1],
+     lambda *a, **k: None)
+
 # ---- non-causal flash attention ------------------------------------------------------------------------------------------
 _def("attention(Tensor q, Tensor k, Tensor v, Tensor(a!) o, int batch, int heads, int kv_heads, int seq, int head_dim, "
      "int[] q_strides, int[] k_strides, int[] v_strides, int[] o_strides, float scale, int variant=0, int? kv_seq=None, "
@@ -251,6 +268,32 @@ class _Namespace:
         return out
 
     @staticmethod
+    def norm_split(x, w, b, out, d, eps):
+        _ops.norm_split(x, w, b, out, d, eps)
+        return out
+
+    @staticmethod
+    def rope_split_(qkv, cos, sin, heads, head_dim, lo_off):
+        _ops.rope_split_(qkv, cos, sin, heads, head_dim, lo_off)
+        return qkv
+
+    @staticmethod
+    def bilinear_pool_split(x, out, T, G, HW, d):
+        _ops.bilinear_pool_split(x, out, T, G, HW, d)
+        return out
+
+    @staticmethod
+    def gemm_split16(a, w, out, *, mode, lo_off, bias=None, act=0):
+        _ops.gemm_split16(a, w, out, mode, lo_off, bias, act)
+        return out
+
+    @staticmethod
+    def attention_split(q, k, v, o, *, lo, batch, heads, kv_heads, seq, head_dim, q_strides, k_strides, v_strides, o_strides, scale, kv_seq=None):
+        _ops.attention_split(q, k, v, o, list(lo), batch, heads, kv_heads, seq, head_dim, list(q_strides), list(k_strides), list(v_strides),
+                             list(o_strides), scale, kv_seq)
+        return o
+
+    @staticmethod
     def gemm_res16(a, w, out, *, bias=None, res16=None, res32=None, res_mod=0):
         _ops.gemm_res16(a, w, out, bias, res16, res32, res_mod)
         return out
@@ -330,4 +373,5 @@ class _Namespace:
 K = _Namespace()
 OP_NAMES: List[str] = ["patchify", "gemm", "gemm_splitk", "gemm_splitk16", "layernorm", "rmsnorm", "rope_", "attention", "bilinear_pool", "gather_rows",
                        "embed_gather", "pool_score", "rank", "bce_loss", "preprocess_u8", "quant_rows_fp8", "norm_quant_fp8", "gemm_fp8", "gemm_fp8_mx",
-                       "gemm_res16", "layernorm16", "bilinear_pool16", "patch_embed16", "norm_quant_fp8_16", "gemm_fp8_res16"] + (["gemm_streamk"] if _raw._lib.PROFILING else [])
+                       "gemm_res16", "layernorm16", "bilinear_pool16", "patch_embed16", "norm_quant_fp8_16", "gemm_fp8_res16",
+                       "norm_split", "rope_split_", "bilinear_pool_split", "gemm_split16", "attention_split"] + (["gemm_streamk"] if _raw._lib.PROFILING else [])
