@@ -426,8 +426,58 @@ def heavy_tailed_block(cfg, T, R, prompt_len, seed, dtype, vit_dtype, dev):
         eng.release_workspace()
         del eng
         torch.cuda.empty_cache()
+        # round 6: the operand-split tier (every MFMA operand an fp16 (hi, lo) pair; csrc/split.hip) on the same heavy-tailed weights - the tier that is
+        # asked to hold north_star's 1e-3 AND the Top-32 set here (tests/test_gpu_split.py states the bounds)
+        if vit_dtype == torch.float16 and dtype == torch.float16:
+            eng = SelectorEngine(packed_random_weights(cfg, dtype, dev, seed=seed, plan=synth.fixture_plan(rec), vit_q_prescaled=False), operand_split=True)
+            lg = eng.forward(ids_h, None, [pix_h])[0].view(-1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lg = eng.forward(ids_h, None, [pix_h])[0].view(-1)
+            _, order = ops.rank(lg)
+            order = order.cpu().tolist()
+            dt_s = time.perf_counter() - t0
+            got = lg.float().cpu()
+            ds, dl = (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item(), (got - want).abs().max().item()
+            out["operand_split"] = {"max_abs_dscore": round(ds, 7), "max_abs_dlogit": round(dl, 6), f"top{k}_kept": len(set(order[:k]) & set(rec["topk"])),
+                                    f"top{k}_set_match": sorted(order[:k]) == rec["topk"], "within_north_star_1e-3": bool(ds <= 1e-3),
+                                    "value": round(T / dt_s, 2), "unit": "frames/s", "ms_per_step": round(dt_s * 1e3, 2)}
+            eng.release_workspace()
+            del eng
+            torch.cuda.empty_cache()
         return out
     return None
+
+
+def operand_split_block(cfg, T, R, prompt_len, seed, dev, ids, pix):
+    """secondary.operand_split: the workload itself through the operand-split tier (SelectorEngine(operand_split=True): fp32-grade GEMMs on (hi, lo) fp16
+    pairs at 2x the MFMA work, 3-term attention at 3x, fp32 streams) with its parity block - the price of a forward that holds 1e-3 on any weights"""
+    from videoitg_amd import ops
+    from videoitg_amd.engine import SelectorEngine
+    from videoitg_amd.synth_device import packed_random_weights
+    eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=seed, vit_q_prescaled=False), operand_split=True)
+    oo = {}
+
+    def step_s():
+        oo["logits"] = eng.forward(ids, None, [pix])[0].view(-1)
+        _, order_ = ops.rank(oo["logits"])
+        oo["order"] = order_.cpu().tolist()
+    step_s()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step_s()
+    step_s()
+    torch.cuda.synchronize()
+    d = (time.perf_counter() - t0) / 2
+    out = {"value": round(T / d, 2), "unit": "frames/s", "ms_per_step": round(d * 1e3, 2),
+           "parity": parity_block(T, R, prompt_len, seed, oo["logits"], oo["order"]),
+           "weights_bytes_doubled": int(sum(t.numel() * t.element_size() for l in eng.sw.vit + eng.sw.llm for t in l.values())),
+           "what": "every MFMA operand as an fp16 (hi, lo) pair: [hi | lo] A operands against [W | W] through the unchanged GEMM main loop, (hi, lo) output "
+                   "pairs from the GEMM epilogues, S = QhKh + QhKl + QlKh and O = PhVh + PhVl + PlVh in attention; fp32 residual streams"}
+    eng.release_workspace()
+    del eng
+    torch.cuda.empty_cache()
+    return out
 
 
 class GemmTimer:
@@ -1127,6 +1177,18 @@ def main():
             out["secondary"]["planted_signal"] = planted_block(eng, cfg, T, R, args.prompt_len, args.seed, dtype, dev) if args.config == "full" else None
             # the heavy-tailed twin: same workload on weights with massive-activation channels, both tower streams, stated bounds
             out["secondary"]["heavy_tailed"] = heavy_tailed_block(cfg, T, R, args.prompt_len, args.seed, dtype, vit_dtype, dev) if args.config == "full" else None
+            # the precision tier that holds 1e-3 on heavy-tailed weights, with its price, and the Pareto over both fixtures
+            if args.dtype == "fp16" and args.config == "full":
+                out["secondary"]["operand_split"] = operand_split_block(cfg, T, R, args.prompt_len, args.seed, dev, ids, pix)
+                ht, osb = out["secondary"]["heavy_tailed"] or {}, out["secondary"]["operand_split"]
+                out["secondary"]["precision_pareto"] = [
+                    {"tier": "fp16 operands, 16-bit tower stream (headline)", "frames_per_s": out["value"],
+                     "max_abs_dscore_c2": out["parity"]["max_abs_dscore"] if out["parity"] else None,
+                     "max_abs_dscore_c2o_heavy_tailed": (ht.get("tower_stream_16bit") or {}).get("max_abs_dscore")},
+                    {"tier": "operand_split (fp16 hi + lo pairs)", "frames_per_s": osb["value"],
+                     "max_abs_dscore_c2": osb["parity"]["max_abs_dscore"] if osb["parity"] else None,
+                     "max_abs_dscore_c2o_heavy_tailed": (ht.get("operand_split") or {}).get("max_abs_dscore"),
+                     "top32_set_match_c2o": (ht.get("operand_split") or {}).get("top32_set_match")}]
             # the tower's residual stream.  The default runs it in fp16 (the reference's own arithmetic, model.half():
             # one rounding per residual update, fp32 accumulation inside the epilogue); this is the fp32-stream alternative of rounds 1-2
             # on the same engine, with its parity block - `residual16` restates the default's numbers beside it.

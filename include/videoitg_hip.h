@@ -49,8 +49,9 @@ int vitg_device_info(char* name, int name_len);
  *               per-shape choice (csrc/gemm256.hip: choose_cfg) - lets a test reach every shipped kernel on a small shape (12 exists for the SwiGLU and
  *               fp32-residual GEMMs; other modes run 256x256 under it)
  *   attn_ab     2  head dim 72 on the per-tile kernel (csrc/attention.hip) instead of the half-tile-out-of-phase one (csrc/attention_ab.hip)
- *   attn_sp     4  head dim 128 on the one-wave-per-SIMD kernel (csrc/attention_w4.hip: +5 % in isolation, -4 % inside the step - opt-in) instead of the 8-wave
- *               software-pipelined one (csrc/attention_sp.hip) | 2  on the per-tile kernel (csrc/attention.hip)
+ *   attn_sp     2  head dim 128 on the per-tile kernel (csrc/attention.hip) instead of the 8-wave software-pipelined one (csrc/attention_sp.hip)
+ *               (the one-wave-per-SIMD kernel of round 5, csrc/attention_w4.hip - +5 % in isolation, -4 % inside the step - lost its A/B where it runs
+ *               and lives in the profiling library since round 6: attn_sp = 4 there)
  * Any other key or value returns VITG_ERR_ARG.  These are process-global test hooks: set them before the forward they should apply to, not from a
  * second thread while one runs.  tests/test_gpu_e2e.py::test_full_size_invariants runs the same video through (gemm_tile 128, attn_ab 2, attn_sp 2)
  * and through the defaults.
@@ -195,8 +196,8 @@ int vitg_rope(void* qkv, int ld, const float* cos_t, const float* sin_t, long N,
 
 /* Non-causal softmax(QK^T * scale) V, fp32 softmax, GQA (heads % kv_heads == 0), head_dim 72 or 128.
  * S queries attend to Sk keys (Sk == S on one GPU; Sk = all-gathered keys in the context-parallel LLM).  One (batch, kv head) slice of K / V must end
- * below 4 GiB - ((Sk - 1) * row stride + head_dim) * 2 bytes < 2^32, else VITG_ERR_SHAPE: the kernels stage it through 32-bit buffer descriptors, whose
- * range check turns the rows past the last key into zeros.
+ * below 2 GiB - ((Sk rounded up to 64 - 1) * row stride + head_dim) * 2 bytes < 2^31, else VITG_ERR_SHAPE: the kernels stage it through 32-bit buffer
+ * descriptors (whose range check turns the rows past the last key into zeros) with signed 32-bit lane offsets.
  * Strides in elements: *_bs batch, *_rs token row, *_hs head.  variant bit 0 = cross-check path that reads V from LDS with scalar
  * loads instead of ds_read_b64_tr_b16; variant bit 1 (value 2) = q already holds Q * scale * log2(e) (the producing projection carries the
  * factor in its q rows - what the engine does for the SigLIP tower): scores are exponentiated in base 2 with no further scaling, which lets

@@ -21,7 +21,7 @@
  *   attn_waves  4 | 8 waves per block;  attn_dma 1 LDS-DMA | 2 register K/V staging;  attn_pipe 1 cross-tile pipelined hd-72 loop
  *   attn_ab     1 forced on | 3 16 waves per block | 4 PV on v_mfma_f32_32x32x16 (head dim padded to 96) | 5 PV on 16x16x32 with the softmax row sums on
  *               the VALU | 6 pre-scaled Q with the multiply and the max subtraction kept on the VALU
- *   attn_sp     1 software-pipelined kernel for both head sizes | 3 hd 128 with PV on v_mfma_f32_16x16x32 (3-4 % slower than the default form) | 5 attention_w4.hip with in-place tt = 1 score tiles | 6 / 7 its staging pieces from step 0 / 16 | 100 + bits its timing ablations
+ *   attn_sp     1 software-pipelined kernel for both head sizes | 4 hd 128 on the one-wave-per-SIMD kernel (attention_w4.hip; product key until round 5) | 3 hd 128 with PV on v_mfma_f32_16x16x32 (3-4 % slower than the default form) | 5 attention_w4.hip with in-place tt = 1 score tiles | 6 / 7 its staging pieces from step 0 / 16 | 100 + bits its timing ablations
  */
 #ifndef VIDEOITG_HIP_PROFILING_H
 #define VIDEOITG_HIP_PROFILING_H

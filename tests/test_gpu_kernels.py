@@ -62,8 +62,8 @@ def gemm_cfg(request, ops):
 
 
 # (attn_waves, attn_pipe, attn_dma, attn_sp, attn_ab).  Product: the defaults (hd 72: half-tile-out-of-phase kernel when 256-query blocks fill the
-# chip, else the per-tile loop with LDS-DMA staging; hd 128: 8-wave software-pipelined loop; attn_sp = 4: the one-wave-per-SIMD kernel) and the cross-check sets (per-tile kernels for both head sizes).
-@pytest.fixture(params=[pytest.param((0, 0, 0, 0, 0), id="auto"), pytest.param((0, 0, 0, 2, 2), id="per_tile_kernels"), pytest.param((0, 0, 0, 4, 0), id="hd128_one_wave_per_simd"),
+# chip, else the per-tile loop with LDS-DMA staging; hd 128: 8-wave software-pipelined loop) and the cross-check sets (per-tile kernels for both head sizes).
+@pytest.fixture(params=[pytest.param((0, 0, 0, 0, 0), id="auto"), pytest.param((0, 0, 0, 2, 2), id="per_tile_kernels"), R((0, 0, 0, 4, 0), id="hd128_one_wave_per_simd"),
                         R((4, 0, 2, 2, 2), id="waves4_reg"), R((8, 0, 2, 2, 2), id="waves8_reg"), R((4, 1, 2, 2, 2), id="waves4_pipelined"),
                         R((4, 0, 1, 2, 2), id="waves4_dma"), R((8, 0, 1, 2, 2), id="waves8_dma"), R((4, 0, 0, 1, 2), id="waves4_swpipe"),
                         R((8, 0, 0, 1, 2), id="waves8_swpipe"), R((0, 0, 0, 2, 1), id="half_tile_out_of_phase"),
@@ -356,12 +356,12 @@ def test_product_library_takes_four_option_keys_and_nothing_else(ops):
     from videoitg_amd._lib import VitgError
     if PROF:
         pytest.skip("the profiling library accepts the research knobs by design")
-    for key, val in (("gemm_tile", 128), ("gemm_tile", 256), ("gemm_cfg", 2), ("gemm_cfg", 6), ("gemm_cfg", 9), ("gemm_cfg", 10), ("gemm_cfg", 12), ("attn_ab", 2), ("attn_sp", 2), ("attn_sp", 4)):
+    for key, val in (("gemm_tile", 128), ("gemm_tile", 256), ("gemm_cfg", 2), ("gemm_cfg", 6), ("gemm_cfg", 9), ("gemm_cfg", 10), ("gemm_cfg", 12), ("attn_ab", 2), ("attn_sp", 2)):
         ops.set_option(key, val)
         ops.set_option(key, 0)
     for key, val in (("gemm_flags", 1 << 27), ("gemm_group", 8), ("gemm_mi", 32), ("gemm_mi_modes", 1), ("gemm_pref", 111), ("gemm_wm4", 15), ("gemm_stagger", 1),
                      ("attn_waves", 4), ("attn_dma", 1), ("attn_pipe", 1), ("gemm_cfg", 13), ("gemm_cfg", 3), ("gemm_tile", 64), ("attn_ab", 4), ("attn_ab", 1),
-                     ("attn_sp", 3), ("attn_sp", 1), ("attn_sp", 5), ("attn_sp", 104), ("no_such_key", 1)):
+                     ("attn_sp", 3), ("attn_sp", 1), ("attn_sp", 4), ("attn_sp", 5), ("attn_sp", 104), ("no_such_key", 1)):
         with pytest.raises(VitgError):
             ops.set_option(key, val)
     # the ablation bits of the attention entry (variant >> 4) are refused as before

@@ -31,12 +31,12 @@ def joined(t: torch.Tensor, width: int, d: int) -> torch.Tensor:
     return t[:, :d].double() + t[:, width:width + d].double()
 
 
-def heavy(x: torch.Tensor, cols=(3, 17)) -> torch.Tensor:
+def heavy(x: torch.Tensor, cols=(3, 17), gain=700.0) -> torch.Tensor:
     """a few columns two to three orders above the rest - and many values below fp16's smallest normal lo (|x| < 0.125: lo is subnormal)"""
     x = x.clone()
     for c in cols:
         if c < x.shape[1]:
-            x[:, c] *= 700.0
+            x[:, c] *= gain
     x[:, 1::5] *= 0.01
     return x
 
@@ -97,7 +97,13 @@ def test_bilinear_pool_split(T, G, HW):
     ref = xd if HW == G else torch.nn.functional.interpolate(xd, size=(HW, HW), mode="bilinear", align_corners=False)
     ref = ref.permute(0, 2, 3, 1).reshape(T * HW * HW, D)
     got = joined(out, Dp, D)
-    assert ((got - ref).abs() / ref.abs().amax(-1, keepdim=True).clamp_min(1.0)).max().item() <= KERNEL_REL
+    scale = ref.abs().amax(-1, keepdim=True).clamp_min(1.0)
+    # the interpolation WEIGHTS are fp32 values in the kernel, in ATen's fp32 upsample (what the oracle runs) and in the reference: against the fp64
+    # evaluation that costs ~1e-5 of the row's scale; against the fp32 evaluation of the same expression the split output is exact to fp32 rounding
+    assert ((got - ref).abs() / scale).max().item() <= 5e-5
+    x32 = x.view(T, G, G, D).permute(0, 3, 1, 2)
+    ref32 = (x32 if HW == G else torch.nn.functional.interpolate(x32, size=(HW, HW), mode="bilinear", align_corners=False)).permute(0, 2, 3, 1).reshape(T * HW * HW, D)
+    assert ((got - ref32.double()).abs() / scale).max().item() <= 1e-6
     assert (out[:, D:Dp] == 0).all() and (out[:, Dp + D:] == 0).all()
 
 
@@ -141,7 +147,7 @@ def test_gemm_split16_swiglu_and_f32_consumer():
     from videoitg_amd.torch_ops import K
     torch.manual_seed(11)
     M, D, F = 700, 256, 640
-    x = heavy(torch.randn(M, D, device=DEV))
+    x = heavy(torch.randn(M, D, device=DEV), gain=40.0)            # silu(gate) * up has to stay inside fp16's range, as on the default path
     g, u = (torch.randn(F, D, device=DEV) * D ** -0.5).half(), (torch.randn(F, D, device=DEV) * D ** -0.5).half()
     gu = torch.cat([g.view(F // 32, 1, 32, D), u.view(F // 32, 1, 32, D)], 1).reshape(2 * F, D)       # rows [32 gate | 32 up] (engine.pack_llm_layer)
     down = (torch.randn(D, F, device=DEV) * F ** -0.5).half()
@@ -173,8 +179,9 @@ def test_attention_split(hd, B, H, KV, S, Sk):
     from videoitg_amd.torch_ops import K
     torch.manual_seed(hd + S)
     wq, wk = H * hd, KV * hd
-    q = heavy(torch.randn(B * S, wq, device=DEV), cols=(5, hd + 9)) * 0.5
-    k = heavy(torch.randn(B * Sk, wk, device=DEV), cols=(5, 40)) * 0.5
+    # (scores stay below ~10^2: at |s| ~ 10^4 - two 700x columns meeting - ANY fp32 softmax is 1e-3 off the fp64 one, and so is this one)
+    q = heavy(torch.randn(B * S, wq, device=DEV), cols=(5, hd + 9), gain=12.0) * 0.5
+    k = heavy(torch.randn(B * Sk, wk, device=DEV), cols=(5, 40), gain=12.0) * 0.5
     v = heavy(torch.randn(B * Sk, wk, device=DEV), cols=(7,))
     q2, k2, v2 = split_pair(q, wq), split_pair(k, wk), split_pair(v, wk)
     op = K.pad64(wq)
@@ -204,6 +211,11 @@ def test_attention_split(hd, B, H, KV, S, Sk):
 # ---- the whole forward ----------------------------------------------------------------------------------------------------------------------------
 GOLDEN = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image", "two_images", "two_images_ragged"]
 GOLDEN_LOGIT_TOL = 2e-4        # on fixtures the REFERENCE ITSELF produced (tests/golden/make_golden.py); the fp16 default sits at 1e-3 .. 1e-2 in logit
+# History: the first build of the tier MISSED this bound on chunk520 (4.65e-4, gpurun_out/r06_c4) - which is what exposed the compiler-contraction bug
+# described at ELEM_REL below (one output element in ~10^4 off by an fp16 ulp).  With the values pinned every fixture is at 2e-6 .. 1.3e-5
+# (gpurun_out/r06_c9), the level at which the oracle itself agrees with the reference (<= 9e-6, tests/test_oracle_golden.py).
+GOLDEN_LOGIT_TOL_CASE = {}
+GOLDEN_SCORE_TOL = 2e-5
 
 
 def split_engine(cfg, sd, vsd):
@@ -224,14 +236,16 @@ def test_split_tier_matches_reference_golden(golden_dir, name):
     eng = split_engine(cfg, synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed))
     got = eng.forward(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), images)
     torch.cuda.synchronize()
-    worst = 0.0
+    worst = worst_s = 0.0
     assert len(got) == len(T) or len(got) >= 1
     for b, g in enumerate(got):                       # one logits tensor per SAMPLE
         want = torch.from_numpy(z[f"logits{b}"]).float().view(-1)
         assert g.numel() == want.numel() and torch.isfinite(g).all()
-        worst = max(worst, (g.float().cpu().view(-1) - want).abs().max().item())
-    print(f"operand-split tier vs the reference's golden logits, {name}: max |dlogit| = {worst:.2e}")
-    assert worst <= GOLDEN_LOGIT_TOL, (name, worst)
+        g = g.float().cpu().view(-1)
+        worst = max(worst, (g - want).abs().max().item())
+        worst_s = max(worst_s, (torch.sigmoid(g) - torch.sigmoid(want)).abs().max().item())
+    print(f"operand-split tier vs the reference's golden logits, {name}: max |dlogit| = {worst:.2e}, max |dscore| = {worst_s:.2e}")
+    assert worst <= GOLDEN_LOGIT_TOL_CASE.get(name, GOLDEN_LOGIT_TOL) and worst_s <= GOLDEN_SCORE_TOL, (name, worst, worst_s)
 
 
 def _full_case(golden_dir, name):
@@ -293,3 +307,52 @@ def test_split_tier_refuses_what_it_does_not_cover():
     eng = split_engine(cfg, sd, vsd)
     with pytest.raises(NotImplementedError):
         eng.llm_forward(torch.zeros(8, cfg.hidden_size, device=DEV), kv_len=torch.tensor([4], dtype=torch.int32, device=DEV))
+
+
+# ---- elementwise precision on BENIGN data -----------------------------------------------------------------------------------------------------------
+# The heavy columns above make the error SCALE large, so they cannot see an fp16-sized error in a single ordinary element.  That is exactly what the first
+# build of this tier had: hipcc (-ffp-contract=fast) fused the multiply that produces a value into its two uses differently - the stored hi was
+# cvt(fl32(a * b)), the hi that lo was taken against v_fma_mix_f16(a, b) - and near a tie (hi, lo) summed to x +- ulp(hi): one element in ~10^4 off by
+# exactly 2^-13 .. 2^-17 (tools/r06/split_attn_debug.py).  Every output ELEMENT is therefore held to 2e-5 of the output's rms (the outliers were 1e-3).
+ELEM_REL = 2e-5
+
+
+def _elementwise_ok(got, ref):
+    e = (got - ref).abs().max().item()
+    # (floor: an unscaled lo below 2^-14 is a subnormal with a quantum of 2^-24 - outputs of overall scale ~1e-3 are exact to that, not to 22 bits)
+    return e <= max(ELEM_REL * ref.pow(2).mean().sqrt().item(), 1.2e-7), e
+
+
+@pytest.mark.parametrize("sc", [1.0, 0.05])
+def test_every_output_element_is_fp32_grade_on_benign_data(sc):
+    from videoitg_amd.torch_ops import K
+    torch.manual_seed(5)
+    M, D = 1000, 1152
+    x = torch.randn(M, D, device=DEV) * sc
+    w, b = torch.randn(D, device=DEV), torch.randn(D, device=DEV)
+    out = torch.zeros(M, 2 * D, dtype=torch.float16, device=DEV)
+    K.norm_split(x, w, b, out, D, 1e-6)
+    ok, e = _elementwise_ok(joined(out, D, D), torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6))
+    assert ok, ("layernorm", e)
+    Kd, N = 384, 768
+    a = torch.randn(M, Kd, device=DEV) * sc
+    wt = (torch.randn(N, Kd, device=DEV) * Kd ** -0.5).half()
+    bias = torch.randn(N, device=DEV) * sc
+    a2 = split_pair(a, Kd)
+    o2 = torch.zeros(M, 2 * N, dtype=torch.float16, device=DEV)
+    for act in (0, 1, 2):
+        K.gemm_split16(a2, torch.cat([wt, wt], 1).contiguous(), o2, mode=K.GEMM_STORE16, lo_off=N, bias=bias, act=act)
+        ok, e = _elementwise_ok(joined(o2, N, N), _act(joined(a2, Kd, Kd) @ wt.double().t() + bias.double(), act))
+        assert ok, ("gemm_split16", act, e)
+    for hd, H, KV, S in ((72, 2, 2, 16), (72, 4, 4, 1024), (128, 4, 2, 523), (128, 1, 1, 128), (128, 2, 1, 192)):
+        wq, wk = H * hd, KV * hd
+        q, k, v = torch.randn(S, wq, device=DEV) * sc, torch.randn(S, wk, device=DEV) * sc, torch.randn(S, wk, device=DEV) * sc
+        q2, k2, v2 = split_pair(q, wq), split_pair(k, wk), split_pair(v, wk)
+        op = K.pad64(wq)
+        ob = torch.zeros(S, 2 * op, dtype=torch.float16, device=DEV)
+        K.attention_split(q2, k2, v2, ob, lo=(wq, wk, wk, op), batch=1, heads=H, kv_heads=KV, seq=S, head_dim=hd, q_strides=(0, 2 * wq, hd),
+                          k_strides=(0, 2 * wk, hd), v_strides=(0, 2 * wk, hd), o_strides=(0, 2 * op, hd), scale=hd ** -0.5)
+        ref = _attn_ref(joined(q2, wq, wq).view(1, S, H, hd).transpose(1, 2), joined(k2, wk, wk).view(1, S, KV, hd).transpose(1, 2),
+                        joined(v2, wk, wk).view(1, S, KV, hd).transpose(1, 2), hd ** -0.5).transpose(1, 2).reshape(S, wq)
+        ok, e = _elementwise_ok(joined(ob, op, wq), ref)
+        assert ok, ("attention_split", hd, S, e)

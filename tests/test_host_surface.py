@@ -130,3 +130,24 @@ def test_model_object_survives_accelerate_wrap_on_cpu():
     assert w.config is cfg and w.get_vision_tower().image_processor is not None
     with pytest.raises(RuntimeError, match="no CPU path"):
         w(torch.tensor([[-200, 5]]), attention_mask=None, images=[torch.zeros(2, 3, 56, 56)])
+
+
+def test_written_checkpoint_layout_loads_through_the_directory_reader(tmp_path):
+    """CPU twin of tests/test_gpu_checkpoint.py on the tiny architecture: synth_device.write_hf_checkpoint lays the model out like a release (sharded
+    safetensors + index + config + tokenizer; the SigLIP repo beside it with the 27th-layer / head / text-tower keys the selector never reads) and
+    `_load_directory` + AutoTokenizer get exactly the tensors back - the text tower's poisoned layers (same shapes as the vision layers) never leak."""
+    from videoitg_amd.model.builder import _load_directory
+    from videoitg_amd.synth_device import write_hf_checkpoint
+    cfg = tiny_config()
+    info = write_hf_checkpoint(cfg, str(tmp_path / "ckpt"), str(tmp_path / "siglip"), seed=3, device="cpu", shard_bytes=300_000)
+    assert info["shards"] >= 3 and os.path.exists(tmp_path / "ckpt" / "model.safetensors.index.json")
+    cfg2, sd, vsd = _load_directory(str(tmp_path / "ckpt"))
+    want_l = synth.counter_state_dict(list(synth.llm_param_specs(cfg)), 3)
+    want_v = synth.counter_state_dict(list(synth.vision_param_specs(cfg)), 3)
+    assert cfg2.to_dict()["hidden_size"] == cfg.hidden_size and cfg2.vision.intermediate_size == cfg.vision.intermediate_size
+    assert set(sd) == set(want_l) and all(torch.equal(sd[k].float(), want_l[k]) for k in sd)            # 16-bit exact values: fp16 files lose nothing
+    assert set(want_v) <= set(vsd) and all(torch.equal(vsd[k].float(), want_v[k]) for k in want_v)
+    assert not any("text_model" in k or k.startswith("logit_") for k in vsd)
+    assert any(k.startswith("vision_model.head.") for k in vsd) and "vision_model.post_layernorm.weight" in vsd    # carried, never packed
+    tok, model, proc, ctx = load_pretrained_model(str(tmp_path / "ckpt"), None, "VideoITG-tiny", device_map="cuda:0")
+    assert not isinstance(tok, ByteTokenizer) and len(tok("which frame ?").input_ids) == 3

@@ -34,6 +34,7 @@ def rel(a: torch.Tensor, b: torch.Tensor):
 
 def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "chunk520"
+    split = "split" in sys.argv[2:]              # round 6: the operand-split tier (SelectorEngine(operand_split=True)) instead of the fp16 default
     z = np.load(os.path.join(ROOT, "tests", "golden", f"{case}.npz"))
     cfg = ITGConfig.from_dict(json.loads(str(z["cfg"])))
     seed, T = int(z["seed"]), z["T"].tolist()
@@ -48,6 +49,8 @@ def main():
           f"logit range [{want.min().item():.2f}, {want.max().item():.2f}]")
 
     def engine(res16=True, prescale=None, llm_layers=None, sd_=sd, vsd_=vsd):
+        if split:
+            prescale = False
         pw = PackedWeights(cfg=cfg, dtype=torch.float16, device=torch.device("cuda:0"), vit_q_prescaled=prescale)
         pw.pack_vision_embeddings(vsd_)
         for i in range(cfg.num_vit_layers_needed()):
@@ -55,7 +58,7 @@ def main():
         pw.pack_projector_and_head(sd_)
         for i in range(cfg.num_hidden_layers if llm_layers is None else llm_layers):
             pw.pack_llm_layer(sd_, i)
-        e = SelectorEngine(pw)
+        e = SelectorEngine(pw, operand_split=split)
         e.residual16 = res16
         return e
 
@@ -86,6 +89,8 @@ def main():
     print(f"worst frame {worst}: logit {got[worst].item():.4f} vs oracle {want[worst].item():.4f} (dlogit {abs(got[worst] - want[worst]).item():.2e}); "
           f"sigmoid slope there {(torch.sigmoid(want[worst]) * (1 - torch.sigmoid(want[worst]))).item():.3f}")
 
+    if split:
+        return
     # ---- mechanisms, end to end ---------------------------------------------------------------------------------------------------
     def e2e(tag, e, ref=want):
         g_ = e.forward(ids, mask, dev_images)[0].view(-1).float().cpu()

@@ -470,8 +470,11 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
     if ((q_rs | k_rs | v_rs | o_rs | q_hs | k_hs | v_hs | o_hs) % 4) return VITG_ERR_ALIGN;
     if ((q_rs | k_rs | v_rs | q_hs | k_hs | v_hs) % 8 || (q_bs | k_bs | v_bs) % 8) return VITG_ERR_ALIGN;
     if (dtype != DT_BF16 && dtype != DT_F16) return VITG_ERR_DTYPE;
-    // the shipped kernels stage K / V through 32-bit buffer descriptors (csrc/attn_common.h: lds_dma_rsrc): one (batch, kv head) slice must end below 4 GiB
-    if ((((long)(Sk - 1) * (k_rs > v_rs ? k_rs : v_rs) + head_dim) * 2) >= (1L << 32)) return VITG_ERR_SHAPE;
+    // the shipped kernels stage K / V through 32-bit buffer descriptors with per-lane byte offsets computed in 32-bit SIGNED arithmetic
+    // (csrc/attn_common.h: lds_dma_rsrc; attention_sp.hip / attention_ab.hip: dk_offb + kt * tile bytes): one (batch, kv head) slice - INCLUDING the rows
+    // the last 64-row tile stages past the last key, which must land in the descriptor's zero-filled range and not wrap - has to end below 2 GiB
+    // (the largest slice of the path is 118 MB)
+    if ((((long)((Sk + 63) / 64 * 64 - 1) * (k_rs > v_rs ? k_rs : v_rs) + head_dim) * 2) >= (1L << 31)) return VITG_ERR_SHAPE;
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.o = o;
     a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
@@ -520,17 +523,19 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
         return rc == 0 ? 0 : VITG_ERR_LAUNCH;
     }
 #endif
-    // hd 128: attn_sp = 4 selects the one-wave-per-SIMD kernel (attention_w4.hip) - +4.9 % over the 8-wave software-pipelined kernel when the two
-    // alternate in isolation, but 3.7 % SLOWER inside the step (2.49 against 2.40 ms per launch, step 635.1 against 630.9 ms in same-call alternation of
-    // bench.py, gpurun_out/r05_step_ab): the default stays the 8-wave kernel.  5 / 6 / 7 / 100+ are research forms of the w4 kernel (profiling library).
+    // hd 128, profiling library only since round 6: attn_sp = 4 selects the one-wave-per-SIMD kernel (attention_w4.hip) - +4.9 % over the 8-wave
+    // software-pipelined kernel when the two alternate in isolation, but 3.7 % SLOWER inside the step (2.49 against 2.40 ms per launch, step 635.1 against
+    // 630.9 ms in same-call alternation of bench.py, gpurun_out/r05_step_ab).  It lost its A/B where it runs, so - like every other variant that did - it
+    // left the product library; 5 / 6 / 7 / 100+ are its research forms.
+#if VITG_PROFILING_BUILD
     {
         const int sp = tuning().attn_sp;
-        const bool w4_research = VITG_PROFILING_BUILD && (sp == 5 || sp == 6 || sp == 7 || sp >= 100);
-        if (tr && head_dim == 128 && !a.ablate && (sp == 4 || w4_research)) {
+        if (tr && head_dim == 128 && !a.ablate && (sp == 4 || sp == 5 || sp == 6 || sp == 7 || sp >= 100)) {
             rc = attention_w4_dispatch(a, batch, heads, dtype, sp == 4 ? 0 : sp, s);
             return rc == 0 ? 0 : VITG_ERR_LAUNCH;
         }
     }
+#endif
 #define GO(T, D) (!tr ? launch_attn<T, D, false, 4>(a, batch, heads, s) : nw == 4 ? launch_attn<T, D, true, 4>(a, batch, heads, s) : launch_attn<T, D, true, 8>(a, batch, heads, s))
 #if !VITG_PROFILING_BUILD
     // PRODUCT library: the measured defaults plus ONE cross-check set (attn_sp = 2 / attn_ab = 2: the per-tile kernels of this file).

@@ -39,7 +39,7 @@ __device__ __forceinline__ void lds_dma16(const char* base_uniform, unsigned off
     const uintptr_t pb = (uintptr_t)base_uniform;
     const char* bu = (const char*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pb >> 32)) << 32) | (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pb));      // (unsigned): the builtin returns int
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :: "s"(ldsu), "v"(off), "s"(bu) : "memory");
+                 :: "s"(ldsu), "v"(off), "s"(bu) : "memory", "m0");
 #else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_uniform + off),
                                      (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
@@ -57,7 +57,7 @@ __device__ __forceinline__ u32x4 lds_dma_rsrc(const void* base_uniform, long byt
     return r;
 }
 __device__ __forceinline__ void lds_dma16_buf(const u32x4& rsrc, unsigned lds_dst_uniform, int off) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst_uniform), "v"(off), "s"(rsrc) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst_uniform), "v"(off), "s"(rsrc) : "memory", "m0");
 }
 __device__ __forceinline__ void lds_dma_drain() {
 #if VITG_ASM_DMA

@@ -6,13 +6,13 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS="device gemm gemm256 gemm_mi16 gemm_fp8 attention attention_sp attention_ab attention_w4 elementwise preprocess probe split"
+SRCS="device gemm gemm256 gemm_mi16 gemm_fp8 attention attention_sp attention_ab elementwise preprocess probe split"
 OUT="$HERE/../libvideoitg_hip.so"
 OBJ="$HERE/build"
 DEFS=""
 if [ "${1:-}" = "--profiling" ]; then
   shift
-  SRCS="$SRCS gemm_w4 gemm_wf gemm_pe"
+  SRCS="$SRCS gemm_w4 gemm_wf gemm_pe attention_w4"
   OUT="$HERE/../libvideoitg_hip_prof.so"
   OBJ="$HERE/build_prof"
   DEFS="-DVITG_PROFILING_BUILD=1"

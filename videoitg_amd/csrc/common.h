@@ -126,7 +126,7 @@ struct Tuning {
     int gemm_tile;     // 0 auto | 128 the 128x128 register-staged kernels everywhere (cross-check set) | 256 never the 128-tile kernel where a 256-wide one applies
     int gemm_cfg;      // 0 auto (choose_cfg per shape) | 2 256x128x32 | 6 256x256x64 | 9 256x384x64 | 10 384x256x64 | 12 320x256x64 (SwiGLU / fp32-residual GEMMs; others fall to 256x256) : forces ONE shipped tile shape (tests reach every shipped kernel on small shapes)
     int attn_ab;       // hd 72: 0 auto (half-tile-out-of-phase kernel when 256-query blocks fill the chip) | 2 off (per-tile kernel: cross-check)
-    int attn_sp;       // hd 128: 0 auto (8-wave software-pipelined kernel) | 4 the one-wave-per-SIMD kernel (csrc/attention_w4.hip: faster in isolation, slower in the step) | 2 per-tile kernel (cross-checks)
+    int attn_sp;       // hd 128: 0 auto (8-wave software-pipelined kernel) | 2 per-tile kernel (cross-check)   [4 = the one-wave-per-SIMD kernel, csrc/attention_w4.hip: profiling library only since round 6]
     // ---- research knobs: libvideoitg_hip_prof.so only (include/videoitg_hip_profiling.h) -------------------------------------
     int gemm_flags;    // A/B and ablation bits (see the kernels)
     int gemm_stagger;  // fp32-residual GEMMs in the tile loop: start the tile groups a third of a tile period apart (0 off, 1 = estimated period, > 1 = ns);

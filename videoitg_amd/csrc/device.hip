@@ -26,7 +26,7 @@ static bool product_value_ok(const char* key, int v) {
     if (!strcmp(key, "gemm_tile")) return v == 0 || v == 128 || v == 256;
     if (!strcmp(key, "gemm_cfg")) return v == 0 || v == 2 || v == 6 || v == 9 || v == 10 || v == 12;
     if (!strcmp(key, "attn_ab")) return v == 0 || v == 2;
-    if (!strcmp(key, "attn_sp")) return v == 0 || v == 2 || v == 4;
+    if (!strcmp(key, "attn_sp")) return v == 0 || v == 2;
     return false;
 }
 static int env_product(const char* env, const char* key) { const int v = env_int(env); return (VITG_PROFILING_BUILD || product_value_ok(key, v)) ? v : 0; }

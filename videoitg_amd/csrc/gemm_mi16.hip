@@ -440,6 +440,13 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                             }
                         }
                     }
+                    if constexpr (SPLIT) {
+                        // pin each value as ONE fp32 number: the hi pass and the lo pass are separate copies of this code, and -ffp-contract=fast fuses the
+                        // last multiply / add of the activation into the 16-bit conversion differently per use (v_fma_mix_f16: one rounding of the exact
+                        // product, against cvt(fl32(product))): near a tie the hi this pass subtracts would not be the hi the other pass stored (csrc/split.hip)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float t_ = v[e]; asm volatile("" : "+v"(t_)); v[e] = t_; }
+                    }
                     typename T16<T>::vec4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);

@@ -21,7 +21,11 @@
 namespace vitg {
 
 // (a macro: vector elements cannot bind to references)
-#define SPLIT2(x_, hi_, lo_) do { const float sx_ = (x_); const f16_t sh_ = (f16_t)sx_; (hi_) = sh_; (lo_) = (f16_t)(sx_ - (float)sh_); } while (0)
+// The empty asm pins x as ONE fp32 value in a register.  Without it hipcc (-ffp-contract=fast) fuses the multiply that produces x into each use separately:
+// the stored hi became cvt(fl32(a * b)) - two roundings - while lo was taken against v_fma_mix_f16(a, b, 0) - one rounding of the exact product - and near a
+// tie the two "hi" are different neighbours: (hi, lo) then sums to x +- ulp(hi), an fp16-sized error in one element out of ~10^4 (found by
+// tools/r06/split_attn_debug.py: errors of exactly 2^-13 .. 2^-17 in single output elements).
+#define SPLIT2(x_, hi_, lo_) do { float sx_ = (x_); asm volatile("" : "+v"(sx_)); const f16_t sh_ = (f16_t)sx_; (hi_) = sh_; (lo_) = (f16_t)(sx_ - (float)sh_); } while (0)
 
 // ---- LayerNorm / RMSNorm of fp32 rows -> split rows.  One wave per row, row in registers (D <= 64 * 4 * NV) --------------------------------------
 template <bool RMS, int NV>
@@ -270,6 +274,8 @@ __global__ __launch_bounds__(AS_NW * 64, 2) void attn_split_kernel(AttnSplitArgs
                 for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             m_run = m_new;
         }
+        // P is split as 2^12 p (p <= 1: exact scaling, no overflow): an unscaled lo would be subnormal for every p < 2^-3 and carry an ABSOLUTE quantum of
+        // 2^-25 - against p ~ 1e-4 (flat attention over 12 860 keys) that is 12 bits, not 22.  O accumulates 2^12 sum p V; the epilogue takes the factor out.
         vec8 ph[4], pl[4];
         float psum = 0.f;
 #pragma unroll
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(AS_NW * 64, 2) void attn_split_kernel(AttnSplitArgs
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], a.scale_log2e, -m_run));
                 psum += p;
-                SPLIT2(p, ph[t * 2 + (r >> 3)][r & 7], pl[t * 2 + (r >> 3)][r & 7]);
+                SPLIT2(p * 4096.0f, ph[t * 2 + (r >> 3)][r & 7], pl[t * 2 + (r >> 3)][r & 7]);
             }
         l_run += psum;
         // ---- O^T += Vh^T Ph^T + Vh^T Pl^T + Vl^T Ph^T ------------------------------------------------------------------------------------
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(AS_NW * 64, 2) void attn_split_kernel(AttnSplitArgs
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = (1.0f / l_tot) * (1.0f / 4096.0f);
     const int qrow = q0 + ql;
     if (qrow < a.S) {
         T* op = a.o + b * a.o_bs + (long)head * a.o_hs + (long)qrow * a.o_rs;

@@ -682,7 +682,7 @@ class SelectorEngine:
         H, hd, eps = v.num_attention_heads, v.head_dim, v.layer_norm_eps
         f16 = torch.float16
         if pix.dtype != f16:
-            raise ValueError("the operand-split tier takes fp16 pixel_values (what infer.py:55 hands the model)")
+            pix = pix.to(f16)           # the model's input IS the fp16 tensor (infer.py:55: preprocess(...)["pixel_values"].half()); patches enter the MFMA as they are
         self.vit_stream_bytes = 4
         x = self._buf("vit_x", (M, Dv), torch.float32)
         a0 = K.patchify(pix, v.patch_size, w.patch_w.shape[1], f16)
