@@ -32,6 +32,8 @@ MUST_MATCH_TOPK_FP16 = {"b0_512x384", "c2_512x448", "c1_64x384", "c2p_512x448", 
 # sits above north_star's 1e-3 at the headline size (profiles/r05_heavy_tail.md: the norm statistics are dominated by the planted channels, so their
 # 2^-11 operand rounding reaches every ordinary channel coherently).  (max |dscore|, max |dlogit|) per fixture: the HIP path measured 5.4e-4 / 1.6e-2 and
 # 2.9e-3 / 8.7e-2; oracle/quant_model.py's CPU model of the product's rounding sites 2.3e-2 / 6.9e-2 in logit, of the reference's all-fp16 arithmetic 3.7e-2 / 1.06e-1
+# Round 6: these are KNOWN MISSES of north_star for the 16-bit-operand tiers (c2o: 2.9e-3 > 1e-3), kept as regression bounds ("no worse than measured");
+# SelectorEngine(operand_split=True) meets 1e-3 AND the Top-32 set on both (4e-5 / 1.1e-5; tests/test_gpu_split.py, bounds stated before its first run).
 HEAVY = {"depth16o_224": (1e-3, 3e-2), "c2o_512x448": (5e-3, 1.2e-1)}
 
 
@@ -139,8 +141,9 @@ def test_heavy_tailed_weights_on_both_tower_streams(golden_dir, name):
     """the tower's 16-bit residual stream (default since round 3, eagle/model/builder.py:59's model.half() arithmetic) was
     gated on benign N(0, 1/fan_in) fixtures only.  These fixtures plant massive-activation channels (|x| up to ~1 000 in 4 of 1152 tower channels,
     ~3 000 in 4 of 3584 decoder channels; tests/golden/heavy_tail_plan.json).  What is asserted: (1) the stated bounds of HEAVY on the default
-    stream; (2) the 16-bit stream is not the carrier - the fp32 stream, run beside it, is no better than 0.7x (measured 0.8x / 1.3x: the error
-    enters through the norm statistics on either stream, tools/heavy_tail_stage_diff.py); (3) the Top-K set up to the one boundary pair the
+    stream - round 6: labelled a KNOWN MISS of north_star's 1e-3 at 512 x 448^2 for every 16-bit-operand tier; the tier that holds 1e-3 on these fixtures is
+    the operand-split one (tests/test_gpu_split.py); (2) reported, no longer asserted: the 16-bit stream is not the carrier - the fp32 stream, run beside it,
+    measured 0.8x / 1.3x (the error enters through the norm statistics on either stream, tools/heavy_tail_stage_diff.py); (3) the Top-K set up to the one boundary pair the
     oracle itself separates by less than the tolerance."""
     rec = load_case(golden_dir, name)
     assert rec["heavy_tail"]["row_gain"] >= 32 and rec["checks"]["vit_absmax"] > 100 and rec["checks"]["llm_absmax"] > 100
@@ -156,7 +159,8 @@ def test_heavy_tailed_weights_on_both_tower_streams(golden_dir, name):
     ds, dl, same, kept = res[True]
     tol_s, tol_l = HEAVY[name]
     assert ds <= tol_s and dl <= tol_l, res
-    assert res[False][1] >= 0.7 * dl, res                # the fp32 tower stream would not buy the bound back
+    # (reported, not asserted - ADVICE r5: a genuine accuracy gain of the fp32 stream must not fail the suite; measured 0.8x / 1.3x of the default)
+    print(f"heavy-tailed {name}: fp32 tower stream / 16-bit tower stream logit error = {res[False][1] / max(dl, 1e-30):.2f}x")
     if rec["gap_k_k1"] is None or rec["gap_k_k1"] > 2 * tol_s:
         assert same, res
     else:           # the oracle's own rank-K / K+1 gap (1.5e-4 at 512 frames) is inside the tolerance: at most the boundary pair may swap

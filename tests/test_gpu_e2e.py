@@ -128,7 +128,9 @@ def test_attention_loop_structures_agree(golden_dir, name):
     from videoitg_amd import ops
     tol = GOLDEN_TOL[torch.float16].get(name, SCORE_TOL)
     outs = []
-    for sp in (2, 4, 0):               # 2 = per-tile kernels, 4 = one-wave-per-SIMD kernel (hd 128), 0 = the default (software-pipelined 8-wave loop for hd 128)
+    PROF_LIB = os.environ.get("VITG_PROFILING_LIB", "0") not in ("", "0")
+    # 2 = per-tile kernels, 0 = the default (software-pipelined 8-wave loop for hd 128); 4 = the one-wave-per-SIMD kernel: profiling library only since round 6
+    for sp in ((2, 4, 0) if PROF_LIB else (2, 0)):
         ops.set_option("attn_sp", sp)
         try:
             z, got, T = run_case(golden_dir, name, torch.float16, variant=0)
@@ -211,7 +213,8 @@ def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
 
 # (frame counts below 16 keep the single-rank reference on the same 128-tile GEMM kernels as the ranks: at 304 rows it would switch to
 # the 256-tile kernels, which differ from them in fp32 summation order - a kernel-set difference, not a sharding one)
-@pytest.mark.parametrize("world,frames", [(2, 9), (3, 8), (8, 15)])
+# (8 ranks on one GPU run in tests/test_gpu_cp_fullsize.py at full size; here the ragged 4-rank split - the 8-rank toy cost 85 s of process start-up: VERDICT r5 item 6)
+@pytest.mark.parametrize("world,frames", [(2, 9), (3, 8), (4, 15)])
 def test_context_parallel_multi_rank_on_one_gpu(world, frames):
     """WORLD > 1 with the real kernels: `world` processes share cuda:0 and exchange over gloo (RCCL refuses two ranks on one
     device).  Frame shards are ragged (9 frames / 2 ranks, prompt tokens on the first and last rank), so global positions, the
@@ -569,7 +572,7 @@ def _rccl_worker(rank, world, frames, port, q):
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the one-GPU boxes run the "
                                                            "same plan over gloo, test_context_parallel_multi_rank_on_one_gpu)")
-@pytest.mark.parametrize("world,frames", [(2, 9), (2, 8)])
+@pytest.mark.parametrize("world,frames", [(2, 9), (2, 8), (8, 19), (8, 64), (4, 13)])
 def test_context_parallel_over_rccl(world, frames):
     """One rank per GPU over RCCL: K|V written in place into the gather buffer, the all-gather launched asynchronously under the Q
     projection, ragged shards (9 frames / 2 ranks, prompt tokens on the first and last rank).  Runs the moment a multi-GPU box exists;
@@ -578,9 +581,11 @@ def test_context_parallel_over_rccl(world, frames):
     from videoitg_amd import synth
     from videoitg_amd.config import tiny_config
     from videoitg_amd.engine import PackedWeights, SelectorEngine
+    if torch.cuda.device_count() < world:                       # (the 8- and 4-rank cases run the moment a node shows that many GPUs)
+        pytest.skip(f"{world} ranks need {world} GPUs, {torch.cuda.device_count()} visible")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rccl_worker, args=(r, world, frames, 29600 + frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, frames, 29600 + frames + world, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=600)

@@ -479,7 +479,9 @@ def test_gemm_splitk_matches_plain_gemm_and_is_deterministic(ops, dtype, M, N, K
     assert torch.equal(outs[0], outs[1])
     assert (outs[0] - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
     sp, nb = ops.gemm_splitk_plan(1660, 3584, 18944)
-    assert sp == 3 and nb == 3 * 1660 * 3584 * 4
+    # (the split count follows from the device's CU count - 84 tiles of 320 x 256 on 256 CUs plan 3 - so only its consistency is asserted: ADVICE r5)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert 2 <= sp <= 8 and nb == sp * 1660 * 3584 * 4 and (cus != 256 or sp == 3)
     assert ops.gemm_splitk_plan(12860, 3584, 18944)[0] == 1 and ops.gemm_splitk_plan(1660, 3584, 1152)[0] == 1
 
 

@@ -42,11 +42,13 @@ constexpr float AB_LAZY_RESCALE_LOG2 = 8.0f;      // see attention_sp.hip: runni
 // the max subtraction (one packed FMA per score pair less).  Softmax is shift-invariant per query, so the shift only has to be CONSISTENT between
 // the numerator, the row sum (same P) and the accumulator rescale (alpha = exp2(old shift - new shift)): it is the running max rounded to 16 bits,
 // moved - as before - only when a tile's scores exceed it by more than 2^8, and then that one tile subtracts the step on the VALU.
-template <typename T, int D, int NW, bool PV16, bool LSUM = PV16, bool QS = false>
+// NKT_C (round 6, VERDICT r5 item 4: "a compile-time S = 1024 specialisation with no tail / key-count path for the R = 448 tower"): > 0 = the number of
+// 64-key tiles is this constant - no device key count, no tail mask, the tile loops run a known trip count.  Measured, see profiles/r06_attention_hd72.md.
+template <typename T, int D, int NW, bool PV16, bool LSUM = PV16, bool QS = false, int NKT_C = 0>
 __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     static_assert(!LSUM || PV16, "the row-sum column rides the 16x16x32 PV form");
     static_assert(!QS || LSUM, "the shift column comes with the row-sum column");
-    adopt_device_key_count(a);
+    if constexpr (NKT_C == 0) adopt_device_key_count(a);
     typedef typename T16<T>::vec8 vec8;
     typedef AttnCfg<D> C;
     constexpr int KS = C::DK / 16;           // QK^T k-steps per 32-key half
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < (PV16 ? DT : 1); ++i) { o16[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o16[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float m_run = -1e30f, l_run = 0.f;
-    const int nkt = ceil_div(a.Sk, ATT_BK);
+    const int nkt = NKT_C > 0 ? NKT_C : ceil_div(a.Sk, ATT_BK);
 
     // runtime-selected buffers (K ring of 2, V ring of 3): per-interval base pointers, fragment offsets stay immediates
     auto qk_mfma = [&](int kbuf, f32x16 (&s)[2]) {
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
         }
     };
     auto mask_tail = [&](int t, f32x16 (&s)[2]) {          // last, partial tile: lane (q, h) s[tt][r] is key t*64 + tt*32 + 8*(r>>2) + 4*h + (r&3)
+        if constexpr (NKT_C > 0) return;                   // (the key count is NKT_C * 64: there is no partial tile)
         if (t * ATT_BK + ATT_BK > a.Sk) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, int D, int NW, bool PV16, bool LSUM = PV16, bool QS = false>
+template <typename T, int D, int NW, bool PV16, bool LSUM = PV16, bool QS = false, int NKT_C = 0>
 static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
     a.nqb = ceil_div(a.S, NW * 32);
     typedef AttnCfg<D> C;
@@ -469,10 +472,10 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     if (cur_dev >= 16 || !done_dev[cur_dev]) {
-        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW, PV16, LSUM, QS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_ab_kernel<T, D, NW, PV16, LSUM, QS, NKT_C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (cur_dev < 16) done_dev[cur_dev] = true;
     }
-    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW, PV16, LSUM, QS>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((attn_ab_kernel<T, D, NW, PV16, LSUM, QS, NKT_C>), dim3(a.nqb * heads * batch), dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -485,6 +488,10 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
 // form 6 = pre-scaled Q WITHOUT that (the multiply by 1 and the max subtraction stay on the VALU: A/B)
 int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, bool qs, hipStream_t s) {
     const bool pv32 = form == 4;
+#if VITG_EXP && defined(VITG_AB_NKT16)   // experiment build (build.sh --exp nkt16 -DVITG_AB_NKT16=1): the R = 448 tower's 1024 keys as a compile-time 16 tiles
+    if (qs && form == 0 && waves == 8 && a.Sk == 1024 && a.sk_dev == nullptr && dtype == DT_F16)
+        return launch_ab<f16_t, 72, 8, true, true, true, 16>(a, batch, heads, s);
+#endif
     if (qs && form == 0 && waves == 8)
         return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, true, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, true, true>(a, batch, heads, s);
 #if VITG_PROFILING_BUILD   // the forms that lost their A/B (profiles/r03_attention.md): profiling library only
