@@ -810,3 +810,29 @@ def test_engine_default_paths_against_their_unfused_forms():
     print(f"fp8 tower vs 16-bit tower: rms error {ea:.3e} on the 16-bit stream, {eb:.3e} on the fp32 stream (signal rms {rms(fused):.3e})")
     assert ea <= 1.25 * eb and eb <= 1.25 * ea and ea <= 0.1 * rms(fused)
     assert rms(a - b) <= 1.6 * max(ea, eb)
+
+
+def test_hd72_compile_time_tile_count_form_is_bit_identical(ops):
+    """round 6: 1024 keys (the 32 x 32 grid of the R = 448 tower) run attn_ab_kernel with a COMPILE-TIME 16 tiles (no device key count, no tail mask).
+    The same call through vitg_attention_dyn - key count in device memory - takes the run-time form of the same kernel: the two must agree in every bit,
+    and both with the per-tile cross-check kernel to 16-bit rounding."""
+    if PROF:
+        pytest.skip("product dispatch")
+    torch.manual_seed(7)
+    B, H, S, D = 6, 16, 1024, 72
+    ld = 3 * H * D
+    qkv = (torch.randn((B * S, ld), device="cuda") * 0.7).half()
+    kw = dict(batch=B, heads=H, kv_heads=H, seq=S, head_dim=D, q_strides=(S * ld, ld, D), k_strides=(S * ld, ld, D), v_strides=(S * ld, ld, D),
+              o_strides=(S * H * D, H * D, D), scale=1.0, variant=2)          # variant bit 1: q arrives pre-scaled (the tower's default form)
+    o_fixed = torch.zeros((B * S, H * D), dtype=torch.float16, device="cuda")
+    o_dyn = torch.zeros_like(o_fixed)
+    ops.attention(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o_fixed, **kw)
+    ops.attention(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o_dyn, kv_len=torch.tensor([S], dtype=torch.int32, device="cuda"), **kw)
+    assert torch.equal(o_fixed, o_dyn)
+    ops.set_option("attn_ab", 2)
+    try:
+        o_tile = torch.zeros_like(o_fixed)
+        ops.attention(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o_tile, **kw)
+    finally:
+        ops.set_option("attn_ab", 0)
+    assert (o_fixed.float() - o_tile.float()).abs().max().item() <= 4e-3

@@ -43,7 +43,8 @@ constexpr float AB_LAZY_RESCALE_LOG2 = 8.0f;      // see attention_sp.hip: runni
 // the numerator, the row sum (same P) and the accumulator rescale (alpha = exp2(old shift - new shift)): it is the running max rounded to 16 bits,
 // moved - as before - only when a tile's scores exceed it by more than 2^8, and then that one tile subtracts the step on the VALU.
 // NKT_C (round 6, VERDICT r5 item 4: "a compile-time S = 1024 specialisation with no tail / key-count path for the R = 448 tower"): > 0 = the number of
-// 64-key tiles is this constant - no device key count, no tail mask, the tile loops run a known trip count.  Measured, see profiles/r06_attention_hd72.md.
+// 64-key tiles is this constant - no device key count, no tail mask, the tile loops run a known trip count (+3.3 % on the launch inside the step:
+// profiles/r06_attention_hd72.md).  Bit-identical to the run-time form.
 template <typename T, int D, int NW, bool PV16, bool LSUM = PV16, bool QS = false, int NKT_C = 0>
 __global__ __launch_bounds__(NW * 64, 4) void attn_ab_kernel(AttnArgs a) {
     static_assert(!LSUM || PV16, "the row-sum column rides the 16x16x32 PV form");
@@ -488,10 +489,11 @@ static int launch_ab(AttnArgs a, int batch, int heads, hipStream_t s) {
 // form 6 = pre-scaled Q WITHOUT that (the multiply by 1 and the max subtraction stay on the VALU: A/B)
 int attention_ab_dispatch(const AttnArgs& a, int batch, int heads, int dtype, int waves, int form, bool qs, hipStream_t s) {
     const bool pv32 = form == 4;
-#if VITG_EXP && defined(VITG_AB_NKT16)   // experiment build (build.sh --exp nkt16 -DVITG_AB_NKT16=1): the R = 448 tower's 1024 keys as a compile-time 16 tiles
-    if (qs && form == 0 && waves == 8 && a.Sk == 1024 && a.sk_dev == nullptr && dtype == DT_F16)
-        return launch_ab<f16_t, 72, 8, true, true, true, 16>(a, batch, heads, s);
-#endif
+    // round 6: 1024 keys - the 32 x 32 grid of the R = 448 tower, BASELINE configs[1] - as a compile-time 16 tiles: no device key
+    // count, no tail-mask test per tile, a known trip count.  Same-call alternation inside the step, three rounds (gpurun_out/r06_attn72/ab.txt): 2.946 / 2.952 /
+    // 2.963 -> 2.851 / 2.855 / 2.864 ms per launch (+3.3 %, 0.335 -> 0.347 of peak), step 631.3 / 633.0 / 632.7 -> 629.3 / 630.6 / 631.6 ms; bit-identical.
+    if (qs && form == 0 && waves == 8 && a.Sk == 16 * ATT_BK && a.sk_dev == nullptr)
+        return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, true, true, 16>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, true, true, 16>(a, batch, heads, s);
     if (qs && form == 0 && waves == 8)
         return dtype == DT_BF16 ? launch_ab<bf16_t, 72, 8, true, true, true>(a, batch, heads, s) : launch_ab<f16_t, 72, 8, true, true, true>(a, batch, heads, s);
 #if VITG_PROFILING_BUILD   // the forms that lost their A/B (profiles/r03_attention.md): profiling library only
