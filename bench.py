@@ -303,23 +303,35 @@ class Watchdog:
             self._t = None
 
 
-def first_step_with_overlap_fallback(step, eng, any_rank_failed):
+def first_step_with_overlap_fallback(step, eng, any_rank_failed, collectives_started=lambda: 0, _abort=None):
     """The context-parallel layers launch their K|V all-gather asynchronously from a side stream (engine.llm_forward, parallel.RowGatherer.start).
-    That path has met RCCL on ONE rank only; if its first step raises on ANY rank, every rank falls back to the blocking exchange
-    (eng.cp_overlap = False, what VITG_CP_OVERLAP=0 selects) and says so in the JSON line.  `any_rank_failed(bool) -> bool` is the
-    agreement (an all-reduce MAX over ranks).  -> None, or the reason of the fallback."""
+    That path has met RCCL on ONE rank only.  If the first step raises BEFORE this rank has started any exchange (set-up, argument validation - the
+    failures every rank sees alike), all ranks agree (`any_rank_failed(bool) -> bool`, an all-reduce MAX) to fall back to the blocking exchange
+    (eng.cp_overlap = False, what VITG_CP_OVERLAP=0 selects) and the JSON line says so.  If it raises AFTER an exchange was started, the peers are
+    inside a collective this rank has left: an agreement all-reduce would be queued behind a gather that can never complete (and a HIP error is sticky,
+    so a retried step would fail again) - the rank ends the job with a clear message instead; its peers end through VITG_DIST_TIMEOUT_S /
+    the bench Watchdog.  -> None, or the reason of the fallback."""
     err = None
     try:
         step()
     except Exception as e:                                        # noqa: BLE001 - whatever the async path raised is the reason
         err = f"{type(e).__name__}: {e}"
+        if collectives_started() > 0:
+            msg = (f"bench.py: the context-parallel step failed AFTER {collectives_started()} K|V exchange(s) had been started on this rank ({err}); the peer "
+                   f"ranks are inside a collective this rank has left, so no agreement is possible - ending the job (rerun with VITG_CP_OVERLAP=0 for the "
+                   f"blocking exchange)")
+            if _abort is not None:
+                return _abort(msg)
+            sys.stderr.write(msg + "\n")
+            sys.stderr.flush()
+            os._exit(125)
     if not any_rank_failed(err is not None):
         return None
     if not getattr(eng, "cp_overlap", False):
         raise RuntimeError(f"context-parallel step failed with the blocking exchange too: {err}")
     eng.cp_overlap = False
     step()                                                        # must work on every rank now; an exception here ends the job loudly
-    return err or "another rank's first step failed on the asynchronous exchange"
+    return err or "another rank's first step failed before its first exchange"
 
 
 def parity_block(T, R, prompt_len, seed, logits, order, tol=1e-3):
@@ -893,7 +905,8 @@ def main():
             flag = torch.tensor([1 if mine else 0], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             return bool(flag.item())
-        cp_fallback = first_step_with_overlap_fallback(step, eng, any_rank_failed)
+        from videoitg_amd.parallel import RowGatherer
+        cp_fallback = first_step_with_overlap_fallback(step, eng, any_rank_failed, collectives_started=lambda: RowGatherer.launched)
     dog.phase("warm-up")
     for _ in range(args.warmup):
         step()

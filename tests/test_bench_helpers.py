@@ -149,6 +149,15 @@ def test_first_step_falls_back_to_the_blocking_exchange_on_every_rank():
         raise ValueError("boom")
     with pytest.raises(RuntimeError, match="blocking exchange too"):
         bench.first_step_with_overlap_fallback(always, eng, lambda mine: mine)
+    # a failure AFTER this rank started an exchange cannot be agreed upon (the peers sit in a collective this rank left): no all-reduce, no
+    # retry - the rank ends the job with a message naming the way out
+    eng = Eng()
+    said = []
+    agreed = []
+    out = bench.first_step_with_overlap_fallback(step_async_breaks, eng, lambda mine: agreed.append(mine) or mine, collectives_started=lambda: 3,
+                                                 _abort=lambda msg: said.append(msg) or "aborted")
+    assert out == "aborted" and agreed == [] and eng.cp_overlap is True
+    assert "AFTER 3 K|V exchange" in said[0] and "VITG_CP_OVERLAP=0" in said[0]
 
 
 def test_algorithmic_gemm_bytes_of_the_headline_workload():

@@ -70,6 +70,8 @@ class RowGatherer:
     all-gather (RCCL: asynchronous, ordered after the work already queued on the current stream) and ``finish(w)`` makes the current
     stream wait for it and returns all rows (ragged shards: ONE gather-rows launch compacts the padded receive buffer)."""
 
+    launched = 0          # exchanges started in this process (bench.py: a failure AFTER the first one cannot be agreed upon with collectives any more)
+
     def __init__(self, plan: ShardPlan, rank: int, group=None):
         self.plan, self.rank, self.group = plan, rank, group
         self.n_max = max(plan.n_local)
@@ -100,6 +102,7 @@ class RowGatherer:
         the current stream; other backends (gloo in the CPU / one-GPU tests) exchange in finish()."""
         if self._async is None:
             self._async = dist.get_backend(self.group) == "nccl"
+        RowGatherer.launched += 1
         if self._async:
             return dist.all_gather_into_tensor(self._recv, self._slot(), group=self.group, async_op=True)
         return None
