@@ -32,25 +32,13 @@ def _mod():
 
 
 _SINGLE = {}
-_WEIGHTS = {}
-
-
-def weights_of(case, fp8=None):
-    """ONE copy of a fixture's packed model on cuda:0, mapped by every rank process through IPC and used by the one-GPU forward too (round 6: drawing
-    the 7.6 B parameters once per RANK was half of each 8-rank run).  Only the latest model stays resident."""
-    key = (case, fp8)
-    if key not in _WEIGHTS:
-        _WEIGHTS.clear()
-        torch.cuda.empty_cache()
-        _WEIGHTS[key] = _mod().build_weights(case, fp8)
-    return _WEIGHTS[key]
 
 
 def single_gpu(case):
     """the one-GPU forward of a fixture's video (computed once per case)"""
     if case not in _SINGLE:
         torch.cuda.empty_cache()
-        _SINGLE[case] = _mod().single_gpu_logits(case, weights=weights_of(case))
+        _SINGLE[case] = _mod().single_gpu_logits(case)
     return _SINGLE[case]
 
 
@@ -64,7 +52,7 @@ def test_context_parallel_full_size_meets_oracle(world, case):
     rec = mod.load_case(case)
     ref1 = single_gpu(case)
     torch.cuda.empty_cache()
-    got, forms = mod.run(world, case, port=29560 + world + (0 if case == CASE else 20 if case.startswith("b0") else 40), weights=weights_of(case))
+    got, forms = mod.run(world, case, port=29560 + world + (0 if case == CASE else 20 if case.startswith("b0") else 40))
     rep = mod.report(case, got, ref1)
     print(f"context-parallel x{world} on {case}, full model: {rep}; rows per rank {forms['n_local']}; split-K shapes {forms['splitk']}")
     assert got.shape == (rec["frames"],) and torch.isfinite(got).all()
@@ -96,7 +84,7 @@ def test_context_parallel_on_heavy_tailed_weights():
     rec = mod.load_case(case)
     ref1 = single_gpu(case)
     torch.cuda.empty_cache()
-    got, forms = mod.run(4, case, port=29575, weights=weights_of(case))             # (4 ranks since round 6: what is tested is the amplified re-association, not the rank count)
+    got, forms = mod.run(4, case, port=29575)             # (4 ranks since round 6: what is tested is the amplified re-association, not the rank count)
     rep = mod.report(case, got, ref1)
     print(f"context-parallel x4 on {case} (heavy-tailed weights): {rep}")
     assert got.shape == (rec["frames"],) and torch.isfinite(got).all()
@@ -110,8 +98,8 @@ def test_context_parallel_full_size_fp8_llm_mlp():
     8-way context-parallel forward against the oracle at the tier's own bound, and against the same tier on one GPU."""
     mod = _mod()
     torch.cuda.empty_cache()
-    got, forms = mod.run(8, CASE, fp8=FP8_POLICY, port=29571, weights=weights_of(CASE, FP8_POLICY))
-    single = mod.single_gpu_logits(CASE, fp8=FP8_POLICY, weights=weights_of(CASE, FP8_POLICY))      # (the fp8 tier's own one-GPU forward)
+    got, forms = mod.run(8, CASE, fp8=FP8_POLICY, port=29571)
+    single = mod.single_gpu_logits(CASE, fp8=FP8_POLICY)      # (the fp8 tier's own one-GPU forward)
     rep = mod.report(CASE, got, single)
     print(f"context-parallel x8 fp8 {FP8_POLICY}: {rep}")
     assert torch.isfinite(got).all()

@@ -36,18 +36,7 @@ def parse_fp8(fp8):
     return fp8
 
 
-def build_weights(case: str, fp8=None):
-    """the packed counter-generated weights of a fixture's model, on cuda:0"""
-    from videoitg_amd import synth
-    from videoitg_amd.config import ITGConfig
-    from videoitg_amd.synth_device import packed_random_weights
-    rec = load_case(case)
-    return packed_random_weights(ITGConfig(), torch.float16, torch.device("cuda:0"), seed=rec["weight_seed"], fp8=parse_fp8(fp8), plan=synth.fixture_plan(rec))
-
-
-def worker(rank: int, world: int, port: int, case: str, fp8, q, weights=None) -> None:
-    """weights: the parent's PackedWeights, arriving as IPC handles of its device tensors (round 6: the `world` ranks of one box share ONE copy of the
-    15 GB model instead of generating eight - the generation was half of an 8-rank run's 39 s); None = this rank draws its own"""
+def worker(rank: int, world: int, port: int, case: str, fp8, q) -> None:
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -57,10 +46,11 @@ def worker(rank: int, world: int, port: int, case: str, fp8, q, weights=None) ->
         from videoitg_amd.config import ITGConfig
         from videoitg_amd.engine import SelectorEngine
         from videoitg_amd.parallel import ContextParallel
+        from videoitg_amd.synth_device import packed_random_weights
         rec = load_case(case)
         cfg = ITGConfig()
         dev = torch.device("cuda:0")
-        eng = SelectorEngine(weights if weights is not None else build_weights(case, fp8))
+        eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=parse_fp8(fp8), plan=synth.fixture_plan(rec)))
         ids, pix = synth.fixture_inputs(cfg, rec)
         T = rec["frames"]
         cp = ContextParallel(rank, world)
@@ -79,51 +69,35 @@ def worker(rank: int, world: int, port: int, case: str, fp8, q, weights=None) ->
         dist.destroy_process_group()
 
 
-def run(world: int = 8, case: str = "c2_512x448", fp8=None, port: int = 29561, timeout: int = 900, weights=None):
-    """-> (logits fp32 [T] gathered on rank 0, {"splitk": [((M, N, K), splits), ...], "n_local": rows per rank}).
-    weights: a PackedWeights on cuda:0 (build_weights) that every rank maps through IPC instead of drawing its own; if the ranks cannot map it (an
-    IPC-less driver) the run is repeated with per-rank weights."""
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (the only form this driver supports)
-    share = weights is not None and os.environ.get("VITG_CP_SHARE_WEIGHTS", "1") not in ("", "0")
-    for attempt in ((True, False) if share else (False,)):
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, world, port + (0 if attempt == share else 50), case, fp8, q, weights if attempt else None)) for r in range(world)]
+def run(world: int = 8, case: str = "c2_512x448", fp8=None, port: int = 29561, timeout: int = 900):
+    """-> (logits fp32 [T] gathered on rank 0, {"splitk": [((M, N, K), splits), ...], "n_local": rows per rank})"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, case, fp8, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got, forms = q.get(timeout=timeout)
+        got = torch.tensor(got, dtype=torch.float32)
+    finally:
         for p in procs:
-            p.start()
-        got = None
-        try:
-            import queue as _queue
-            waited = 0
-            while waited < timeout:
-                try:
-                    got, forms = q.get(timeout=5)
-                    break
-                except _queue.Empty:
-                    waited += 5
-                    if any(p.exitcode not in (None, 0) for p in procs):      # a rank died (e.g. it could not map the shared weights)
-                        break
-        finally:
-            for p in procs:
-                p.join(timeout if got is not None else 20)
-                if p.is_alive():
-                    p.kill()
-        if got is not None and all(p.exitcode == 0 for p in procs):
-            return torch.tensor(got, dtype=torch.float32), forms
-        if not attempt:
-            break
-        print("cp_full_one_gpu: the ranks could not share the parent's weights over IPC - repeating with per-rank weights", flush=True)
-    raise AssertionError([p.exitcode for p in procs])
+            p.join(timeout)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        assert p.exitcode == 0, p.exitcode
+    return got, forms
 
 
-def single_gpu_logits(case: str = "c2_512x448", fp8=None, weights=None) -> torch.Tensor:
+def single_gpu_logits(case: str = "c2_512x448", fp8=None) -> torch.Tensor:
     from videoitg_amd import synth
     from videoitg_amd.config import ITGConfig
     from videoitg_amd.engine import SelectorEngine
+    from videoitg_amd.synth_device import packed_random_weights
     rec = load_case(case)
     cfg = ITGConfig()
     dev = torch.device("cuda:0")
-    eng = SelectorEngine(weights if weights is not None else build_weights(case, fp8))
+    eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=parse_fp8(fp8), plan=synth.fixture_plan(rec)))
     ids, pix = synth.fixture_inputs(cfg, rec)
     out = eng.forward(ids, None, [pix.to(torch.float16).to(dev)])[0].view(-1).float().cpu()
     torch.cuda.synchronize()
@@ -151,9 +125,8 @@ if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     case = sys.argv[2] if len(sys.argv) > 2 else "c2_512x448"
     fp8 = sys.argv[3] if len(sys.argv) > 3 else None
-    pw = build_weights(case, fp8)
-    got, forms = run(world, case, fp8, weights=pw)
-    single = single_gpu_logits(case, fp8, weights=pw)
+    got, forms = run(world, case, fp8)
+    single = single_gpu_logits(case, fp8)
     rep = report(case, got, single)
     rep.update(world=world, fp8=fp8 or False, rows_per_rank=forms["n_local"], splitk_shapes=[list(s[0]) + [s[1]] for s in forms["splitk"]])
     print(json.dumps(rep), flush=True)
