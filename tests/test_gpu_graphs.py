@@ -126,9 +126,14 @@ def test_batch_of_eight_videos_through_one_capture_at_the_headline_workload(gold
     cache = GraphCache(eng, bucket=64)
     videos = [(rec["pixel_seed"], rec["prompt_len"])] + [(5000 + 17 * i, L) for i, L in enumerate((33, 64, 41, 57, 36, 49, 62))]
     seen = []
-    for seed, L in videos:
-        ids, pix = synth.workload_inputs(cfg, rec["frames"], rec["resolution"], L, pix_seed=seed)
-        pix = pix.half().cuda()
+    for vi, (seed, L) in enumerate(videos):
+        if vi == 0:                                      # the fixture video: the oracle's own inputs
+            ids, pix = synth.workload_inputs(cfg, rec["frames"], rec["resolution"], L, pix_seed=seed)
+            pix = pix.half().cuda()
+        else:                                            # seven other documents: own prompt, own pixels drawn on the device (the seeded low-pass CPU
+            ids = torch.cat([torch.tensor([-200]), synth.synth_prompt_ids(L, cfg.vocab_size, seed=seed)]).unsqueeze(0)      # generator cost 3 s per video)
+            g = torch.Generator(device="cuda").manual_seed(seed)
+            pix = torch.empty((rec["frames"], 3, rec["resolution"], rec["resolution"]), device="cuda").uniform_(-1.0, 1.0, generator=g).half()
         want = eng.forward(ids, None, [pix])[0].view(-1).clone()
         got = cache(ids.view(-1), pix).clone()
         assert torch.isfinite(got).all() and torch.equal(got, want), (seed, L, (got - want).abs().max().item())
