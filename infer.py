@@ -74,13 +74,17 @@ def main():
                                         "Knight; D. Oppenheimer; E. Dune \n Please respond with only the letter of the correct answer.")
     ap.add_argument("--topk", type=int, default=32)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--operand-split", action="store_true",
+                    help="this build's precision tier: every MFMA operand as an fp16 (hi, lo) pair - scores within ~1e-5 of the reference's fp32 CPU path on any "
+                         "16-bit checkpoint, 2.4x the time (fp16 only; profiles/r06_operand_split.md)")
     ap.add_argument("--save-dir", default="./vis", help="where the selected frames are written as JPEGs (infer.py:81-94); '' = do not save")
     ap.add_argument("--num-frames", type=int, default=0, help="frames to sample (reference: 512; default 32 for synthetic:tiny, whose "
                                                               "72-token visual budget pools 512 frames down to nothing)")
     a = ap.parse_args()
     num_frm = a.num_frames or (32 if a.model.startswith("synthetic:tiny") or a.model == "synthetic" else 512)
     dtype = torch.float16 if a.dtype == "fp16" else torch.bfloat16
-    tok, model, proc, _ = load_pretrained_model(a.model, None, get_model_name_from_path(a.model), device_map="cuda:0", torch_dtype=dtype)
+    tok, model, proc, _ = load_pretrained_model(a.model, None, get_model_name_from_path(a.model), device_map="cuda:0", torch_dtype=dtype,
+                                                operand_split=True if a.operand_split else None)
     model.eval().to(DEVICE)
     selected, _ = topk_selection(model, tok, proc, a.prompt, a.video, min(a.topk, num_frm), dtype, num_frm)
     print(selected)

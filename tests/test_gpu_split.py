@@ -356,3 +356,27 @@ def test_every_output_element_is_fp32_grade_on_benign_data(sc):
                         joined(v2, wk, wk).view(1, S, KV, hd).transpose(1, 2), hd ** -0.5).transpose(1, 2).reshape(S, wq)
         ok, e = _elementwise_ok(joined(ob, op, wq), ref)
         assert ok, ("attention_split", hd, S, e)
+
+
+def test_operand_split_through_the_operator_surface():
+    """the tier is ONE switch on the reference-side surface: load_pretrained_model(..., operand_split=True) -> model(...).logits as infer.py:15-21,60-72 uses
+    it, against the oracle on the same weights and inputs; the default model on the same call is the fp16 tier (further away)"""
+    from oracle import videoitg_oracle as O                          # checker
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.model.builder import load_pretrained_model
+    cfg = tiny_config()
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    pix = synth.synth_pixel_values(8, cfg.vision.image_size, seed=1234)
+    ids = torch.tensor([[-200, 5, 6, 7, 8, 9]])
+    want = O.forward(cfg, sd, vsd, ids, None, [pix])[0].view(-1)
+    errs = {}
+    for split in (True, False):
+        tok, model, proc, ctx = load_pretrained_model("synthetic:tiny:0", None, "VideoITG-tiny", device_map="cuda:0", operand_split=split)
+        model = model.half().eval()
+        assert model.operand_split is split
+        got = model(ids, attention_mask=torch.ones_like(ids).bool(), images=[pix.half().to(DEV)]).logits[0].view(-1).float().cpu()
+        assert model.engine().operand_split is split
+        errs[split] = (got - want).abs().max().item()
+    print(f"operator surface: operand_split max|dlogit| = {errs[True]:.2e}, fp16 default {errs[False]:.2e}")
+    assert errs[True] <= 5e-5 and errs[True] * 10 <= errs[False]
