@@ -272,7 +272,7 @@ int vitg_preprocess_u8(const void* frames, int T, int H, int W, long frame_strid
  * vitg_norm_split: LayerNorm (b != NULL) / RMSNorm (b == NULL) of fp32 rows -> split rows ([3P] SigLIP layer_norm1/2, Qwen2RMSNorm; the call
  *   sites vitg_layernorm / vitg_rmsnorm replace).  lo_off = padded payload width (multiple of 4, >= D), ldo >= 2 lo_off.
  * vitg_rope_split: vitg_rope on split q | k heads, in place (hi + lo is rotated in fp32 and split again).
- * vitg_bilinear_pool_split: vitg_bilinear_pool (mlp_proj.py:57-68) of dense fp32 features -> split rows.
+ * vitg_bilinear_pool_split: vitg_bilinear_pool (mlp_proj.py:57-68) of fp32 features (dense, or compact with cmap / Pc as there) -> split rows.
  * vitg_gemm_split16: vitg_gemm's 16-bit-output modes (STORE16 with bias / activation, SWIGLU) writing (hi, lo) pairs: out[m, n] and
  *   out[m, n + lo_off]; N % 8 == 0, lo_off % 8 == 0, lo_off >= output width, ldo >= lo_off + output width.
  * vitg_attention_split: vitg_attention on split Q / K / V (lo planes at element offsets q_lo / k_lo / v_lo from the hi planes, same strides),
@@ -280,7 +280,8 @@ int vitg_preprocess_u8(const void* frames, int T, int H, int W, long frame_strid
  *   Replaces flash-attn at clip_encoder.py:117 / grounding_qwen2.py:45-53 for this tier; head_dim 72 or 128, GQA, non-causal. */
 int vitg_norm_split(const float* x, int ldx, const float* w, const float* b, void* out, int ldo, int lo_off, long M, int D, float eps, void* stream);
 int vitg_rope_split(void* qkv, int ld, long lo_off, const float* cos_t, const float* sin_t, long N, int heads, int head_dim, void* stream);
-int vitg_bilinear_pool_split(const float* x, int ldx, void* out, int ldo, int lo_off, int T, int G, int HW, int D, void* stream);
+int vitg_bilinear_pool_split(const float* x, int ldx, void* out, int ldo, int lo_off, int T, int G, int HW, int D, const int* cmap, int Pc,
+                             void* stream);
 int vitg_gemm_split16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int mode, const float* bias, int act, void* out,
                       int ldo, long lo_off, void* stream);
 int vitg_attention_split(const void* q, const void* k, const void* v, void* o, long q_lo, long k_lo, long v_lo, long o_lo, int batch, int heads,

@@ -380,3 +380,31 @@ def test_operand_split_through_the_operator_surface():
         errs[split] = (got - want).abs().max().item()
     print(f"operator surface: operand_split max|dlogit| = {errs[True]:.2e}, fp16 default {errs[False]:.2e}")
     assert errs[True] <= 5e-5 and errs[True] * 10 <= errs[False]
+
+
+def test_bilinear_pool_split_on_compact_rows_and_the_compact_last_layer():
+    """the split tier skips the last tower layer's dead rows like the default path: the pool then reads COMPACT rows through cmap.  (a) pool on compact
+    input == pool on dense input, bit for bit; (b) the engine with and without skip_dead_rows agrees to fp32 rounding"""
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.torch_ops import K
+    torch.manual_seed(9)
+    T, G, HW, D = 3, 27, 5, 144
+    cfg = tiny_config()
+    eng = split_engine(cfg, synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0))
+    idx, cmap = eng.pool_sources(G, HW)
+    Pc = idx.numel()
+    x = torch.randn(T * G * G, D, device=DEV)
+    xc = x.view(T, G * G, D)[:, idx.long()].reshape(T * Pc, D).contiguous()
+    Dp = K.pad64(D)
+    a, b = torch.zeros((T * HW * HW, 2 * Dp), dtype=torch.float16, device=DEV), torch.zeros((T * HW * HW, 2 * Dp), dtype=torch.float16, device=DEV)
+    K.bilinear_pool_split(x, a, T, G, HW, D)
+    K.bilinear_pool_split(xc, b, T, G, HW, D, cmap, Pc)
+    assert Pc in (81, 100) and torch.equal(a, b)              # (9 or 10 source rows per axis: the 13.0 coordinate lists row 14 with weight 0)
+    pix = synth.synth_pixel_values(6, cfg.vision.image_size, seed=3).half().to(DEV)
+    ids = torch.tensor([[-200, 5, 6, 7]])
+    outs = []
+    for skip in (True, False):
+        eng.skip_dead_rows = skip
+        outs.append(eng.forward(ids, None, [pix])[0].view(-1).float().cpu())
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5

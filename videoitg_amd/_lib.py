@@ -70,7 +70,7 @@ SIGNATURES = {
     # operand-split precision tier (csrc/split.hip; round 6)
     "vitg_norm_split": [_p, _i, _p, _p, _p, _i, _i, _l, _i, _f, _p],
     "vitg_rope_split": [_p, _i, _l, _p, _p, _l, _i, _i, _p],
-    "vitg_bilinear_pool_split": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "vitg_bilinear_pool_split": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "vitg_gemm_split16": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _l, _p],
     "vitg_attention_split": [_p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
 }

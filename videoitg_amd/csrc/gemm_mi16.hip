@@ -394,8 +394,15 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
             }
         }
         const bool has_bias = EMODE != MODE_SWIGLU && g.bias != nullptr && !(MODE == MODE_STORE16 && bias_init) && !res_bias_done;      // a bias is still to be added here
+#ifndef VITG_SPLIT_ONEPASS
+#define VITG_SPLIT_ONEPASS 1      // SPLIT: both planes from ONE pass over the accumulators (a second wave-private LDS window for lo); 0 = two passes (A/B:
+                                  // the tier's step 1 504 -> 1 400 ms in three same-call alternations, bit-identical - gpurun_out/r06_c16/onepass_ab.txt)
+#endif
         auto stages_hl = [&](auto act_c, auto in_c, auto bias_c, auto lo_c) {
-        constexpr bool LO = decltype(lo_c)::value;           // SPLIT: the pass that writes lo = fp16(v - fp16(v)) to out + split_off
+        constexpr bool LO = decltype(lo_c)::value;           // SPLIT, two-pass form: the pass that writes lo = fp16(v - fp16(v)) to out + split_off
+        constexpr bool BOTH = SPLIT && VITG_SPLIT_ONEPASS;   // SPLIT, one-pass form: hi to the wave's window, lo to its second window (behind all first windows)
+        char* const stage_lo = stage + (G16_THREADS / 64) * (32 * RB);
+        static_assert(!BOTH || 2 * (G16_THREADS / 64) * 32 * RB <= 2 * (BM + BN) * 128, "two staging windows per wave fit the operand ring");
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool IN = decltype(in_c)::value;           // interior tile: no bounds predicates
         constexpr int BIAS = decltype(bias_c)::value;        // 1 / 0: a bias is / is not added here (interior forms); -1: tested per quad (edge tiles)
@@ -450,19 +457,27 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                     typename T16<T>::vec4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e]);
-                    if constexpr (LO) {
+                    const int row = h * 16 + r16, c = nt * 2 + (fq >> 1);
+                    if constexpr (BOTH) {
+                        typename T16<T>::vec4 o2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o2[e] = T16<T>::from_f32(v[e] - T16<T>::to_f32(o[e]));
+                        *(typename T16<T>::vec4*)(stage_lo + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4) + (fq & 1) * 8) = o2;
+                    } else if constexpr (LO) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(v[e] - T16<T>::to_f32(o[e]));
                     }
-                    const int row = h * 16 + r16, c = nt * 2 + (fq >> 1);
                     *(typename T16<T>::vec4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4) + (fq & 1) * 8) = o;
                 }
-            char* const ob = (char*)((T*)g.out + (LO ? (size_t)g.split_off : (size_t)0) + (size_t)(mw + mp * 32) * g.ldo + n_out);
+#pragma unroll
+            for (int plane = 0; plane < (BOTH ? 2 : 1); ++plane) {
+            const char* const sp = plane ? stage_lo : stage;
+            char* const ob = (char*)((T*)g.out + ((LO || plane) ? (size_t)g.split_off : (size_t)0) + (size_t)(mw + mp * 32) * g.ldo + n_out);
 #pragma unroll
             for (int i = 0; i < 32 * CH / 64; ++i) {
                 const int idx = i * 64 + lane;
                 const int row = idx / CH, c = idx % CH;
-                const u32x4 v = *(const u32x4*)(stage + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4));
+                const u32x4 v = *(const u32x4*)(sp + row * RB + ((c ^ ((row >> SH) & SWZ)) << 4));
                 const int m = mw + mp * 32 + row, n = n_out + c * 8;
                 if (IN || m < g.M) {
                     const unsigned boff = (unsigned)(row * g.ldo + c * 8) * 2u;
@@ -470,11 +485,12 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gemm16_kernel(GemmArgs g_) {
                     else if (n + 4 <= n_lim) *(u32x2*)(ob + boff) = u32x2{v[0], v[1]};
                 }
             }
+            }
         }
         };   // stages_hl
         auto stages = [&](auto act_c, auto in_c, auto bias_c) {
             stages_hl(act_c, in_c, bias_c, std::false_type{});
-            if constexpr (SPLIT) stages_hl(act_c, in_c, bias_c, std::true_type{});
+            if constexpr (SPLIT && !VITG_SPLIT_ONEPASS) stages_hl(act_c, in_c, bias_c, std::true_type{});
         };
         typedef std::true_type IY;
         typedef std::false_type IN_;

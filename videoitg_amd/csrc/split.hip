@@ -102,7 +102,8 @@ __global__ void rope_split_kernel(f16_t* __restrict__ qkv, int ld, long lo_off, 
 }
 
 // ---- bilinear token pool (mlp_proj.py:57-68 semantics, the arithmetic of elementwise.hip's pool_kernel) of fp32 features -> split rows ------------
-__global__ void pool_split_kernel(const float* __restrict__ x, int ldx, f16_t* __restrict__ out, int ldo, int lo_off, int T, int G, int HW, int D) {
+__global__ void pool_split_kernel(const float* __restrict__ x, int ldx, f16_t* __restrict__ out, int ldo, int lo_off, int T, int G, int HW, int D,
+                                  const int* __restrict__ cmap, int Pc) {
     const long orow = blockIdx.x;
     const int t = (int)(orow / (HW * HW)), o = (int)(orow % (HW * HW));
     const int oy = o / HW, ox = o % HW;
@@ -113,11 +114,20 @@ __global__ void pool_split_kernel(const float* __restrict__ x, int ldx, f16_t* _
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = min(y0 + 1, G - 1), x1 = min(x0 + 1, G - 1);
     const float wy1 = sy - y0, wx1 = sx - x0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-    const float* base = x + (long)t * G * G * ldx;
-    const float* p00 = base + (long)(y0 * G + x0) * ldx;
-    const float* p01 = base + (long)(y0 * G + x1) * ldx;
-    const float* p10 = base + (long)(y1 * G + x0) * ldx;
-    const float* p11 = base + (long)(y1 * G + x1) * ldx;
+    // dense input: G*G rows per frame; compact input (cmap != null): only the Pc rows the pool reads, at cmap[y*G+x] (as pool_kernel)
+    const float* base = x + (long)t * (cmap ? Pc : G * G) * ldx;
+    int r00 = y0 * G + x0, r01 = y0 * G + x1, r10 = y1 * G + x0, r11 = y1 * G + x1;
+    if (cmap) {
+        r00 = cmap[r00]; r01 = cmap[r01]; r10 = cmap[r10]; r11 = cmap[r11];
+        if ((r00 | r01 | r10 | r11) < 0) {                   // a token the host did not list: poison the row, never dereference
+            for (int c = threadIdx.x; c < 2 * lo_off; c += blockDim.x) out[orow * ldo + c] = (f16_t)__builtin_nanf("");
+            return;
+        }
+    }
+    const float* p00 = base + (long)r00 * ldx;
+    const float* p01 = base + (long)r01 * ldx;
+    const float* p10 = base + (long)r10 * ldx;
+    const float* p11 = base + (long)r11 * ldx;
     for (int c = threadIdx.x * 4; c < lo_off; c += blockDim.x * 4) {
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (c < D) {
@@ -374,12 +384,14 @@ extern "C" int vitg_rope_split(void* qkv, int ld, long lo_off, const float* cos_
     return CHECK_LAUNCH();
 }
 
-extern "C" int vitg_bilinear_pool_split(const float* x, int ldx, void* out, int ldo, int lo_off, int T, int G, int HW, int D, void* stream) {
+extern "C" int vitg_bilinear_pool_split(const float* x, int ldx, void* out, int ldo, int lo_off, int T, int G, int HW, int D, const int* cmap, int Pc,
+                                        void* stream) {
     if (T <= 0) return 0;
     if (!x || !out) return VITG_ERR_ARG;
+    if (cmap && (HW == G || Pc <= 0)) return VITG_ERR_ARG;
     if (D % 4 || ldo % 4 || ldx % 4 || lo_off % 4) return VITG_ERR_ALIGN;
     if (HW <= 0 || HW > G || lo_off < D || ldo < 2 * lo_off) return VITG_ERR_SHAPE;
-    hipLaunchKernelGGL(pool_split_kernel, dim3((unsigned)((long)T * HW * HW)), dim3(256), 0, (hipStream_t)stream, x, ldx, (f16_t*)out, ldo, lo_off, T, G, HW, D);
+    hipLaunchKernelGGL(pool_split_kernel, dim3((unsigned)((long)T * HW * HW)), dim3(256), 0, (hipStream_t)stream, x, ldx, (f16_t*)out, ldo, lo_off, T, G, HW, D, cmap, Pc);
     return CHECK_LAUNCH();
 }
 

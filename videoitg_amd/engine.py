@@ -502,7 +502,7 @@ class SelectorEngine:
         only for the Pc tokens the pool reads (their outputs are the only ones anything downstream consumes), and features
         are compact [T*Pc, Dv] with cmap: token -> compact row."""
         if self.operand_split:
-            return self.vit_forward_split(pix)
+            return self.vit_forward_split(pix, hw)
         cfg, v, w = self.cfg, self.cfg.vision, self.w
         T, _, R, _ = pix.shape
         G = R // v.patch_size
@@ -654,10 +654,10 @@ class SelectorEngine:
         Dv, Dvp, Dp = cfg.vision.hidden_size, pad64(cfg.vision.hidden_size), pad64(cfg.hidden_size)
         nv = T * hw * hw
         if self.operand_split:
-            if cmap is not None or feats.dtype != torch.float32:
-                raise ValueError("the operand-split tier pools dense fp32 tower features")
+            if feats.dtype != torch.float32:
+                raise ValueError("the operand-split tier pools fp32 tower features")
             pooled2 = self._buf("pooled2", (nv, 2 * Dvp), torch.float16, zero=True)
-            K.bilinear_pool_split(feats, pooled2, T, G, hw, Dv)
+            K.bilinear_pool_split(feats, pooled2, T, G, hw, Dv, cmap, pc)
             g2 = self._buf("proj_g2", (nv, 2 * Dp), torch.float16)
             K.gemm_split16(pooled2, self.sw.proj0, g2, mode=K.GEMM_STORE16, lo_off=Dp, bias=w.proj0_b, act=K.ACT_GELU_ERF)
             self._gemm(g2, self.sw.proj2, dst_rows, mode=K.GEMM_F32, bias=w.proj2_b)
@@ -669,10 +669,11 @@ class SelectorEngine:
         K.gemm(g, w.proj2_w, dst_rows, mode=K.GEMM_F32, bias=w.proj2_b)
 
     # ---- operand-split tier (csrc/split.hip): the same forward with every MFMA operand as an fp16 (hi, lo) pair --------------------------------
-    def vit_forward_split(self, pix: torch.Tensor):
-        """A7 on split operands -> (dense fp32 features [T*P, Dv], G, None, 0).  fp32 residual stream, every layer on all tokens; LayerNorm writes
-        [hi | lo] rows, the qkv / fc1 GEMMs write (hi, lo) pairs from their epilogues, attention runs the 3-term products, out-proj / fc2 add into the
-        fp32 stream.  The patch embedding takes the 16-bit pixel tensor as it is (pixels and weights are 16-bit exact: nothing to split)."""
+    def vit_forward_split(self, pix: torch.Tensor, hw: Optional[int] = None):
+        """A7 on split operands -> (fp32 features, G, cmap, Pc) as vit_forward: dense [T*P, Dv] without a pooled grid, else the LAST needed layer
+        computes K|V for all tokens and queries / out-proj / MLP only for the Pc tokens the pool reads (compact rows + cmap).  fp32 residual stream;
+        LayerNorm writes [hi | lo] rows, the qkv / fc1 GEMMs write (hi, lo) pairs from their epilogues, attention runs the 3-term products, out-proj /
+        fc2 add into the fp32 stream.  The patch embedding takes the 16-bit pixel tensor as it is (pixels and weights are 16-bit exact: nothing to split)."""
         v, w, sw = self.cfg.vision, self.w, self.sw
         T, _, R, _ = pix.shape
         G = R // v.patch_size
@@ -693,16 +694,42 @@ class SelectorEngine:
         o = self._buf("vit_o2", (M, 2 * Dvp), f16, zero=True)
         f = self._buf("vit_f2", (M, 2 * Fvp), f16)
         st = (P * 6 * Dv, 6 * Dv, hd)
-        for lw, l2 in zip(w.vit, sw.vit):
+        scale = hd ** -0.5
+        src = self.pool_sources(G, hw) if (hw is not None and self.skip_dead_rows and len(w.vit) > 0) else None
+        layers = list(zip(w.vit, sw.vit))
+        for lw, l2 in (layers if src is None else layers[:-1]):
             K.norm_split(x, lw.ln1_w, lw.ln1_b, h, Dv, eps)
             K.gemm_split16(h, l2["qkv"], qkv, mode=K.GEMM_STORE16, lo_off=3 * Dv, bias=lw.qkv_b)
             K.attention_split(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], o, lo=(3 * Dv, 3 * Dv, 3 * Dv, Dvp), batch=T, heads=H, kv_heads=H, seq=P, head_dim=hd,
-                              q_strides=st, k_strides=st, v_strides=st, o_strides=(P * 2 * Dvp, 2 * Dvp, hd), scale=hd ** -0.5)
+                              q_strides=st, k_strides=st, v_strides=st, o_strides=(P * 2 * Dvp, 2 * Dvp, hd), scale=scale)
             self._gemm(o, l2["out"], x, mode=K.GEMM_F32, bias=lw.out_b, res=x)
             K.norm_split(x, lw.ln2_w, lw.ln2_b, h, Dv, eps)
             K.gemm_split16(h, l2["fc1"], f, mode=K.GEMM_STORE16, lo_off=Fvp, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
             self._gemm(f, l2["fc2"], x, mode=K.GEMM_F32, bias=lw.fc2_b, res=x)
-        return x, G, None, 0
+        if src is None:
+            return x, G, None, 0
+        # ---- last needed layer on compact query rows (as vit_forward: K|V for every token, everything else for the Pc tokens the pool reads) ----
+        idx, cmap = src
+        Pc = idx.numel()
+        Mc = T * Pc
+        lw, l2 = layers[-1]
+        K.norm_split(x, lw.ln1_w, lw.ln1_b, h, Dv, eps)
+        K.gemm_split16(h, l2["qkv"][Dv:], qkv[:, Dv:], mode=K.GEMM_STORE16, lo_off=3 * Dv, bias=lw.qkv_b[Dv:])
+        xq = self._buf("vit_xq", (Mc, Dv), torch.float32)
+        K.gather_rows(x, idx, P, T, xq, Dv)
+        hq = self._buf("vit_hq2", (Mc, 2 * Dvp), f16, zero=True)
+        K.norm_split(xq, lw.ln1_w, lw.ln1_b, hq, Dv, eps)                  # LayerNorm is per row: normalising the gathered rows = gathering the normalised rows
+        qc = self._buf("vit_qc2", (Mc, 2 * Dv), f16)
+        K.gemm_split16(hq, l2["qkv"][:Dv], qc, mode=K.GEMM_STORE16, lo_off=Dv, bias=lw.qkv_b[:Dv])
+        oc = self._buf("vit_oc2", (Mc, 2 * Dvp), f16, zero=True)
+        K.attention_split(qc, qkv[:, Dv:], qkv[:, 2 * Dv:], oc, lo=(Dv, 3 * Dv, 3 * Dv, Dvp), batch=T, heads=H, kv_heads=H, seq=Pc, kv_seq=P, head_dim=hd,
+                          q_strides=(Pc * 2 * Dv, 2 * Dv, hd), k_strides=st, v_strides=st, o_strides=(Pc * 2 * Dvp, 2 * Dvp, hd), scale=scale)
+        self._gemm(oc, l2["out"], xq, mode=K.GEMM_F32, bias=lw.out_b, res=xq)
+        K.norm_split(xq, lw.ln2_w, lw.ln2_b, hq, Dv, eps)
+        fc = self._buf("vit_fc2", (Mc, 2 * Fvp), f16)
+        K.gemm_split16(hq, l2["fc1"], fc, mode=K.GEMM_STORE16, lo_off=Fvp, bias=lw.fc1_b, act=K.ACT_GELU_TANH)
+        self._gemm(fc, l2["fc2"], xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
+        return xq, G, cmap, Pc
 
     def llm_forward_split(self, x: torch.Tensor) -> torch.Tensor:
         """A11 on split operands: fp32 x [N, D] (in place) -> final-normed fp32"""

@@ -564,9 +564,11 @@ def rope_split_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: 
     return qkv
 
 
-def bilinear_pool_split(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d: int) -> torch.Tensor:
+def bilinear_pool_split(x: torch.Tensor, out: torch.Tensor, T: int, G: int, HW: int, d: int, cmap: Optional[torch.Tensor] = None, pc: int = 0) -> torch.Tensor:
     _req(x, torch.float32); _req(out, torch.float16)
-    _lib.call("vitg_bilinear_pool_split", _ptr(x), x.stride(0), _ptr(out), out.stride(0), out.shape[1] // 2, T, G, HW, d, _stream())
+    if cmap is not None:
+        _req(cmap, torch.int32)
+    _lib.call("vitg_bilinear_pool_split", _ptr(x), x.stride(0), _ptr(out), out.stride(0), out.shape[1] // 2, T, G, HW, d, _ptr(cmap), pc, _stream())
     return out
 
 

@@ -105,8 +105,8 @@ _def("norm_split(Tensor x, Tensor w, Tensor? b, Tensor(a!) out, int d, float eps
      lambda x, w, b, out, d, eps: (_raw.norm_split(x, w, b, out, d, eps), None)[1], lambda *a, **k: None)
 _def("rope_split_(Tensor(a!) qkv, Tensor cos, Tensor sin, int heads, int head_dim, int lo_off) -> ()",
      lambda qkv, cos, sin, heads, head_dim, lo_off: (_raw.rope_split_(qkv, cos, sin, heads, head_dim, lo_off), None)[1], lambda *a, **k: None)
-_def("bilinear_pool_split(Tensor x, Tensor(a!) out, int T, int G, int HW, int d) -> ()",
-     lambda x, out, T, G, HW, d: (_raw.bilinear_pool_split(x, out, T, G, HW, d), None)[1], lambda *a, **k: None)
+_def("bilinear_pool_split(Tensor x, Tensor(a!) out, int T, int G, int HW, int d, Tensor? cmap=None, int pc=0) -> ()",
+     lambda x, out, T, G, HW, d, cmap=None, pc=0: (_raw.bilinear_pool_split(x, out, T, G, HW, d, cmap, pc), None)[1], lambda *a, **k: None)
 _def("gemm_split16(Tensor a, Tensor w, Tensor(a!) out, int mode, int lo_off, Tensor? bias=None, int act=0) -> ()",
      lambda a, w, out, mode, lo_off, bias=None, act=0: (_raw.gemm_split16(a, w, out, mode=mode, lo_off=lo_off, bias=bias, act=act), None)[1],
      lambda *a, **k: None)
@@ -278,8 +278,8 @@ class _Namespace:
         return qkv
 
     @staticmethod
-    def bilinear_pool_split(x, out, T, G, HW, d):
-        _ops.bilinear_pool_split(x, out, T, G, HW, d)
+    def bilinear_pool_split(x, out, T, G, HW, d, cmap=None, pc=0):
+        _ops.bilinear_pool_split(x, out, T, G, HW, d, cmap, pc)
         return out
 
     @staticmethod
