@@ -638,15 +638,15 @@ def cpu_baseline(cfg, T, R, n_text, cores):
     def layer(xx):
         return O.qwen2_layer(xx, sd, 0, num_heads=cfg.num_attention_heads, num_kv_heads=cfg.num_key_value_heads,
                              eps=cfg.rms_norm_eps, cos=cos, sin=sin, key_mask=None)
+    # the decoder runs on the thread count the tower sweep chose (round 6: its own sweep over {32, 64, 128} cost 55 s of the default run for the same
+    # answer - 32 of 128 cores - every time; SURVEY 8d's sample is "2 of 28 layers at the full N", timed here as two consecutive calls)
+    th_l = th_v
     sweep_l = {}
     with torch.inference_mode():
-        for th in cands:
-            torch.set_num_threads(th)
-            t0 = time.perf_counter()
-            layer(x)
-            sweep_l[th] = time.perf_counter() - t0
-        th_l = min(sweep_l, key=sweep_l.get)
         torch.set_num_threads(th_l)
+        t0 = time.perf_counter()
+        layer(x)
+        sweep_l[th_l] = time.perf_counter() - t0
         t0 = time.perf_counter()
         layer(x)
         t_second = time.perf_counter() - t0
@@ -657,11 +657,11 @@ def cpu_baseline(cfg, T, R, n_text, cores):
                sample=f"oracle (torch CPU fp32): SigLIP embed + all {n_vit} needed layers on {nf} of {T} frames@{R} in {t_vit:.2f}s on {th_v} "
                       f"threads (x{T / nf:g} frame groups); {nl} of {cfg.num_hidden_layers} Qwen2 layers at the full N={N} tokens in "
                       f"{t_llm:.2f}s on {th_l} threads (x{cfg.num_hidden_layers / nl:g}) = {est:.0f}s per video; thread sweep (s): tower 2 layers "
-                      f"{ {k: round(val, 2) for k, val in sweep_v.items()} }, decoder 1 layer { {k: round(val, 2) for k, val in sweep_l.items()} }",
+                      f"{ {k: round(val, 2) for k, val in sweep_v.items()} } (the decoder runs on the tower's choice)",
                sample_short=f"oracle fp32: tower {n_vit} layers on {nf}/{T} frames {t_vit:.1f}s@{th_v}thr x{T / nf:g}; decoder {nl}/{cfg.num_hidden_layers} layers at "
                             f"N={N} {t_llm:.1f}s@{th_l}thr x{cfg.num_hidden_layers / nl:g} => {est:.0f} s/video",
                threads={"tower": th_v, "decoder": th_l, "host_cores": cores},
-               sample_seconds=round(t_vit + t_llm + sum(sweep_v.values()) + sum(val for k, val in sweep_l.items() if k != th_l), 2))
+               sample_seconds=round(t_vit + t_llm + sum(sweep_v.values()), 2))
     gdir = os.path.join(ROOT, "tests", "golden")
     done = {}
     for fn in sorted(os.listdir(gdir)) if os.path.isdir(gdir) else []:
@@ -1233,7 +1233,9 @@ def main():
             eng.release_workspace()
             # ("tower bf16 + LLM fp16": the tower tolerates bf16 inside the 1e-3 bound, the LLM does not - profiles/r02_parity.md)
             F16, B16 = torch.float16, torch.bfloat16
-            policies = {"fp16": (F16, F16), "bf16": (B16, B16), "tower_bf16_llm_fp16": (F16, B16)}
+            # (round 6: the mix "tower bf16 + LLM fp16" - 786 frames/s at 1.4e-3, a miss of 1e-3 on two fixtures, profiles/r02_parity.md - left the
+            # default run to keep it under five minutes; `--dtype tower_bf16_llm_fp16` still runs it as the job)
+            policies = {"fp16": (F16, F16), "bf16": (B16, B16)}
             policies.pop(args.dtype, None)
             for pname, (ldt, vdt) in policies.items():
                 eng_o = SelectorEngine(packed_random_weights(cfg, ldt, dev, seed=args.seed, vit_dtype=vdt))

@@ -151,3 +151,33 @@ def test_written_checkpoint_layout_loads_through_the_directory_reader(tmp_path):
     assert any(k.startswith("vision_model.head.") for k in vsd) and "vision_model.post_layernorm.weight" in vsd    # carried, never packed
     tok, model, proc, ctx = load_pretrained_model(str(tmp_path / "ckpt"), None, "VideoITG-tiny", device_map="cuda:0")
     assert not isinstance(tok, ByteTokenizer) and len(tok("which frame ?").input_ids) == 3
+
+
+def test_split_weights_layout_and_refusals_on_cpu():
+    """host side of the operand-split tier (videoitg_amd.engine.SplitWeights): every GEMM weight that meets a [hi | lo] operand is laid twice side by side;
+    the tier refuses the combinations it does not define (bf16 pairs, fp8 weights, re-rounded q rows) before anything is launched"""
+    from videoitg_amd.engine import PackedWeights, SplitWeights
+    cfg = tiny_config()
+    sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
+    pw = PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cpu", vit_q_prescaled=False)
+    sw = pw.doubled()
+    assert sw is pw.doubled()                                         # built once
+    assert len(sw.vit) == cfg.num_vit_layers_needed() and len(sw.llm) == cfg.num_hidden_layers
+    for lw, l2 in zip(pw.vit, sw.vit):
+        for name, w in (("qkv", lw.qkv_w), ("out", lw.out_w), ("fc1", lw.fc1_w), ("fc2", lw.fc2_w)):
+            k = w.shape[1]
+            assert l2[name].shape == (w.shape[0], 2 * k) and torch.equal(l2[name][:, :k], w) and torch.equal(l2[name][:, k:], w)
+    for lw, l2 in zip(pw.llm, sw.llm):
+        assert l2["gu"].shape == (lw.gu_w.shape[0], 2 * lw.gu_w.shape[1]) and torch.equal(l2["down"][:, lw.down_w.shape[1]:], lw.down_w)
+    assert sw.proj0.shape[1] == 2 * pw.proj0_w.shape[1] and sw.proj2.shape[1] == 2 * pw.proj2_w.shape[1]
+    # the softmax scale is NOT folded into the q rows: they are the checkpoint's own 16-bit values
+    Dv = cfg.vision.hidden_size
+    assert torch.equal(pw.vit[0].qkv_w[:Dv, :Dv], vsd["vision_model.encoder.layers.0.self_attn.q_proj.weight"].half())
+    with pytest.raises(ValueError, match="vit_q_prescaled"):
+        SplitWeights(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cpu", vit_q_prescaled=True))
+    with pytest.raises(ValueError, match="float16"):
+        SplitWeights(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.bfloat16, "cpu", vit_q_prescaled=False))
+    m = EagleQwenG(cfg, sd, vsd, torch_dtype=torch.float16, device="cpu")
+    m.operand_split = True
+    with pytest.raises(RuntimeError):                                 # still no CPU path, whatever the tier
+        m(torch.tensor([[-200, 5]]), images=[torch.zeros(2, 3, 56, 56)])

@@ -256,3 +256,34 @@ def test_avi_with_a_real_codec_falls_through_to_pyav(tmp_path, fake_av, monkeypa
     monkeypatch.setitem(sys.modules, "av", None)
     with pytest.raises(ValueError, match="needs a codec"):
         plug.load_video(path, num_frames=8, target_fps=1)
+
+
+@pytest.mark.parametrize("fmt,suffix,exact", [("GIF", ".gif", False), ("PNG", ".png", True), ("WEBP", ".webp", True), ("TIFF", ".tif", True)])
+def test_animated_images_are_videos_too(tmp_path, no_decoders, fmt, suffix, exact):
+    """round 6, A2 / N3 "as far as the image allows": GIF / APNG / animated WebP / multi-page TIFF are frame sequences whose codecs ship inside Pillow, so
+    `read_video_decord` and the plugin's loader read them without decord or PyAV (lossless formats exactly; GIF through its 256-colour palette)"""
+    from PIL import Image
+    from videoitg_amd import video_io
+    from videoitg_amd.lmms_plugin.models import videoitg as plug
+    clip = _clip(T=40, h=32, w=44)
+    clip[:, :, :, :] = clip[:, :, :, :1]                       # grey levels: inside any palette
+    frames = [Image.fromarray(f) for f in clip]
+    path = str(tmp_path / f"clip{suffix}")
+    kw = dict(save_all=True, append_images=frames[1:])
+    if fmt in ("GIF", "PNG", "WEBP"):
+        kw.update(duration=40, loop=0)                          # 25 fps
+    if fmt == "WEBP":
+        kw.update(lossless=True)
+    try:
+        frames[0].save(path, format=fmt, **kw)
+    except (KeyError, OSError, ValueError) as e:                # a Pillow build without that writer
+        pytest.skip(f"Pillow cannot write {fmt} here: {e}")
+    vr = video_io.VideoReader(path)
+    assert len(vr) == 40 and (vr.height, vr.width) == (32, 44)
+    if fmt != "TIFF":
+        assert abs(vr.get_avg_fps() - 25.0) < 1e-6
+    got = vr.get_batch([0, 17, 39, 5]).asnumpy()               # (a backward seek in a delta-coded format included)
+    want = clip[[0, 17, 39, 5]]
+    assert got.shape == want.shape and (np.array_equal(got, want) if exact else np.abs(got.astype(int) - want.astype(int)).max() <= 4)
+    imgs, idx = plug.load_video(path, num_frames=8, target_fps=1)
+    assert len(imgs) == len(idx) >= 1 and imgs[0].size == (44, 32)

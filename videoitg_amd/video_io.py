@@ -1,4 +1,5 @@
-"""Built-in video reader for the two container formats that need no codec library: MJPEG / uncompressed frames in AVI, and YUV4MPEG2.
+"""Built-in video reader for the container formats that need no codec library: MJPEG / uncompressed frames in AVI (incl. OpenDML), YUV4MPEG2, and -
+round 6 - the animated image formats Pillow decodes itself (GIF, APNG, animated WebP, multi-page TIFF).
 
 Row A2 / N3 of SURVEY.md section 8: the reference decodes with decord (``infer.py:44-51``) or PyAV (``eagle/mm_utils.py:43-103``,
 ``lmms_eval/models/videoitg.py:95-130``); neither is in this image, and building a codec is out of scope.  What CAN be done without one is
@@ -17,7 +18,7 @@ from typing import List, Sequence, Tuple
 
 import numpy as np
 
-SUFFIXES = (".avi", ".y4m")
+SUFFIXES = (".avi", ".y4m", ".gif", ".webp", ".apng", ".png", ".tif", ".tiff")      # (the image suffixes: ANIMATED files Pillow decodes - round 6)
 
 
 class _Batch:
@@ -127,11 +128,13 @@ class VideoReader:
         self.path = path
         with open(path, "rb") as f:
             self._data = f.read()
-        head = self._data[:10]
+        head = self._data[:12]
         if head.startswith(b"YUV4MPEG2"):
             self._init_y4m()
-        elif head[:4] == b"RIFF":
+        elif head[:4] == b"RIFF" and head[8:12] != b"WEBP":
             self._init_avi()
+        elif head[:6] in (b"GIF87a", b"GIF89a") or head[:8] == b"\x89PNG\r\n\x1a\n" or head[:4] in (b"II*\0", b"MM\0*") or (head[:4] == b"RIFF" and head[8:12] == b"WEBP"):
+            self._init_pil()
         else:
             raise ValueError(f"{path}: neither a RIFF AVI nor a YUV4MPEG2 file (the built-in reader covers only these; install decord / PyAV for coded video)")
 
@@ -160,6 +163,32 @@ class VideoReader:
         rows = np.frombuffer(self._data, np.uint8, stride * self.height, off).reshape(self.height, stride)[:, :self.width * 3]
         img = rows.reshape(self.height, self.width, 3)[:, :, ::-1]
         return np.ascontiguousarray(img if self._ix.top_down else img[::-1])
+
+    # ---- animated images Pillow decodes itself: GIF, APNG, animated WebP, multi-page TIFF (round 6) ----------------------------------------
+    def _init_pil(self):
+        """frame-sequence containers whose codecs ship INSIDE Pillow (LZW / deflate / VP8 via libwebp): the last kind of "video" file the image can
+        read without a decoder library.  Frame rate from the per-frame `duration` (ms) the container records; one still image is a 1-frame video."""
+        from PIL import Image
+        im = Image.open(io.BytesIO(self._data))
+        self._pil = im
+        self._n = int(getattr(im, "n_frames", 1))
+        self.width, self.height = im.size
+        durs = []
+        for i in range(min(self._n, 64)):                   # (the average over the first frames: GIFs may vary it per frame)
+            im.seek(i)
+            d = im.info.get("duration")
+            if d:
+                durs.append(float(d))
+        self._fps = 1000.0 / (sum(durs) / len(durs)) if durs else 25.0
+        self._kind, self._pil_at = "pil", -1
+
+    def _pil_frame(self, i: int) -> np.ndarray:
+        im = self._pil
+        if i < self._pil_at:                                # delta-coded formats compose forward: Pillow replays from the start on a backward seek
+            im.seek(0)
+        im.seek(i)
+        self._pil_at = i
+        return np.asarray(im.convert("RGB"))
 
     # ---- YUV4MPEG2 ------------------------------------------------------------------------------------------------------------
     def _init_y4m(self):
@@ -218,6 +247,8 @@ class VideoReader:
         if not -self._n <= i < self._n:
             raise IndexError(f"frame {i} of {self._n}")
         i %= self._n
+        if self._kind == "pil":
+            return self._pil_frame(i)
         return self._y4m_frame(i) if self._kind == "y4m" else self._avi_frame(i)
 
     def __getitem__(self, i: int) -> _Batch:
