@@ -93,6 +93,22 @@ def test_context_parallel_on_heavy_tailed_weights():
     assert rep["max_abs_dlogit_vs_single_gpu"] <= 1e-2, rep
 
 
+def test_context_parallel_operand_split_tier_on_the_heavy_tailed_headline_video():
+    """round 6: the frame-sharded / context-parallel forward in the OPERAND-SPLIT tier (K|V exchanged as (hi, lo) pairs, 3-term attention against the
+    gathered keys) at full size on the heavy-tailed twin of the headline video: two ranks on one GPU against the complete fp32 oracle pass at the tier's own
+    bounds (tests/test_gpu_split.py: 1e-4 in score, the oracle's Top-32 although its rank-32/33 gap is 1.5e-4)."""
+    mod = _mod()
+    case = "c2o_512x448"
+    rec = mod.load_case(case)
+    torch.cuda.empty_cache()
+    got, forms = mod.run(2, case, port=29577, split=True)
+    rep = mod.report(case, got)
+    print(f"operand-split tier, context-parallel x2 on {case}: {rep}")
+    assert got.shape == (rec["frames"],) and torch.isfinite(got).all()
+    assert rep["max_abs_dscore_vs_oracle"] <= 1e-4 and rep["max_abs_dlogit_vs_oracle"] <= 4e-3, rep
+    assert rep[f"top{rec['k']}_set_match"], rep
+
+
 def test_context_parallel_full_size_fp8_llm_mlp():
     """configs[4] names the fp8 weight path at 1 AND 8 GPUs: the named fp8 tier (decoder gate/up + down on e4m3, MX hand-over) through the
     8-way context-parallel forward against the oracle at the tier's own bound, and against the same tier on one GPU."""

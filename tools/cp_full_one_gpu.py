@@ -36,7 +36,7 @@ def parse_fp8(fp8):
     return fp8
 
 
-def worker(rank: int, world: int, port: int, case: str, fp8, q) -> None:
+def worker(rank: int, world: int, port: int, case: str, fp8, q, split=False) -> None:
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -50,7 +50,9 @@ def worker(rank: int, world: int, port: int, case: str, fp8, q) -> None:
         rec = load_case(case)
         cfg = ITGConfig()
         dev = torch.device("cuda:0")
-        eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=parse_fp8(fp8), plan=synth.fixture_plan(rec)))
+        # split: the operand-split precision tier (SelectorEngine(operand_split=True); K|V travel as (hi, lo) pairs) - 45 GB of weights per rank
+        eng = SelectorEngine(packed_random_weights(cfg, torch.float16, dev, seed=rec["weight_seed"], fp8=parse_fp8(fp8), plan=synth.fixture_plan(rec),
+                                                   vit_q_prescaled=False if split else None), operand_split=bool(split))
         ids, pix = synth.fixture_inputs(cfg, rec)
         T = rec["frames"]
         cp = ContextParallel(rank, world)
@@ -69,11 +71,11 @@ def worker(rank: int, world: int, port: int, case: str, fp8, q) -> None:
         dist.destroy_process_group()
 
 
-def run(world: int = 8, case: str = "c2_512x448", fp8=None, port: int = 29561, timeout: int = 900):
+def run(world: int = 8, case: str = "c2_512x448", fp8=None, port: int = 29561, timeout: int = 900, split: bool = False):
     """-> (logits fp32 [T] gathered on rank 0, {"splitk": [((M, N, K), splits), ...], "n_local": rows per rank})"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, port, case, fp8, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, case, fp8, q, split)) for r in range(world)]
     for p in procs:
         p.start()
     try:

@@ -13,17 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build(fp8=False):
+def build(fp8=False, split=False):
     from videoitg_amd import synth
     from videoitg_amd.config import tiny_config
     from videoitg_amd.engine import PackedWeights, SelectorEngine
     cfg = tiny_config(vision_token_num=72)
     sd, vsd = synth.synth_llm_state_dict(cfg, 0), synth.synth_vision_state_dict(cfg, 0)
-    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0", fp8=fp8))
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0", fp8=fp8, vit_q_prescaled=False if split else None),
+                         operand_split=split)
     return cfg, eng
 
 
-def worker(rank, world, frames, port, q, fp8=False):
+def worker(rank, world, frames, port, q, fp8=False, split=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -31,7 +32,7 @@ def worker(rank, world, frames, port, q, fp8=False):
     try:
         from videoitg_amd import synth
         from videoitg_amd.parallel import ContextParallel
-        cfg, eng = build(fp8)
+        cfg, eng = build(fp8, split)
         pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
         ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
         cp = ContextParallel(rank, world)
@@ -50,10 +51,10 @@ def worker(rank, world, frames, port, q, fp8=False):
         dist.destroy_process_group()
 
 
-def run(world=2, frames=9, port=29533, fp8=False):
+def run(world=2, frames=9, port=29533, fp8=False, split=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, frames, port, q, fp8)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, frames, port, q, fp8, split)) for r in range(world)]
     for p in procs:
         p.start()
     got = torch.tensor(q.get(timeout=600), dtype=torch.float32)
@@ -61,7 +62,7 @@ def run(world=2, frames=9, port=29533, fp8=False):
         p.join(600)
         assert p.exitcode == 0, p.exitcode
     from videoitg_amd import synth
-    cfg, eng = build(fp8)
+    cfg, eng = build(fp8, split)
     pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
     ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
     want = eng.forward(ids, None, [pix])[0].view(-1).float().cpu()
@@ -71,7 +72,7 @@ def run(world=2, frames=9, port=29533, fp8=False):
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 9
-    got, want = run(world, frames, fp8=len(sys.argv) > 3 and sys.argv[3] == "fp8")
+    got, want = run(world, frames, fp8=len(sys.argv) > 3 and sys.argv[3] == "fp8", split=len(sys.argv) > 3 and sys.argv[3] == "split")
     d = (got - want).abs().max().item()
     print(f"world={world} frames={frames}: max|dlogit| vs single rank = {d:.3e}", flush=True)
     assert d < 5e-3, d

@@ -316,7 +316,7 @@ class SelectorEngine:
         self.w = weights
         # operand-split precision tier (round 6; csrc/split.hip): every MFMA operand as an fp16 (hi, lo) pair - fp32-grade GEMMs and attention at
         # 2 x / 3 x the MFMA work, for weights on which 11-bit operands miss north_star's 1e-3 (massive-activation channels, profiles/r05_heavy_tail.md).
-        # fp32 residual streams, every tower layer on all tokens, eager launches on one GPU (no graph capture, no context parallelism).
+        # fp32 residual streams, eager launches (no graph capture); context-parallel through the blocking K|V exchange of pairs.
         self.operand_split = bool(operand_split)
         self.sw = weights.doubled() if self.operand_split else None
         self.cfg = weights.cfg
@@ -731,26 +731,38 @@ class SelectorEngine:
         self._gemm(fc, l2["fc2"], xq, mode=K.GEMM_F32, bias=lw.fc2_b, res=xq)
         return xq, G, cmap, Pc
 
-    def llm_forward_split(self, x: torch.Tensor) -> torch.Tensor:
-        """A11 on split operands: fp32 x [N, D] (in place) -> final-normed fp32"""
+    def llm_forward_split(self, x: torch.Tensor, pos0: int = 0, total: Optional[int] = None, kv_gather=None) -> torch.Tensor:
+        """A11 on split operands: fp32 x [N, D] (in place) -> final-normed fp32.  Context-parallel use (videoitg_amd.parallel): pos0 / total /
+        kv_gather as in llm_forward - the per-layer exchange carries the local K|V rows as PAIRS ([k v hi | k v lo], twice the bytes) through the blocking
+        all-gather (the asynchronous in-place form is the default tier's)."""
         cfg, w, sw = self.cfg, self.w, self.sw
         N, D = x.shape
+        total = N if total is None else total
         Dp, Fp = pad64(D), pad64(cfg.intermediate_size)
         nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        qkv_n, op = (nq + 2 * nkv) * hd, pad64(nq * hd)
+        qkv_n, op, kvw = (nq + 2 * nkv) * hd, pad64(nq * hd), 2 * nkv * hd
         f16 = torch.float16
         h = self._buf("llm_h2", (N, 2 * Dp), f16, zero=True)
         qkv = self._buf("llm_qkv2", (N, 2 * qkv_n), f16)
         o = self._buf("llm_o2", (N, 2 * op), f16, zero=True)
         f = self._buf("llm_f2", (N, 2 * Fp), f16)
-        cos, sin = self.rope_tables(N)
+        kv_loc = self._buf("llm_kv2", (N, 2 * kvw), f16) if kv_gather is not None else None
+        cos, sin = self.rope_tables(total)
+        cos, sin = cos[pos0:pos0 + N], sin[pos0:pos0 + N]
         st = (0, 2 * qkv_n, hd)
         for lw, l2 in zip(w.llm, sw.llm):
             K.norm_split(x, lw.in_ln, None, h, D, cfg.rms_norm_eps)
             K.gemm_split16(h, l2["qkv"], qkv, mode=K.GEMM_STORE16, lo_off=qkv_n, bias=lw.qkv_b)
             K.rope_split_(qkv, cos, sin, nq + nkv, hd, qkv_n)
-            K.attention_split(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, lo=(qkv_n, qkv_n, qkv_n, op), batch=1, heads=nq, kv_heads=nkv, seq=N,
-                              head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=(0, 2 * op, hd), scale=hd ** -0.5)
+            if kv_gather is None:
+                K.attention_split(qkv, qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:], o, lo=(qkv_n, qkv_n, qkv_n, op), batch=1, heads=nq, kv_heads=nkv, seq=N,
+                                  head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=(0, 2 * op, hd), scale=hd ** -0.5)
+            else:
+                kv_loc[:, :kvw].copy_(qkv[:, nq * hd:qkv_n])                      # [k v hi | k v lo] rows of this rank
+                kv_loc[:, kvw:].copy_(qkv[:, qkv_n + nq * hd:])
+                kv = kv_gather(kv_loc)                                            # [total, 2 kvw], blocking (RowGatherer.__call__ or any callable)
+                K.attention_split(qkv, kv, kv[:, nkv * hd:], o, lo=(qkv_n, kvw, kvw, op), batch=1, heads=nq, kv_heads=nkv, seq=N, kv_seq=total, head_dim=hd,
+                                  q_strides=st, k_strides=(0, 2 * kvw, hd), v_strides=(0, 2 * kvw, hd), o_strides=(0, 2 * op, hd), scale=hd ** -0.5)
             self._gemm(o, l2["o"], x, mode=K.GEMM_F32, res=x)
             K.norm_split(x, lw.post_ln, None, h, D, cfg.rms_norm_eps)
             K.gemm_split16(h, l2["gu"], f, mode=K.GEMM_SWIGLU, lo_off=Fp)
@@ -777,9 +789,9 @@ class SelectorEngine:
         kv_len (int32 device scalar, single-GPU path): only the first kv_len rows are real tokens - the rest is bucket padding
         that no query may attend to (a captured graph serves every prompt length of its bucket)."""
         if self.operand_split:
-            if kv_gather is not None or kv_len is not None or pos0 != 0 or (total is not None and total != x.shape[0]):
-                raise NotImplementedError("the operand-split tier runs the eager one-GPU forward (no context parallelism, no bucketed graph capture)")
-            return self.llm_forward_split(x)
+            if kv_len is not None:
+                raise NotImplementedError("the operand-split tier runs eager forwards (no bucketed graph capture: its attention takes no device key count)")
+            return self.llm_forward_split(x, pos0=pos0, total=total, kv_gather=kv_gather)
         cfg, w = self.cfg, self.w
         N, D = x.shape
         total = N if total is None else total

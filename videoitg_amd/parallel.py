@@ -12,6 +12,9 @@ grid depends on the global frame count, mlp_proj.py:48), so the split that prese
   RoPE uses global positions;
 * score head: local frames -> all-gather of the T logits -> every rank ranks them.
 
+The operand-split precision tier (engine.llm_forward_split) shards the same way; its exchange carries (hi, lo) PAIRS of the K|V rows through the blocking
+form of the gather.
+
 ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests) is the only
 communication layer.  The planning and gather code is device-agnostic so the world_size-2 gloo tests exercise the
 same code that runs on the GPUs.
