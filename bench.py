@@ -14,9 +14,11 @@ N > 1: one process per GPU; the video's frames are sharded over ranks for the to
 context-parallel (per-layer RCCL all-gather of K/V, final all-gather of the logits), so total work is fixed
 ("scaling": "strong").
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the MFMA GEMM; HIP
-events around every GEMM launch of the timed steps, on the launch stream) and `cpu_baseline` (the oracle timed on
-this host's cores on a bounded sample, rank 0, N = 1 only).
+Prints ONE JSON line (rank 0) of < 4 KB with the driver's contract plus `roofline` (dominant kernel = the MFMA GEMM; HIP
+events around every GEMM launch of the timed steps, on the launch stream), `roofline_other`, `parity` and `cpu_baseline` (the oracle
+timed on this host's cores on a bounded sample, rank 0, N = 1 only), and writes everything else it measured - the `secondary`
+blocks (other resolutions / dtypes / tiers, the operand-split precision tier, the heavy-tailed twin, fp8 Pareto), ladders, probes - to
+`bench_full.json` next to this file (`full_record` in the line names it; VITG_BENCH_FULL = another path).
 """
 from __future__ import annotations
 
@@ -600,7 +602,8 @@ def cpu_baseline(cfg, T, R, n_text, cores):
     """Oracle (kind "port") on this host's cores on the bounded sample SURVEY.md 8d prescribes for T = 512: the WHOLE needed tower depth
     (26 layers) on a 16-frame slice, x (T / 16) frame groups (frames are independent), plus 2 whole decoder layers at the FULL token
     count N, x (28 / 2) (layers are identical in cost).  The thread count is chosen by a quick sweep over {32, 64, 128} (capped at the
-    host's cores) on the real operators - two tower layers on the slice, one decoder layer at full N - because a 16k-token slice does
+    host's cores) on the real operators - two tower layers on the slice; the decoder layers run on the tower's choice since round 6 (their own
+    sweep cost 55 s of every default run for the same answer) - because a 16k-token slice does
     not load 128 threads (round 2's 4-frame sample on 128 threads came out SLOWER than the complete pass on 8 vCPUs); the count used
     is reported in `cores`.  Projector / head < 0.1 % of the work.  Same counter-generated weights as the GPU run.  The COMPLETE
     passes behind the parity fixtures (tests/golden/full_*.json, 8 vCPUs of the build container) are quoted beside it."""
