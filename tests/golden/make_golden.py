@@ -102,9 +102,21 @@ def build_reference_model(g, ce, cfg: ITGConfig):
     return m
 
 
-def load_synth(m, cfg: ITGConfig, seed: int):
+def tiny_heavy_plan(cfg: ITGConfig) -> "synth.HeavyTailPlan":
+    """the massive-activation anatomy of synth.HeavyTailPlan on the toy architecture (round 6): 4 planted channels in each residual stream, a constant
+    from a bias in the first tower layers / the projector's last bias + the embedding column, 64x rows in every fc2 / down_proj, norm gains of (4, 1/4)
+    and (4, 1/8).  Power-of-two factors and 16-bit-exact constants only: the weights stay 16-bit exact."""
+    vc, lc = synth.HeavyTailPlan.channels(cfg)
+    n_vit = cfg.num_vit_layers_needed()
+    return synth.HeavyTailPlan(vc, lc, vit_norm=[(4.0, 0.25)] * n_vit, llm_norm=[(4.0, 0.125)] * cfg.num_hidden_layers, final_norm=(4.0, 0.125),
+                               row_gain=64.0, vit_bias=128.0, vit_bias_layers=(0, 1), llm_bias=1024.0)
+
+
+def load_synth(m, cfg: ITGConfig, seed: int, plan=None):
     sd = synth.synth_llm_state_dict(cfg, seed)
     vsd = synth.synth_vision_state_dict(cfg, seed)
+    if plan is not None:
+        sd, vsd = plan.apply(sd), plan.apply(vsd)
     own = m.state_dict()
     mapped = {}
     for k, t in sd.items():
@@ -148,6 +160,10 @@ CASES = {
     # the same with clips of different length: each is pooled with ITS OWN grid (4 frames -> 4x4, 8 frames -> 3x3: 64 + 72 rows), the
     # head's groups of 136 / 4 = 34 rows straddle frames and clips
     "two_images_ragged": dict(cfg=dict(vision_token_num=72), T=[4, 8], ids=[[-200, 5, 6, -200, 7]], samples=1),
+    # round 6: HEAVY-TAILED weights through the reference itself (tiny_heavy_plan: |x| ~ 10^2 - 10^3 in four channels of each residual stream), 24 frames,
+    # a 20-token prompt - the anatomy of tests/golden/full_c2o_512x448.json at a size the reference runs here, so that the precision tiers are
+    # compared with THE REFERENCE's fp32 forward on such weights and not only with the oracle's
+    "heavy_pool_post": dict(cfg=dict(vision_token_num=216), T=[24], ids=[[-200] + list(range(40, 60))], heavy=True),
 }
 # degenerate inputs (recorded in helpers.json["forward_errors"]: exception type, or shape / all-NaN flag of the logits): a sample
 # without <image> still consumes an entry of `images` (eagle_archv1.py:282-294) and then has no visual rows - the head's mean over
@@ -162,7 +178,8 @@ def run_case(g, ce, name, spec, seed=0):
     cfg = tiny_config(**spec["cfg"])
     torch.manual_seed(0)
     m = build_reference_model(g, ce, cfg)
-    load_synth(m, cfg, seed)
+    plan = tiny_heavy_plan(cfg) if spec.get("heavy") else None
+    load_synth(m, cfg, seed, plan)
     R = cfg.vision.image_size
     images = [synth.synth_pixel_values(T, R, seed=1234 + i) for i, T in enumerate(spec["T"])]
     ids = torch.tensor(spec["ids"], dtype=torch.long)
@@ -193,6 +210,9 @@ def run_case(g, ce, name, spec, seed=0):
     )
     for b, lg in enumerate(out.logits):
         rec[f"logits{b}"] = lg.numpy()
+    if plan is not None:
+        rec["heavy_tail"] = json.dumps(plan.to_json())
+        rec["stream_absmax"] = np.array([feats.abs().max().item(), max(h.abs().max().item() for h in hs[:-1])])
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
     print(name, "N=", emb.shape[1], "logits0[:4]=", out.logits[0].view(-1)[:4].tolist())
 

@@ -209,7 +209,7 @@ def test_attention_split(hd, B, H, KV, S, Sk):
 
 
 # ---- the whole forward ----------------------------------------------------------------------------------------------------------------------------
-GOLDEN = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image", "two_images", "two_images_ragged"]
+GOLDEN = ["pool_post", "nopool_prepost", "oddgrid", "batch2_pad", "chunk520", "ragged_image", "two_images", "two_images_ragged", "heavy_pool_post"]
 GOLDEN_LOGIT_TOL = 2e-4        # on fixtures the REFERENCE ITSELF produced (tests/golden/make_golden.py); the fp16 default sits at 1e-3 .. 1e-2 in logit
 # History: the first build of the tier MISSED this bound on chunk520 (4.65e-4, gpurun_out/r06_c4) - which is what exposed the compiler-contraction bug
 # described at ELEM_REL below (one output element in ~10^4 off by an fp16 ulp).  With the values pinned every fixture is at 2e-6 .. 1.3e-5
@@ -233,7 +233,11 @@ def test_split_tier_matches_reference_golden(golden_dir, name):
     seed = int(z["seed"])
     T = z["T"].tolist()
     images = [synth.synth_pixel_values(t, cfg.vision.image_size, seed=1234 + i).half().to(DEV) for i, t in enumerate(T)]
-    eng = split_engine(cfg, synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed))
+    sd, vsd = synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed)
+    if "heavy_tail" in z:                              # heavy_pool_post: the REFERENCE's forward on weights with massive-activation channels
+        plan = synth.HeavyTailPlan.from_json(json.loads(str(z["heavy_tail"])))
+        sd, vsd = plan.apply(sd), plan.apply(vsd)
+    eng = split_engine(cfg, sd, vsd)
     got = eng.forward(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), images)
     torch.cuda.synchronize()
     worst = worst_s = 0.0
@@ -424,3 +428,28 @@ def test_operand_split_tier_context_parallel_on_one_gpu():
     d = (got - want).abs().max().item()
     print(f"operand-split tier, context-parallel x2: max|dlogit| vs one rank = {d:.2e}")
     assert d <= 2e-5, d
+
+
+def test_heavy_tailed_weights_against_the_reference_itself(golden_dir):
+    """tests/golden/heavy_pool_post.npz is the REFERENCE's own fp32 forward (tests/golden/make_golden.py) on toy-size weights with massive-activation
+    channels (|x| max 989 in the tower stream, 1 328 in the decoder's).  CPU rounding models against it (oracle/quant_model.py): the product's 16-bit sites
+    1.9e-3 in logit / 4.7e-4 in score, the reference's OWN model.half() arithmetic 5.8e-3 / 1.3e-3 - it misses north_star's 1e-3 against its own fp32 path.
+    Measured here: the fp16 default inside 1e-3 in score at this size, the operand-split tier >= 50x closer (bounds: 2e-4 logit as for every golden)."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    z = np.load(os.path.join(golden_dir, "heavy_pool_post.npz"))
+    cfg = ITGConfig.from_dict(json.loads(str(z["cfg"])))
+    plan = synth.HeavyTailPlan.from_json(json.loads(str(z["heavy_tail"])))
+    sd, vsd = plan.apply(synth.synth_llm_state_dict(cfg, 0)), plan.apply(synth.synth_vision_state_dict(cfg, 0))
+    pix = synth.synth_pixel_values(int(z["T"][0]), cfg.vision.image_size, seed=1234).half().to(DEV)
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    want = torch.from_numpy(z["logits0"]).float().view(-1)
+    res = {}
+    for tier, eng in (("fp16", SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, DEV))), ("split", split_engine(cfg, sd, vsd))):
+        got = eng.forward(ids, mask, [pix])[0].view(-1).float().cpu()
+        res[tier] = ((got - want).abs().max().item(), (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item())
+    print(f"heavy-tailed reference golden: fp16 default dlogit {res['fp16'][0]:.2e} dscore {res['fp16'][1]:.2e}; operand-split dlogit {res['split'][0]:.2e} "
+          f"dscore {res['split'][1]:.2e}")
+    assert res["fp16"][1] <= 1e-3
+    assert res["split"][0] <= 2e-4 and res["split"][0] * 50 <= res["fp16"][0]
