@@ -453,3 +453,33 @@ def test_heavy_tailed_weights_against_the_reference_itself(golden_dir):
           f"dscore {res['split'][1]:.2e}")
     assert res["fp16"][1] <= 1e-3
     assert res["split"][0] <= 2e-4 and res["split"][0] * 50 <= res["fp16"][0]
+
+
+def test_split_entries_refuse_bad_arguments():
+    """C-ABI argument checks of the round-6 entry points: nothing is launched on a bad shape / alignment (VITG_ERR_* -> VitgError)"""
+    from videoitg_amd._lib import VitgError
+    from videoitg_amd.torch_ops import K
+    x = torch.randn(8, 144, device=DEV)
+    w = torch.ones(144, device=DEV)
+    out = torch.zeros(8, 2 * 192, dtype=torch.float16, device=DEV)
+    K.norm_split(x, w, None, out, 144, 1e-6)                                   # fine
+    with pytest.raises((VitgError, RuntimeError)):
+        K.norm_split(x, w, None, torch.zeros(8, 200, dtype=torch.float16, device=DEV), 144, 1e-6)          # two planes of 144 do not fit 200 columns
+    with pytest.raises((VitgError, RuntimeError)):
+        K.norm_split(x.view(-1)[1:1 + 7 * 144].view(7, 144), w, None, out[:7], 144, 1e-6)                  # rows not 16-B aligned
+    a2 = torch.zeros(64, 128, dtype=torch.float16, device=DEV)
+    w2 = torch.zeros(256, 128, dtype=torch.float16, device=DEV)
+    o2 = torch.zeros(64, 512, dtype=torch.float16, device=DEV)
+    K.gemm_split16(a2, w2, o2, mode=K.GEMM_STORE16, lo_off=256)               # fine
+    with pytest.raises((VitgError, RuntimeError)):
+        K.gemm_split16(a2, w2, o2, mode=K.GEMM_STORE16, lo_off=128)           # planes would overlap
+    with pytest.raises((VitgError, RuntimeError)):
+        K.gemm_split16(a2, w2, o2, mode=K.GEMM_F32, lo_off=256)               # pairs are a 16-bit-output form
+    q = torch.zeros(64, 2 * 3 * 128, dtype=torch.float16, device=DEV)
+    o = torch.zeros(64, 2 * 128, dtype=torch.float16, device=DEV)
+    kw = dict(batch=1, heads=1, kv_heads=1, seq=64, q_strides=(0, 768, 128), k_strides=(0, 768, 128), v_strides=(0, 768, 128), o_strides=(0, 256, 128), scale=0.1)
+    K.attention_split(q, q[:, 128:], q[:, 256:], o, lo=(384, 384, 384, 128), head_dim=128, **kw)       # fine
+    with pytest.raises((VitgError, RuntimeError)):
+        K.attention_split(q, q[:, 128:], q[:, 256:], o, lo=(384, 384, 384, 128), head_dim=64, **kw)    # head dims 72 and 128 only
+    with pytest.raises((VitgError, RuntimeError)):
+        K.attention_split(q, q[:, 128:], q[:, 256:], o, lo=(383, 384, 384, 128), head_dim=128, **kw)   # lo plane offset not 16-B aligned

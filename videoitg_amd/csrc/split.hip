@@ -363,6 +363,7 @@ extern "C" int vitg_norm_split(const float* x, int ldx, const float* w, const fl
     if (M <= 0) return 0;
     if (!x || !w || !out) return VITG_ERR_ARG;
     if (D % 4 || ldo % 4 || ldx % 4 || lo_off % 4) return VITG_ERR_ALIGN;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (b && ((uintptr_t)b & 15)) || ((uintptr_t)out & 7)) return VITG_ERR_ALIGN;
     if (lo_off < D || ldo < 2 * lo_off) return VITG_ERR_SHAPE;
     const int need = ceil_div(lo_off, 256);
     dim3 blk(256), grid((unsigned)((M + 3) / 4));
@@ -404,6 +405,7 @@ extern "C" int vitg_attention_split(const void* q, const void* k, const void* v,
     if (head_dim != 72 && head_dim != 128) return VITG_ERR_SHAPE;
     if ((o_rs | o_hs) % 4 || (o_lo % 4)) return VITG_ERR_ALIGN;
     if ((q_rs | k_rs | v_rs | q_hs | k_hs | v_hs) % 8 || (q_bs | k_bs | v_bs | q_lo | k_lo | v_lo) % 8) return VITG_ERR_ALIGN;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) || ((uintptr_t)o & 7)) return VITG_ERR_ALIGN;      // 16-B fragment loads, 8-B output stores
     AttnSplitArgs a;
     a.q = (const f16_t*)q; a.k = (const f16_t*)k; a.v = (const f16_t*)v; a.o = (f16_t*)o;
     a.q_lo = q_lo; a.k_lo = k_lo; a.v_lo = v_lo; a.o_lo = o_lo;
