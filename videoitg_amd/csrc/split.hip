@@ -197,22 +197,44 @@ __global__ __launch_bounds__(AS_NW * 64, 2) void attn_split_kernel(AttnSplitArgs
     // staging: thread -> (row, 16-B chunk) of a 64-row tile, the LDS images of attention.hip (K: k_lds_off, V: row-major, hd 128 XOR-swizzled 64-B units)
     constexpr int NCH = ATT_BK * C::CH;
     constexpr int PER = (NCH + THREADS - 1) / THREADS;
+    // hd 72 prefetches the next tile's four planes into registers while the current tile computes (48 VGPRs; hd 128 has none to spare: 255 in use).
+    // Worth 0.7 % of the tier's step in three same-call alternations (1 432 -> 1 421 ms, gpurun_out/r06_c23): the kernel is bound by its 3x MFMA stream
+    // and the softmax beside it, not by staging latency.
+#ifndef VITG_SPLIT_PREFETCH
+#define VITG_SPLIT_PREFETCH 1
+#endif
+    constexpr bool PREFETCH = D == 72 && VITG_SPLIT_PREFETCH;
+    u32x4 rg[PREFETCH ? PER : 1][4];
+    auto load_tile = [&](int kt, u32x4 (&r)[PREFETCH ? PER : 1][4], int i) {
+        const int c = tid + i * THREADS;
+        const int row = c / C::CH, ch = c % C::CH;
+        const long gr = min((long)kt * ATT_BK + row, (long)a.Sk - 1);          // rows past the last key: any finite filler (their scores are masked)
+        const T* kp = K + gr * a.k_rs + ch * 8;
+        const T* vp = V + gr * a.v_rs + ch * 8;
+        r[PREFETCH ? i : 0][0] = *(const u32x4*)kp; r[PREFETCH ? i : 0][1] = *(const u32x4*)(kp + a.k_lo);
+        r[PREFETCH ? i : 0][2] = *(const u32x4*)vp; r[PREFETCH ? i : 0][3] = *(const u32x4*)(vp + a.v_lo);
+    };
+    auto store_tile = [&](const u32x4 (&r)[PREFETCH ? PER : 1][4], int i) {
+        const int c = tid + i * THREADS;
+        const int row = c / C::CH, ch = c % C::CH;
+        const int lk = k_lds_off<D>(row, ch);
+        const int vch = D == 128 ? (ch ^ ((row & 3) << 2)) : ch;
+        const int lv = row * (C::LDV * 2) + (vch << 4);
+        *(u32x4*)(kh_s + lk) = r[PREFETCH ? i : 0][0]; *(u32x4*)(kl_s + lk) = r[PREFETCH ? i : 0][1];
+        *(u32x4*)(vh_s + lv) = r[PREFETCH ? i : 0][2]; *(u32x4*)(vl_s + lv) = r[PREFETCH ? i : 0][3];
+    };
+    auto prefetch = [&](int kt) {                            // PREFETCH: issue the global loads of tile kt (consumed by publish() one iteration later)
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if ((NCH % THREADS == 0) || tid + i * THREADS < NCH) load_tile(kt, rg, i);
+    };
+    // staging: thread -> (row, 16-B chunk) of a 64-row tile, the LDS images of attention.hip (K: k_lds_off, V: row-major, hd 128 XOR-swizzled 64-B units)
     auto stage = [&](int kt) {
-        const long krow0 = (long)kt * ATT_BK;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int c = tid + i * THREADS;
-            if ((NCH % THREADS == 0) || c < NCH) {
-                const int row = c / C::CH, ch = c % C::CH;
-                const long gr = min(krow0 + row, (long)a.Sk - 1);          // rows past the last key: any finite filler (their scores are masked)
-                const T* kp = K + gr * a.k_rs + ch * 8;
-                const T* vp = V + gr * a.v_rs + ch * 8;
-                const u32x4 r0 = *(const u32x4*)kp, r1 = *(const u32x4*)(kp + a.k_lo), r2 = *(const u32x4*)vp, r3 = *(const u32x4*)(vp + a.v_lo);
-                const int lk = k_lds_off<D>(row, ch);
-                const int vch = D == 128 ? (ch ^ ((row & 3) << 2)) : ch;
-                const int lv = row * (C::LDV * 2) + (vch << 4);
-                *(u32x4*)(kh_s + lk) = r0; *(u32x4*)(kl_s + lk) = r1;
-                *(u32x4*)(vh_s + lv) = r2; *(u32x4*)(vl_s + lv) = r3;
+            if ((NCH % THREADS == 0) || tid + i * THREADS < NCH) {
+                if constexpr (!PREFETCH) load_tile(kt, rg, i);
+                store_tile(rg, i);
             }
         }
         if constexpr (D == 72) {
@@ -240,9 +262,11 @@ __global__ __launch_bounds__(AS_NW * 64, 2) void attn_split_kernel(AttnSplitArgs
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) voff_dt[dt] = voff + (D == 128 ? ((dt ^ ((lane & 15) >> 2)) * 64) : dt * 64);
 
+    if constexpr (PREFETCH) prefetch(0);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                                  // every wave is done with the previous tile
         stage(kt);
+        if constexpr (PREFETCH) { if (kt + 1 < nkt) prefetch(kt + 1); }      // lands while this tile computes
         __syncthreads();
         // ---- S^T = Kh Qh^T + Kh Ql^T + Kl Qh^T : two 32-key tiles (small terms first) -------------------------------------------------
         f32x16 s[2];
