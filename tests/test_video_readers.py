@@ -201,7 +201,7 @@ def test_y4m_round_trip_and_plugin_loader(tmp_path, no_decoders):
 def test_files_that_need_a_codec_still_raise_like_the_reference(tmp_path, no_decoders):
     from videoitg_amd import video_io
     with pytest.raises(ImportError):
-        mm_utils.read_video_decord(str(tmp_path / "movie.mp4"), num_frm=4)                   # no decord, not a codec-free container
+        mm_utils.read_video_decord(str(tmp_path / "movie.mkv"), num_frm=4)                   # no decord, not a container the built-in reader parses
     bad = tmp_path / "not_a_video.avi"
     bad.write_bytes(b"hello, this is not RIFF")
     with pytest.raises(ValueError):
@@ -287,3 +287,80 @@ def test_animated_images_are_videos_too(tmp_path, no_decoders, fmt, suffix, exac
     assert got.shape == want.shape and (np.array_equal(got, want) if exact else np.abs(got.astype(int) - want.astype(int)).max() <= 4)
     imgs, idx = plug.load_video(path, num_frames=8, target_fps=1)
     assert len(imgs) == len(idx) >= 1 and imgs[0].size == (44, 32)
+
+
+@pytest.mark.parametrize("codec,kw,exact", [("raw ", {}, True), ("png ", {"co64": True}, True), ("jpeg", {"per_chunk": 2}, False),
+                                            ("mp4v-jpeg", {"per_chunk": 50}, False)])
+def test_quicktime_and_mp4_tracks_of_individually_coded_frames(tmp_path, no_decoders, codec, kw, exact):
+    """Round 6: *.mov / *.mp4 are CONTAINERS; when the track's samples are individually coded (QuickTime Photo-JPEG 'jpeg', 'png ', uncompressed
+    'raw ', or Motion-JPEG as MP4 muxers label it: 'mp4v' + esds objectTypeIndication 0x6C) the sample table (stsc runs x 32- / 64-bit chunk offsets x
+    stsz) gives every frame's bytes and Pillow decodes them - read_video_decord runs end to end on such a file without decord / PyAV."""
+    from videoitg_amd import video_io
+    clip = _clip(T=40, h=34, w=46)
+    path = str(tmp_path / ("clip.mp4" if codec == "mp4v-jpeg" else "clip.mov"))
+    video_io.write_mov(path, clip, fps=30000 / 1001, codec=codec, **kw)
+    vr = video_io.VideoReader(path)
+    assert len(vr) == 40 and (vr.width, vr.height) == (46, 34) and abs(vr.get_avg_fps() - 30000 / 1001) < 1e-6
+    frames, idx, seconds = mm_utils.read_video_decord(path, num_frm=8, target_fps=2)           # infer.py:44-51
+    assert list(idx) == mm_utils.get_frame_indices(40, 30000 / 1001, 2, 8) and frames.shape == (len(idx), 34, 46, 3) and frames.dtype == np.uint8
+    err = np.abs(frames.astype(int) - clip[list(idx)].astype(int))
+    assert err.max() == 0 if exact else err.mean() < 3.0
+    assert np.array_equal(vr[-1].asnumpy(), vr[39].asnumpy())
+
+
+def test_mp4_with_a_coded_track_names_the_codec_and_leaves_it_to_pyav(tmp_path, fake_av, monkeypatch):
+    """an 'avc1' track (what nearly every real .mp4 holds): the container still parses - frame count, size, rate - and the error is the reference's
+    ImportError (eagle/mm_utils.py:27-29 without decord) with the codec's name in it; the plugin's loader then goes to PyAV as the reference does"""
+    from videoitg_amd import video_io
+    from videoitg_amd.lmms_plugin.models import videoitg as plug
+    monkeypatch.setitem(sys.modules, "decord", None)
+    path = str(tmp_path / "movie.mp4")
+    video_io.write_mov(path, _clip(T=5), fps=25.0, codec="raw ")
+    raw = bytearray(open(path, "rb").read())
+    k = raw.index(b"stsd") + 4 + 8 + 4
+    assert raw[k:k + 4] == b"raw "
+    raw[k:k + 4] = b"avc1"
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(ImportError, match=r"'avc1' \(H\.264\), 5 frames .* at 25\.000 fps"):
+        mm_utils.read_video_decord(path, num_frm=4)
+    imgs, idx = plug.load_video(path, num_frames=8, target_fps=1)          # PyAV (the fake: 900 frames at 30 fps)
+    assert list(idx) == mm_utils.get_seq_frames(900, 30.0, 1, 8) and len(imgs) == 8
+    monkeypatch.setitem(sys.modules, "av", None)
+    with pytest.raises(ImportError, match="H.264"):
+        plug.load_video(path, num_frames=8, target_fps=1)
+
+
+def test_mp4_container_edge_cases(tmp_path, no_decoders):
+    """moov before mdat with a 64-bit 'largesize' mdat header (files over 4 GiB use both), a truncated download, a file without a video track"""
+    import struct
+    from videoitg_amd import video_io
+    clip = _clip(T=6, h=10, w=12)
+    path = str(tmp_path / "a.mov")
+    video_io.write_mov(path, clip, fps=12.0, codec="raw ", per_chunk=4)
+    raw = open(path, "rb").read()
+    ft = struct.unpack_from(">I", raw, 0)[0]
+    md = struct.unpack_from(">I", raw, ft)[0]
+    ftyp, mdat, moov = raw[:ft], raw[ft:ft + md], bytearray(raw[ft + md:])
+    # re-mux: ftyp, moov, then mdat with a largesize header -> every chunk offset moves by len(moov) + 8
+    k = moov.index(b"stco") + 4 + 4
+    (n,) = struct.unpack_from(">I", moov, k)
+    for i in range(n):
+        (o,) = struct.unpack_from(">I", moov, k + 4 + 4 * i)
+        struct.pack_into(">I", moov, k + 4 + 4 * i, o + len(moov) + 8)
+    big = struct.pack(">I4sQ", 1, b"mdat", len(mdat) + 8) + mdat[8:]
+    p2 = str(tmp_path / "faststart.mov")
+    open(p2, "wb").write(ftyp + bytes(moov) + big)
+    vr = video_io.VideoReader(p2)
+    assert len(vr) == 6 and vr.get_avg_fps() == 12.0 and np.array_equal(vr.get_batch(list(range(6))).asnumpy(), clip)
+    p3 = str(tmp_path / "cut.mov")
+    open(p3, "wb").write(ftyp + bytes(moov) + big[:len(big) // 2])
+    with pytest.raises(ValueError, match="past the end"):
+        video_io.VideoReader(p3)
+    p4 = str(tmp_path / "audio_only.mov")
+    open(p4, "wb").write(raw.replace(b"vide", b"soun"))
+    with pytest.raises(ValueError, match="no video track"):
+        video_io.VideoReader(p4)
+    p5 = str(tmp_path / "no_moov.mp4")
+    open(p5, "wb").write(ftyp + mdat)
+    with pytest.raises(ValueError, match="no 'moov' box"):
+        video_io.VideoReader(p5)

@@ -84,13 +84,16 @@ def pad_sequence(tokenizer, input_ids: Sequence[torch.Tensor], batch_first: bool
 
 def open_video_reader(video_path: str, num_threads: int = 4):
     """decord.VideoReader(path, ctx=cpu(0)) as the reference opens it (infer.py:45; lmms_eval/models/videoitg.py:98) - or, when decord is
-    not installed AND the file is one of the two container formats that need no codec (MJPEG / uncompressed AVI, YUV4MPEG2), the built-in
-    reader with the same call surface (videoitg_amd.video_io).  Any other file without decord raises the ImportError the reference raises."""
+    not installed AND the file is in a container the built-in reader parses (videoitg_amd.video_io: AVI, YUV4MPEG2, animated images, ISO base
+    media / QuickTime) with frames that need no codec library, that reader with the same call surface.  Anything else without decord raises
+    the ImportError the reference raises."""
     try:
         from decord import VideoReader, cpu
     except ImportError:
         from . import video_io
-        if not str(video_path).lower().endswith(video_io.SUFFIXES):
+        # .mp4 / .mov / .m4v: the built-in reader parses the container; a track of individually coded frames (Motion-JPEG, PNG, uncompressed) is
+        # decoded, a track that needs a codec raises video_io.CodecNeeded - an ImportError like the one above, naming the codec
+        if not str(video_path).lower().endswith(video_io.SUFFIXES + video_io.BMFF_SUFFIXES):
             raise
         return video_io.VideoReader(video_path, ctx=None, num_threads=num_threads)
     return VideoReader(video_path, ctx=cpu(0), num_threads=num_threads)
