@@ -1165,30 +1165,32 @@ def main():
                                           "algorithmic_tflop_per_video": round(fl0["total"] / 1e12, 1),
                                           "parity": parity_block(T, 384, args.prompt_len, args.seed, b0["logits"], b0["order"])}
             del pix0
-            # C1 = 64 frames at 384^2: no pooling below T = 64 -> 16 x 16 tokens per frame, N = 16 444 - the LLM-heavy configuration
-            # (attention is 30 % of its FLOPs), with its own complete-pass oracle fixture
-            ids1, pix1 = synth.workload_inputs(cfg, 64, 384, args.prompt_len)
-            pix1 = pix1.to(dtype).to(dev)
-            c1 = {}
+            # C1 = 64 frames at 384^2: 27 x 27 tokens pooled to 16 x 16 per frame, N = 16 444 - the LLM-heavy configuration (attention is
+            # 30 % of its FLOPs); C0 = BASELINE configs[0]'s own shape, 64 uniformly sampled 224^2 frames: the tower grid IS the 16 x 16 pooled grid (the
+            # projector's no-pool branch), same N.  Each with its own complete-pass oracle fixture.
+            for key_, res_, what_ in (("c1_64x384", 384, "decoder-heavy"), ("c0_64x224", 224, "configs[0]'s shape, no-pool branch")):
+                ids1, pix1 = synth.workload_inputs(cfg, 64, res_, args.prompt_len)
+                pix1 = pix1.to(dtype).to(dev)
+                c1 = {}
 
-            def step_c1():
-                c1["logits"] = eng.forward(ids1, None, [pix1])[0].view(-1)
-                _, order_ = ops.rank(c1["logits"])
-                c1["order"] = order_.cpu().tolist()
-            step_c1()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            step_c1()
-            step_c1()
-            torch.cuda.synchronize()
-            d2 = (time.perf_counter() - t2) / 2
-            fl1 = algorithmic_flops(cfg, 64, 384, ids1.shape[1] - 1)
-            out["secondary"]["c1_64x384"] = {"input": f"64 x 384^2, N={fl1['N']} (decoder-heavy: attention {fl1['llm_attn'] / fl1['total']:.0%} of the FLOPs)",
-                                             "value": round(64 / d2, 2), "unit": "frames/s", "ms_per_step": round(d2 * 1e3, 2),
-                                             "algorithmic_tflop_per_video": round(fl1["total"] / 1e12, 1),
-                                             "end_to_end_tflops": round(fl1["total"] / d2 / 1e12, 1),
-                                             "parity": parity_block(64, 384, args.prompt_len, args.seed, c1["logits"], c1["order"])}
-            del pix1
+                def step_c1():
+                    c1["logits"] = eng.forward(ids1, None, [pix1])[0].view(-1)
+                    _, order_ = ops.rank(c1["logits"])
+                    c1["order"] = order_.cpu().tolist()
+                step_c1()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                step_c1()
+                step_c1()
+                torch.cuda.synchronize()
+                d2 = (time.perf_counter() - t2) / 2
+                fl1 = algorithmic_flops(cfg, 64, res_, ids1.shape[1] - 1)
+                out["secondary"][key_] = {"input": f"64 x {res_}^2, N={fl1['N']} ({what_}: attention {fl1['llm_attn'] / fl1['total']:.0%} of the FLOPs)",
+                                          "value": round(64 / d2, 2), "unit": "frames/s", "ms_per_step": round(d2 * 1e3, 2),
+                                          "algorithmic_tflop_per_video": round(fl1["total"] / 1e12, 1),
+                                          "end_to_end_tflops": round(fl1["total"] / d2 / 1e12, 1),
+                                          "parity": parity_block(64, res_, args.prompt_len, args.seed, c1["logits"], c1["order"])}
+                del pix1
             # the planted-signal twin of the workload on the 16-bit default (the fp8 tiers report the same block below)
             out["secondary"]["planted_signal"] = planted_block(eng, cfg, T, R, args.prompt_len, args.seed, dtype, dev) if args.config == "full" else None
             # the heavy-tailed twin: same workload on weights with massive-activation channels, both tower streams, stated bounds

@@ -48,6 +48,10 @@ CASES = {
     # round 6: planted twins of the reference-native shape and of the decoder-heavy 64-frame video
     "b0p_512x384": (512, 384, 60, 0, 1234, 32),
     "c1p_64x384": (64, 384, 60, 0, 1234, 32),
+    # BASELINE.json configs[0]'s own shape (64 uniformly sampled 224^2 frames: 16 x 16 tower grid = the pooled grid, i.e. the projector's NO-POOL branch,
+    # mlp_proj.py:48-56 with h == hw) at full depth and width, and its planted twin
+    "c0_64x224": (64, 224, 60),
+    "c0p_64x224": (64, 224, 60, 0, 1234, 32),
 }
 # heavy-tailed weights (videoitg_amd.synth.HeavyTailPlan: outlier channels planted through fc2 / down rows, biases and norm gains the
 # way trained towers carry them).  Same sizes, inputs and base draw as the case without the "o".

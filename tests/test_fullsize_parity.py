@@ -25,8 +25,11 @@ TOL = {torch.float16: SCORE_TOL, torch.bfloat16: 2.5e-3}
 CEIL = {torch.float16: 4e-4, torch.bfloat16: 2.5e-3}
 CASES = ["depth16_224", "depth16_224_s1", "depth24_280_s2", "c1_64x384", "b0_512x384", "c2_512x448",
          # planted per-frame signal (synth.planted_inputs): the oracle's Top-k is the planted set behind a wide gap
-         "depth16p_224", "c2p_512x448", "b0p_512x384", "c1p_64x384"]
-MUST_MATCH_TOPK_FP16 = {"b0_512x384", "c2_512x448", "c1_64x384", "c2p_512x448", "b0p_512x384", "c1p_64x384", "depth16p_224"}
+         "depth16p_224", "c2p_512x448", "b0p_512x384", "c1p_64x384",
+         # BASELINE.json configs[0]'s own shape - 64 uniformly sampled 224^2 frames: tower grid 16 x 16 = the pooled grid, the projector's NO-POOL branch
+         # (mlp_proj.py:48-56 with h == hw) - at full depth and width, and its planted twin (round 6)
+         "c0_64x224", "c0p_64x224"]
+MUST_MATCH_TOPK_FP16 = {"b0_512x384", "c2_512x448", "c1_64x384", "c2p_512x448", "b0p_512x384", "c1p_64x384", "depth16p_224", "c0_64x224", "c0p_64x224"}
 # heavy-tailed weights (synth.HeavyTailPlan): planted channels 10^2 - 10^3 in both residual streams.  Their own test and their own
 # STATED bounds below: with massive-activation channels every 16-bit-operand implementation - the reference's own model.half() arithmetic included -
 # sits above north_star's 1e-3 at the headline size (profiles/r05_heavy_tail.md: the norm statistics are dominated by the planted channels, so their

@@ -260,7 +260,7 @@ def _full_case(golden_dir, name):
 
 
 # (max |dscore|, max |dlogit|) STATED before the first run: north_star's 1e-3 with a 10x margin, and the logit bound that implies it everywhere
-FULL = {"depth16o_224": (1e-4, 2e-3), "c2o_512x448": (1e-4, 4e-3), "c2_512x448": (1e-4, 2e-3)}
+FULL = {"depth16o_224": (1e-4, 2e-3), "c2o_512x448": (1e-4, 4e-3), "c2_512x448": (1e-4, 2e-3), "c0_64x224": (1e-4, 2e-3)}     # (c0: the no-pool branch, bound stated before its first run)
 
 
 @pytest.mark.parametrize("name", list(FULL))
