@@ -52,6 +52,8 @@ CASES = {
     # mlp_proj.py:48-56 with h == hw) at full depth and width, and its planted twin
     "c0_64x224": (64, 224, 60),
     "c0p_64x224": (64, 224, 60, 0, 1234, 32),
+    # more than 512 frames at full depth and width: the projector's chunk branch (mlp_proj.py: T > 512) with a 5 x 5 pooled grid, N = 13 060
+    "t520_224": (520, 224, 60),
 }
 # heavy-tailed weights (videoitg_amd.synth.HeavyTailPlan: outlier channels planted through fc2 / down rows, biases and norm gains the
 # way trained towers carry them).  Same sizes, inputs and base draw as the case without the "o".
