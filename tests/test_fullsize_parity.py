@@ -19,7 +19,7 @@ import torch
 SCORE_TOL = 1e-3
 TOL = {torch.float16: SCORE_TOL, torch.bfloat16: 2.5e-3}
 # Top-K identity: asserted whenever the oracle's own rank-K / K+1 gap exceeds twice the path's error CEILING on this fixture class -
-# a stated number per dtype (fp16 on the benign N(0, 1/fan_in) draws: 4e-4, the worst ever measured is 3.4e-4), itself asserted below, or this run's
+# a stated number per dtype (fp16 on the benign N(0, 1/fan_in) draws: 4e-4, the worst ever measured is 3.75e-4: t520_224), itself asserted below, or this run's
 # measured max error if that is larger.  With 2 x 1e-3 as the threshold (rounds 2-5) the reference-native 512 x 384^2 video (gap 1.35e-3) and the
 # headline video (1.56e-3) never had their Top-32 set checked here.
 CEIL = {torch.float16: 4e-4, torch.bfloat16: 2.5e-3}
@@ -28,8 +28,10 @@ CASES = ["depth16_224", "depth16_224_s1", "depth24_280_s2", "c1_64x384", "b0_512
          "depth16p_224", "c2p_512x448", "b0p_512x384", "c1p_64x384",
          # BASELINE.json configs[0]'s own shape - 64 uniformly sampled 224^2 frames: tower grid 16 x 16 = the pooled grid, the projector's NO-POOL branch
          # (mlp_proj.py:48-56 with h == hw) - at full depth and width, and its planted twin (round 6)
-         "c0_64x224", "c0p_64x224"]
-MUST_MATCH_TOPK_FP16 = {"b0_512x384", "c2_512x448", "c1_64x384", "c2p_512x448", "b0p_512x384", "c1p_64x384", "depth16p_224", "c0_64x224", "c0p_64x224"}
+         "c0_64x224", "c0p_64x224",
+         # more than 512 frames (the projector's chunk branch, mlp_proj.py:57-64): 520 x 224^2, 5 x 5 pooled grid, N = 13 060
+         "t520_224"]
+MUST_MATCH_TOPK_FP16 = {"b0_512x384", "c2_512x448", "c1_64x384", "c2p_512x448", "b0p_512x384", "c1p_64x384", "depth16p_224", "c0_64x224", "c0p_64x224", "t520_224"}
 # heavy-tailed weights (synth.HeavyTailPlan): planted channels 10^2 - 10^3 in both residual streams.  Their own test and their own
 # STATED bounds below: with massive-activation channels every 16-bit-operand implementation - the reference's own model.half() arithmetic included -
 # sits above north_star's 1e-3 at the headline size (profiles/r05_heavy_tail.md: the norm statistics are dominated by the planted channels, so their
