@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""GPU: time-bounded differential fuzzing of the C-ABI kernels against torch fp32 on the values the kernel saw.  The test suite pins chosen shapes; this
+draws shapes nobody chose - ragged M, N that is only a multiple of 4, strided operands, one-key attention, key counts that straddle tile edges, ties in
+the ranking - and reports every case outside the same error bounds the tests use.  Not part of the suite (its run time is the argument).
+
+    python tools/fuzz_kernels.py [seconds per family = 40] [seed = 0]        -> one line per family, failures listed with their shapes; exit 1 on any
+"""
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videoitg_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+EPS = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+gen = torch.Generator().manual_seed(seed)
+
+
+def ri(lo, hi):
+    return int(torch.randint(lo, hi + 1, (1,), generator=gen).item())
+
+
+def pick(*xs):
+    return xs[ri(0, len(xs) - 1)]
+
+
+def rnd(shape, scale=1.0, dtype=torch.float32):
+    return (torch.randn(shape, generator=gen) * scale).to(dtype)
+
+
+def strided(t, extra):
+    """the same values behind a row stride that exceeds the width (a view into a wider buffer)"""
+    if not extra:
+        return t.to(DEV).contiguous()
+    buf = torch.full((t.shape[0], t.shape[1] + extra), float("nan"), dtype=t.dtype, device=DEV)
+    buf[:, :t.shape[1]] = t.to(DEV)
+    return buf[:, :t.shape[1]]
+
+
+def rows_m():
+    return pick(ri(1, 40), ri(1, 700), ri(200, 5000), ri(200, 5000), ri(5000, 70000))
+
+
+def fuzz_gemm():
+    dt = pick(torch.float16, torch.bfloat16)
+    M, N, K = rows_m(), 4 * ri(1, 1100), 64 * ri(1, pick(8, 8, 40, 80))
+    if M * N > 6e7 or M * K > 6e7:
+        M = max(1, int(6e7 // max(N, K)))
+    form = pick("store16", "store16", "f32", "f32_mod", "swiglu", "res16")
+    a, w = rnd((M, K), 1.0, dt), rnd((N, K), K ** -0.5, dt)
+    b = rnd((N,), 0.1) if ri(0, 3) else None
+    af, wf = a.float().to(DEV), w.float().to(DEV)                          # reference on the device through torch's own fp32 GEMM (analysis only): more cases per second
+    mm = lambda x, y: (x @ y.t()).cpu()                                    # noqa: E731
+    ad, wd = strided(a, pick(0, 0, 8, 64)), strided(w, pick(0, 0, 8))
+    lo = pick(0, 0, 4, 36)
+    what = f"gemm {form} {dt} M={M} N={N} K={K} lda={ad.stride(0)} ldw={wd.stride(0)} ldo+={lo} bias={b is not None}"
+    ref = mm(af, wf) + (b if b is not None else 0)
+    if form == "store16":
+        act = pick(ops.ACT_NONE, ops.ACT_GELU_TANH, ops.ACT_GELU_ERF)
+        ref = {ops.ACT_NONE: lambda x: x, ops.ACT_GELU_TANH: lambda x: F.gelu(x, approximate="tanh"), ops.ACT_GELU_ERF: F.gelu}[act](ref)
+        out = strided(torch.full((M, N), float("nan"), dtype=dt), lo)
+        ops.gemm(ad, wd, out, mode=ops.GEMM_STORE16, bias=None if b is None else b.to(DEV), act=act)
+        tol = EPS[dt] * ref.abs().max().item() + 1e-3
+        return what + f" act={act}", (out.float().cpu() - ref).abs().max().item(), tol
+    if form in ("f32", "f32_mod"):
+        if form == "f32_mod":
+            P = ri(1, max(1, min(M, 900)))
+            res = rnd((P, N))
+            ref = ref + res.repeat(M // P + 1, 1)[:M]
+            out = strided(torch.full((M, N), float("nan")), lo)
+            ops.gemm(ad, wd, out, mode=ops.GEMM_F32, bias=None if b is None else b.to(DEV), res=res.to(DEV), res_mod=P)
+        else:
+            x = rnd((M, N))
+            ref = ref + x
+            out = strided(x, lo)
+            ops.gemm(ad, wd, out, mode=ops.GEMM_F32, bias=None if b is None else b.to(DEV), res=out)
+        return what, (out.cpu() - ref).abs().max().item(), 2e-4 * math.sqrt(K)
+    if form == "res16":
+        x = rnd((M, N), 1.0, dt)
+        ref = ref + x.float()
+        out = strided(x, lo)
+        ops.gemm_res16(ad, wd, out, bias=None if b is None else b.to(DEV), res16=out)
+        return what, (out.float().cpu() - ref).abs().max().item(), EPS[dt] * ref.abs().max().item() + 1e-3
+    # swiglu: N = 2 * fp rows interleaved in 32-row groups [gate | up]
+    Fq = 4 * ri(1, 600)
+    fp = ops.pad64(Fq)
+    g, u = rnd((Fq, K), K ** -0.5, dt), rnd((Fq, K), K ** -0.5, dt)
+    ref = F.silu(mm(af, g.float().to(DEV))) * mm(af, u.float().to(DEV))
+    gp = F.pad(g, (0, 0, 0, fp - Fq)).reshape(fp // 32, 1, 32, K)
+    up = F.pad(u, (0, 0, 0, fp - Fq)).reshape(fp // 32, 1, 32, K)
+    gu = torch.cat([gp, up], 1).reshape(2 * fp, K)
+    out = strided(torch.full((M, fp), float("nan"), dtype=dt), lo)
+    ops.gemm(ad, gu.to(DEV), out, mode=ops.GEMM_SWIGLU)
+    got = out.float().cpu()
+    pad_ok = bool((got[:, Fq:] == 0).all())
+    err = (got[:, :Fq] - ref).abs().max().item()
+    return f"gemm swiglu {dt} M={M} F={Fq} K={K} lda={ad.stride(0)}", err if pad_ok else float("inf"), EPS[dt] * ref.abs().max().item() + 1e-3
+
+
+def ref_attention(q, k, v, scale, nk=None):
+    rep = q.shape[1] // k.shape[1]
+    k, v = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
+    if nk is not None:
+        k, v = k[:, :, :nk], v[:, :, :nk]
+    return torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) @ v
+
+
+def fuzz_attention():
+    dt = pick(torch.float16, torch.bfloat16)
+    D = pick(72, 128)
+    HKV = ri(1, 4)
+    H = HKV * (1 if D == 72 else pick(1, 2, 7))
+    B = ri(1, 3)
+    S = pick(ri(1, 70), ri(1, 600), ri(1, 1500), pick(63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025))
+    Sk = S if ri(0, 1) else pick(1, ri(1, 70), ri(1, 2000), pick(63, 64, 65, 1024, 1025))
+    variant = pick(0, 0, 1)
+    dyn = ri(0, 3) == 0
+    real = ri(1, Sk) if dyn else Sk
+    q, k, v = rnd((B, H, S, D), 1.0, dt), rnd((B, HKV, Sk, D), 1.0, dt), rnd((B, HKV, Sk, D), 1.0, dt)
+    if ri(0, 4) == 0:
+        k[:, :, ri(0, real - 1)] *= 6.0                                     # a spiked key: forces the running-max rescale
+    want = ref_attention(q.float(), k.float(), v.float(), D ** -0.5, real)
+    qd = q.permute(0, 2, 1, 3).reshape(B * S, H * D).to(DEV).contiguous()
+    kv = torch.cat([k.permute(0, 2, 1, 3).reshape(B * Sk, HKV * D), v.permute(0, 2, 1, 3).reshape(B * Sk, HKV * D)], -1).to(DEV).contiguous()
+    if dyn and real < Sk:
+        kv.view(B, Sk, -1)[:, real:] = float("nan")                         # rows past the device-side key count must never reach the result
+    o = torch.zeros((B * S, H * D), dtype=dt, device=DEV)
+    ldk = 2 * HKV * D
+    kw = dict(batch=B, heads=H, kv_heads=HKV, seq=S, kv_seq=Sk, head_dim=D, q_strides=(S * H * D, H * D, D), k_strides=(Sk * ldk, ldk, D),
+              v_strides=(Sk * ldk, ldk, D), o_strides=(S * H * D, H * D, D), scale=D ** -0.5, variant=variant)
+    if dyn:
+        kw["kv_len"] = torch.tensor([real], dtype=torch.int32, device=DEV)
+    ops.attention(qd, kv, kv[:, HKV * D:], o, **kw)
+    got = o.float().cpu().view(B, S, H, D).permute(0, 2, 1, 3)
+    err = (got - want).abs().max().item() if torch.isfinite(got).all() else float("inf")
+    return f"attention {dt} D={D} B={B} H={H} HKV={HKV} S={S} Sk={Sk} real={real} variant={variant} dyn={dyn}", err, 6 * EPS[dt] * v.float().abs().max().item()
+
+
+def fuzz_norm():
+    kind = pick("ln", "rms", "ln16")
+    M, D = rows_m(), (8 if kind == "ln16" else 4) * ri(2, 512 if kind == "ln16" else 1024)
+    if M * D > 8e7:
+        M = int(8e7 // D)
+    w, b = 1 + rnd((D,), 0.2), rnd((D,), 0.2)
+    lo = pick(0, 0, 8)
+    if kind == "ln16":
+        dt = pick(torch.float16, torch.bfloat16)
+        x = (rnd((M, D)) * pick(1.0, 8.0) + pick(0.0, 3.0)).to(dt)
+        out = strided(torch.zeros((M, D), dtype=dt), lo)
+        ops.layernorm16(strided(x, pick(0, 8)), w.to(DEV), b.to(DEV), out, D, 1e-6)
+        ref = F.layer_norm(x.float(), (D,), w, b, 1e-6)
+        return f"layernorm16 {dt} M={M} D={D}", (out.float().cpu() - ref).abs().max().item(), EPS[dt] * ref.abs().max().item() + 1e-3
+    odt = pick(torch.float16, torch.bfloat16, torch.float32)
+    x = rnd((M, D)) * pick(1.0, 30.0) + pick(0.0, 5.0)
+    out = strided(torch.zeros((M, D), dtype=odt), lo)
+    if kind == "ln":
+        ops.layernorm(strided(x, pick(0, 4)), w.to(DEV), b.to(DEV), out, D, 1e-6)
+        ref = F.layer_norm(x, (D,), w, b, 1e-6)
+    else:
+        ops.rmsnorm(strided(x, pick(0, 4)), w.to(DEV), out, D, 1e-6)
+        ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    tol = (EPS[odt] if odt in EPS else 2e-6) * ref.abs().max().item() + (1e-3 if odt in EPS else 2e-5)
+    return f"{kind} -> {odt} M={M} D={D}", (out.float().cpu() - ref).abs().max().item(), tol
+
+
+def fuzz_rank():
+    n = pick(ri(1, 40), ri(1, 600), ri(1, 3000))
+    lg = rnd((n,), pick(0.5, 3.0, 30.0))
+    if ri(0, 1):
+        lg = (lg * 4).round() / 4                                           # many exact ties: ties go to the lower index
+    if ri(0, 5) == 0:
+        lg[ri(0, n - 1)] = float("-inf") if ri(0, 1) else float("inf")
+    s, o = ops.rank(lg.to(DEV))
+    want_s = torch.sigmoid(lg)
+    want_o = torch.sort(want_s, descending=True, stable=True).indices
+    ok = torch.equal(o.cpu().long(), want_o) and (s.cpu() - want_s).abs().max().item() <= 1e-6
+    if not ok:                                                              # sigmoid on the device may differ by an ulp and reorder near-ties: compare on ITS scores
+        ok = torch.equal(o.cpu().long(), torch.sort(s.cpu(), descending=True, stable=True).indices) and (s.cpu() - want_s).abs().max().item() <= 1e-6
+    return f"rank n={n}", 0.0 if ok else float("inf"), 0.0
+
+
+def fuzz_pool_rope():
+    if ri(0, 1):
+        T, G = ri(1, 6), ri(1, 33)
+        HW, D = ri(1, G), 4 * ri(1, 300)
+        x = rnd((T * G * G, D))
+        pdt = pick(torch.float16, torch.bfloat16)
+        out = torch.full((T * HW * HW, ops.pad64(D)), float("nan"), dtype=pdt, device=DEV)
+        ops.bilinear_pool(x.to(DEV), out, T, G, HW, D)
+        ref = F.interpolate(x.view(T, G, G, D).permute(0, 3, 1, 2), size=(HW, HW), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).reshape(T * HW * HW, D) \
+            if HW < G else x
+        pad_ok = bool((out[:, D:].float() == 0).all())
+        err = (out[:, :D].float().cpu() - ref).abs().max().item()
+        return f"bilinear_pool {pdt} T={T} G={G} HW={HW} D={D}", err if pad_ok else float("inf"), EPS[pdt] * ref.abs().max().item() + 1e-6
+    dt = pick(torch.float16, torch.bfloat16)
+    N, heads, hd = ri(1, 3000), ri(1, 12), pick(128, 64, 32)
+    extra = hd * ri(0, 4)
+    qkv = rnd((N, heads * hd + extra), 1.0, dt)
+    ang = torch.rand((N, hd // 2), generator=gen) * 6.28
+    cos, sin = ang.cos(), ang.sin()
+    d = qkv.clone().to(DEV)
+    ops.rope_(d, cos.to(DEV), sin.to(DEV), heads, hd)
+    xf = qkv[:, :heads * hd].float().view(N, heads, hd)
+    x1, x2 = xf[..., :hd // 2], xf[..., hd // 2:]
+    ref = torch.cat([x1 * cos[:, None] - x2 * sin[:, None], x2 * cos[:, None] + x1 * sin[:, None]], -1).reshape(N, heads * hd)
+    got = d.float().cpu()
+    untouched = torch.equal(got[:, heads * hd:], qkv[:, heads * hd:].float())
+    err = (got[:, :heads * hd] - ref).abs().max().item()
+    return f"rope {dt} N={N} heads={heads} hd={hd} extra={extra}", err if untouched else float("inf"), EPS[dt] * ref.abs().max().item() + 1e-3
+
+
+def fuzz_split():
+    kind = pick("gemm", "attention", "norm")
+    if kind == "norm":
+        M, D = ri(1, 3000), 4 * ri(2, 900)
+        Dp = ops.pad64(D)
+        x = rnd((M, D)) * pick(1.0, 30.0)
+        x[:, ri(0, D - 1)] *= pick(1.0, 300.0)
+        w, b = 1 + rnd((D,), 0.2), (rnd((D,), 0.2) if ri(0, 1) else None)
+        out = torch.zeros((M, 2 * Dp), dtype=torch.float16, device=DEV)
+        ops.norm_split(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), out, D, 1e-6)
+        x64 = x.double()
+        ref = (F.layer_norm(x64, (D,), w.double(), b.double(), 1e-6) if b is not None else x64 * torch.rsqrt(x64.pow(2).mean(-1, keepdim=True) + 1e-6) * w.double())
+        got = out[:, :D].double().cpu() + out[:, Dp:Dp + D].double().cpu()
+        return f"norm_split M={M} D={D} rms={b is None}", ((got - ref).abs().max() / ref.abs().max()).item(), 2e-6
+    if kind == "gemm":
+        M, N, Kh = ri(1, 3000), 64 * ri(1, 24), 64 * ri(1, 20)
+        a = rnd((M, Kh)) * pick(1.0, 10.0)
+        hi = a.half()
+        lo = (a - hi.float()).half()
+        w = rnd((N, Kh), Kh ** -0.5, torch.float16)
+        b = rnd((N,), 0.1)
+        A2 = torch.cat([hi, lo], 1).to(DEV)
+        W2 = torch.cat([w, w], 1).to(DEV).contiguous()
+        out = torch.zeros((M, 2 * N), dtype=torch.float16, device=DEV)
+        act = pick(ops.ACT_NONE, ops.ACT_GELU_TANH)
+        ops.gemm_split16(A2, W2, out, mode=ops.GEMM_STORE16, lo_off=N, bias=b.to(DEV), act=act)
+        ref = (hi.double() + lo.double()) @ w.double().t() + b.double()
+        if act == ops.ACT_GELU_TANH:
+            ref = F.gelu(ref, approximate="tanh")
+        got = out[:, :N].double().cpu() + out[:, N:].double().cpu()
+        return f"gemm_split16 M={M} N={N} K=2x{Kh} act={act}", ((got - ref).abs().max() / ref.abs().max()).item(), 3e-6
+    D = pick(72, 128)
+    HKV = ri(1, 3)
+    H = HKV * (1 if D == 72 else pick(1, 2, 7))
+    B, S, Sk = ri(1, 2), ri(1, 700), pick(1, ri(1, 70), ri(1, 1500), pick(63, 64, 65))
+    mk = lambda shape: rnd(shape)                                           # noqa: E731
+    q, k, v = mk((B, H, S, D)), mk((B, HKV, Sk, D)), mk((B, HKV, Sk, D))
+
+    def pair(t, rows, heads):                                               # [B, heads, rows, D] -> [B * rows, 2 * heads * D] = [hi | lo]
+        f = t.permute(0, 2, 1, 3).reshape(B * rows, heads * D)
+        h = f.half()
+        return torch.cat([h, (f - h.float()).half()], 1).to(DEV).contiguous(), h.double() + (f - h.float()).half().double()
+    q2, qv = pair(q, S, H)
+    k2, kvv = pair(k, Sk, HKV)
+    v2, vv = pair(v, Sk, HKV)
+    Dq = ops.pad64(H * D)
+    o = torch.zeros((B * S, 2 * Dq), dtype=torch.float16, device=DEV)
+    ops.attention_split(q2, k2, v2, o, lo=(H * D, HKV * D, HKV * D, Dq), batch=B, heads=H, kv_heads=HKV, seq=S, kv_seq=Sk, head_dim=D,
+                        q_strides=(S * 2 * H * D, 2 * H * D, D), k_strides=(Sk * 2 * HKV * D, 2 * HKV * D, D), v_strides=(Sk * 2 * HKV * D, 2 * HKV * D, D),
+                        o_strides=(S * 2 * Dq, 2 * Dq, D), scale=D ** -0.5)
+    ref = ref_attention(qv.view(B, S, H, D).permute(0, 2, 1, 3), kvv.view(B, Sk, HKV, D).permute(0, 2, 1, 3), vv.view(B, Sk, HKV, D).permute(0, 2, 1, 3), D ** -0.5)
+    got = (o[:, :H * D].double().cpu() + o[:, Dq:Dq + H * D].double().cpu()).view(B, S, H, D).permute(0, 2, 1, 3)
+    return f"attention_split D={D} B={B} H={H} HKV={HKV} S={S} Sk={Sk}", ((got - ref).abs().max() / ref.abs().max()).item(), 3e-6
+
+
+FAMILIES = [("gemm", fuzz_gemm), ("attention", fuzz_attention), ("norm", fuzz_norm), ("rank", fuzz_rank), ("pool_rope", fuzz_pool_rope), ("split", fuzz_split)]
+
+
+def main():
+    bad_total = 0
+    for name, fn in FAMILIES:
+        t0, n, bad, worst = time.time(), 0, [], 0.0
+        while time.time() - t0 < budget:
+            try:
+                what, err, tol = fn()
+            except Exception as e:                                          # a refusal of a shape this tool thought legal is a finding too
+                what, err, tol = f"{name}: {type(e).__name__}: {str(e)[:200]}", float("inf"), 0.0
+            torch.cuda.synchronize()
+            n += 1
+            if not (err <= tol):
+                bad.append((what, err, tol))
+            elif tol > 0:
+                worst = max(worst, err / tol)
+        print(f"{name}: {n} cases in {time.time() - t0:.0f} s, {len(bad)} outside their bound (worst passing case at {worst:.2f} of its bound)", flush=True)
+        for what, err, tol in bad[:12]:
+            print(f"    FAIL {what}: err {err:.3e} > {tol:.3e}", flush=True)
+        bad_total += len(bad)
+    print(f"fuzz: {'clean' if not bad_total else f'{bad_total} failures'} (seed {seed}, {budget:.0f} s per family)", flush=True)
+    sys.exit(1 if bad_total else 0)
+
+
+if __name__ == "__main__":
+    main()
