@@ -77,3 +77,46 @@ def test_pad_sequence_sides():
     r = mm_utils.pad_sequence(types.SimpleNamespace(padding_side="right"), seqs, True, 0)
     l = mm_utils.pad_sequence(types.SimpleNamespace(padding_side="left"), seqs, True, 0)
     assert r.tolist() == [[1, 2, 3], [4, 0, 0]] and l.tolist() == [[1, 2, 3], [0, 0, 4]]
+
+
+# ---- the reference's integer helpers on a sweep of seeded random arguments (tests/golden/make_helpers_sweep.py ran THEM; data only) ----------------
+def _digest(xs):
+    import hashlib
+    xs = [int(x) for x in xs]
+    return {"n": len(xs), "head": xs[:3], "tail": xs[-3:], "sha1": hashlib.sha1(",".join(map(str, xs)).encode()).hexdigest()}
+
+
+def _outcome(fn, *args):
+    try:
+        return _digest(fn(*args))
+    except Exception as e:
+        return {"error": type(e).__name__}
+
+
+@pytest.fixture(scope="module")
+def sweep(golden_dir):
+    with open(os.path.join(golden_dir, "helpers_sweep.json")) as f:
+        return json.load(f)
+
+
+def test_frame_samplers_equal_the_reference_on_a_sweep(sweep):
+    """A1 / A1': 400 seeded draws each (frame counts 1 .. 200 000, frame rates incl. 0.4 / 4.99 / 5.01 / 23.976 / 59.94, sample budgets 1 .. 600,
+    `multiple` padding): the index list - or the exception type the reference raises (zero stride) - is identical, by SHA-1 of the list"""
+    assert len(sweep["get_frame_indices"]) >= 400 and len(sweep["get_seq_frames"]) >= 400
+    for e in sweep["get_frame_indices"]:
+        assert _outcome(mm_utils.get_frame_indices, *e["args"]) == e["out"], e["args"]
+    n_err = 0
+    for e in sweep["get_seq_frames"]:
+        assert _outcome(mm_utils.get_seq_frames, *e["args"]) == e["out"], e["args"]
+        n_err += "error" in e["out"]
+    assert n_err >= 10                                   # the sweep does reach the reference's failure mode
+
+
+def test_prompt_splice_and_padding_equal_the_reference_on_a_sweep(sweep):
+    """A4 / A5: 200 prompts of random text around 0-3 <image> tokens (with / without BOS), 60 ragged batches padded on either side"""
+    for e in sweep["tokenizer_image_token"]:
+        assert _outcome(mm_utils.tokenizer_image_token, e["prompt"], Tok(e["bos"]), -200) == e["out"], e["prompt"]
+    assert len(sweep["pad_sequence"]) >= 60
+    for e in sweep["pad_sequence"]:
+        got = mm_utils.pad_sequence(types.SimpleNamespace(padding_side=e["side"]), [torch.tensor(s) for s in e["seqs"]], True, e["pad"])
+        assert got.tolist() == e["out"], e
