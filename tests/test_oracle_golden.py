@@ -122,3 +122,29 @@ def test_oracle_training_mode_pooled_grids(golden_dir):
     lg = O.forward(cfg, sd, vsd, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), images, pooled_grids=grids)
     for b in range(len(T)):
         assert (lg[b] - torch.from_numpy(z[f"logits{b}"])).abs().max() < TOL
+
+
+def _structure(golden_dir, seed):
+    import structures as ST
+    z = np.load(os.path.join(golden_dir, "random_structures.npz"))
+    s = ST.draw(seed)
+    # the committed fixture holds the inputs the reference saw: the draw rule must still produce them
+    assert np.array_equal(z[f"s{seed}_ids"], s["ids"].numpy()) and np.array_equal(z[f"s{seed}_mask"], s["mask"].numpy())
+    assert z[f"s{seed}_T"].tolist() == s["T"] and z[f"s{seed}_meta"].tolist() == [s["side"], s["budget"], int(s["two_first"])]
+    return z, s, ST
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_oracle_matches_reference_on_random_batch_structures(golden_dir, seed):
+    """Round 6: sixteen seeded batch structures nobody chose (tests/structures.py: 1-3 prompts, left / right padding, random text around the <image> tokens,
+    clips of 1-11 frames, two clips in one prompt, pooled 1 x 1 .. 3 x 3 or unpooled, two image sides) through THE REFERENCE
+    (tests/golden/make_random_structures.py) - the oracle reproduces its logits to the same 2e-5 as on the hand-written cases."""
+    z, s, ST = _structure(golden_dir, seed)
+    cfg = ST.config(s)
+    sd, vsd = synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed)
+    logits = O.forward(cfg, sd, vsd, s["ids"], s["mask"], ST.images(s))
+    assert len(logits) == s["B"]
+    for b in range(s["B"]):
+        ref = torch.from_numpy(z[f"s{seed}_logits{b}"])
+        assert logits[b].shape == ref.shape
+        assert (logits[b] - ref).abs().max() < TOL, s["what"]
