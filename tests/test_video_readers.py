@@ -364,3 +364,19 @@ def test_mp4_container_edge_cases(tmp_path, no_decoders):
     open(p5, "wb").write(ftyp + mdat)
     with pytest.raises(ValueError, match="no 'moov' box"):
         video_io.VideoReader(p5)
+
+
+def test_get_batch_decodes_on_threads_in_index_order(tmp_path, no_decoders):
+    """decord's `num_threads`: individually coded frames decode on a thread pool (Pillow's decoders release the GIL); the batch is in the order of the indices
+    asked for - repeated and descending ones included - and equal to the one-thread result"""
+    from videoitg_amd import video_io
+    clip = _clip(T=30, h=34, w=46)
+    idx = [29, 0, 7, 7, 3, 28, 1]
+    for name, write in (("a.avi", lambda p: video_io.write_avi(p, clip, fps=30.0)), ("a.mov", lambda p: video_io.write_mov(p, clip, fps=30.0, codec="jpeg"))):
+        path = str(tmp_path / name)
+        write(path)
+        one = video_io.VideoReader(path, num_threads=1).get_batch(idx).asnumpy()
+        many = video_io.VideoReader(path, num_threads=4).get_batch(idx).asnumpy()
+        assert np.array_equal(one, many) and np.array_equal(many[2], many[3])
+        assert [int(np.abs(many[k].astype(int) - clip[i].astype(int)).mean() < 3.0) for k, i in enumerate(idx)] == [1] * len(idx)
+    assert mm_utils.open_video_reader(path, num_threads=4)._threads == 4

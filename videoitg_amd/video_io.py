@@ -300,6 +300,7 @@ class VideoReader:
 
     def __init__(self, path: str, ctx=None, num_threads: int = 1):
         self.path = path
+        self._threads = max(1, int(num_threads or 1))        # decord: 0 = automatic; here 0 / None = one thread
         with open(path, "rb") as f:
             self._data = f.read()
         head = self._data[:12]
@@ -461,7 +462,19 @@ class VideoReader:
         return _Batch(self._frame(i))
 
     def get_batch(self, indices: Sequence[int]) -> _Batch:
-        return _Batch(np.stack([self._frame(i) for i in indices]) if len(indices) else np.zeros((0, self.height, self.width, 3), np.uint8))
+        """decord's get_batch.  Individually coded frames (Motion-JPEG / PNG samples) decode on `num_threads` threads, as decord's reader does with its own
+        (Pillow's decoders release the GIL); frame order is the order of `indices`.  Delta-coded animated images compose forward and stay sequential."""
+        indices = [int(i) for i in indices]
+        if not indices:
+            return _Batch(np.zeros((0, self.height, self.width, 3), np.uint8))
+        parallel = self._threads > 1 and len(indices) > 1 and (self._kind == "bmff_pil" or (self._kind == "mjpg"))
+        if parallel:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(self._threads, len(indices))) as pool:
+                frames = list(pool.map(self._frame, indices))
+        else:
+            frames = [self._frame(i) for i in indices]
+        return _Batch(np.stack(frames))
 
     def seek(self, pos: int) -> None:                       # random access needs no state
         return None
