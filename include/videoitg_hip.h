@@ -256,7 +256,10 @@ int vitg_bce_loss(const float* logits, const float* labels, int n, float* out2, 
  * eagle/model/multimodal_encoder/clip_encoder.py:115: Pillow BICUBIC resize on uint8, x * 1/255, (x - 0.5) / 0.5, HWC -> CHW).
  * frames: uint8 [T,H,W,3] device memory, strides in bytes (row_stride >= 3 W, frame_stride >= H row_stride);
  * out: [T,3,S,S] contiguous of out_dtype (VITG_F32 reproduces the reference's fp32 tensor bit for bit, VITG_F16 / VITG_BF16 its
- * .half() / .bfloat16()); tmp: scratch of vitg_preprocess_tmp_bytes bytes (may be null when that is 0). */
+ * .half() / .bfloat16()); tmp: scratch of vitg_preprocess_tmp_bytes bytes (may be null when that is 0).
+ * The horizontal pass runs first, as Pillow's does - except that Pillow runs the VERTICAL pass first when an image more than 100 times taller than wide
+ * is reduced in height (H > 100 W and S < H): that geometry returns VITG_ERR_SHAPE (W > 1, W != S); transpose the frames, call, transpose the result
+ * (the two orders are each other's transposes - videoitg_amd/ops.py: preprocess_u8 does exactly that). */
 int vitg_preprocess_tmp_bytes(int T, int H, int W, int S, long* bytes);
 int vitg_preprocess_u8(const void* frames, int T, int H, int W, long frame_stride, int row_stride, void* out, int S,
                        int out_dtype, void* tmp, long tmp_bytes, void* stream);

@@ -134,3 +134,48 @@ def test_gpu_preprocess_equals_oracle_on_odd_sizes():
         want = torch.from_numpy(PO.preprocess(fr, S))
         got = ops.preprocess_u8(torch.from_numpy(fr).cuda(), S, torch.float32)
         assert torch.equal(got.cpu(), want), (T, H, W, S)
+
+
+TALL = [(201, 2, 21), (200, 2, 21), (301, 3, 8), (300, 3, 8), (349, 3, 21), (308, 3, 224), (509, 5, 56), (1101, 11, 64), (1100, 11, 64), (1001, 10, 1000),
+        (3, 700, 16), (101, 1, 8), (296, 2, 448), (435, 4, 471), (400, 2, 401), (400, 2, 399), (435, 4, 434), (283, 1, 371)]
+
+
+@pytest.mark.skipif(not _HAVE, reason="hypothesis / Pillow not importable")
+@pytest.mark.parametrize("H,W,S", TALL)
+def test_pillow_resamples_very_tall_images_vertical_pass_first(H, W, S):
+    """Found by tools/fuzz_kernels.py (round 6): Pillow (12.2 here) runs the VERTICAL pass first when an image more than 100 times taller than wide is
+    reduced in height - exactly from H = 100 W + 1, only for S < H, never for wide images - and each pass rounds to 8 bits, so the order shows (up to 20 grey levels at
+    308 x 3 -> 224).  The oracle restates the rule; here it is pinned against the library on both sides of the switch, and against the real
+    SiglipImageProcessor path through the host twin."""
+    from videoitg_amd.image_processor import SiglipImageProcessor
+    img = np.random.default_rng(H * 7 + W).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ref = np.asarray(_PILImage.fromarray(img).resize((S, S), resample=_PILImage.BICUBIC))
+    assert np.array_equal(PO.pil_bicubic_resize(img, S, S), ref)
+    twin = SiglipImageProcessor(size=S).preprocess(img[None], return_tensors="np")["pixel_values"]
+    assert np.array_equal(np.stack(twin), PO.preprocess(img[None], S))
+    if H > 100 * W and S < H and W > 1 and W != S:     # the order matters on these draws (a 1-pixel-wide image is constant along x: either order): the test would notice a regression to horizontal-first
+        hfirst = PO._pass(PO._pass(img, *PO.resample_coeffs(W, S), axis=1), *PO.resample_coeffs(H, S), axis=0)
+        assert not np.array_equal(hfirst, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,S", TALL)
+def test_gpu_preprocess_on_very_tall_images(H, W, S):
+    """the product path on the geometry where Pillow swaps its passes: `ops.preprocess_u8` transposes around the horizontal-first kernel; the C entry
+    itself refuses the geometry (include/videoitg_hip.h) instead of returning the other order's pixels"""
+    from videoitg_amd import _lib, ops
+    fr = np.random.default_rng(H * 7 + W).integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    want = torch.from_numpy(PO.preprocess(fr, S))
+    dev = torch.from_numpy(fr).cuda()
+    for dt in (torch.float32, torch.float16):
+        got = ops.preprocess_u8(dev, S, dt)
+        assert got.is_contiguous() and torch.equal(got.cpu(), want.to(dt)), (H, W, S, dt)
+    if H > 100 * W and S < H and 1 < W != S:
+        import ctypes as C
+        need = C.c_long(0)
+        _lib.call("vitg_preprocess_tmp_bytes", 2, H, W, S, C.byref(need))
+        tmp = torch.empty(max(need.value, 1), dtype=torch.uint8, device="cuda")
+        out = torch.empty((2, 3, S, S), device="cuda")
+        with pytest.raises(_lib.VitgError):
+            _lib.call("vitg_preprocess_u8", dev.data_ptr(), 2, H, W, dev.stride(0), dev.stride(1), out.data_ptr(), S, ops.dt_code(torch.float32),
+                      tmp.data_ptr(), need.value, None)

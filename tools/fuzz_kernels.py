@@ -3,7 +3,7 @@
 draws shapes nobody chose - ragged M, N that is only a multiple of 4, strided operands, one-key attention, key counts that straddle tile edges, ties in
 the ranking - and reports every case outside the same error bounds the tests use.  Not part of the suite (its run time is the argument).
 
-    python tools/fuzz_kernels.py [seconds per family = 40] [seed = 0]        -> one line per family, failures listed with their shapes; exit 1 on any
+    python tools/fuzz_kernels.py [seconds per family = 40] [seed = 0] [families]      -> one line per family, failures listed with their shapes; exit 1 on any
 """
 import math
 import os
@@ -20,6 +20,7 @@ DEV = torch.device("cuda:0")
 EPS = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None           # family names, comma-separated
 gen = torch.Generator().manual_seed(seed)
 
 
@@ -271,12 +272,89 @@ def fuzz_split():
     return f"attention_split D={D} B={B} H={H} HKV={HKV} S={S} Sk={Sk}", ((got - ref).abs().max() / ref.abs().max()).item(), 3e-6
 
 
-FAMILIES = [("gemm", fuzz_gemm), ("attention", fuzz_attention), ("norm", fuzz_norm), ("rank", fuzz_rank), ("pool_rope", fuzz_pool_rope), ("split", fuzz_split)]
+def fuzz_patch_embed():
+    """vitg_patch_embed16 (im2col inside the GEMM's operand loader) against the stride-p convolution + bias + position table in fp32"""
+    dt = pick(torch.float16, torch.bfloat16)
+    ps = pick(14, 14, 8, 10, 12, 16)
+    G = ri(1, 12)
+    R = G * ps + 2 * ri(0, (ps - 1) // 2)                                   # even sides; a ragged border the VALID convolution ignores
+    T, N = ri(1, 6), 4 * ri(64, 320)
+    if not ops.patch_embed_fusable(T, R, ps, N):
+        return f"patch_embed16 (not fusable: T={T} R={R} p={ps} N={N})", 0.0, 0.0
+    P = G * G
+    pix, w = rnd((T, 3, R, R), 1.0, dt), rnd((N, 3, ps, ps), 0.05, dt)
+    b, pos = (rnd((N,), 0.1) if ri(0, 1) else None), (rnd((P, N), 0.5) if ri(0, 1) else None)
+    want = F.conv2d(pix.float().to(DEV), w.float().to(DEV), stride=ps).flatten(2).transpose(1, 2).reshape(-1, N).cpu()
+    if b is not None:
+        want = want + b
+    if pos is not None:
+        want = want + pos.repeat(T, 1)
+    rows = w.reshape(N, 3 * ps, ps)
+    wf = torch.zeros((N, (3 * ps + 3) // 4 * 4, 16), dtype=dt)
+    wf[:, :3 * ps, :8] = rows[:, :, :8]
+    wf[:, :3 * ps, 16 - (ps - 8):] = rows[:, :, 8:]
+    buf = torch.full((T * 3 * R * R + 128,), float("nan"), dtype=dt, device=DEV)      # NaN guards around the pixels: a loader chunk past a row's end would show
+    dpix = buf[64:64 + T * 3 * R * R].view(T, 3, R, R)
+    dpix.copy_(pix)
+    out = torch.full((T * P, N), float("nan"), dtype=dt, device=DEV)
+    ops.patch_embed16(dpix, wf.reshape(N, -1).contiguous().to(DEV), out, patch=ps, bias=None if b is None else b.to(DEV), pos=None if pos is None else pos.to(DEV))
+    got = out.float().cpu()
+    if not torch.isfinite(got).all():
+        return f"patch_embed16 {dt} T={T} R={R} p={ps} N={N}: non-finite output", float("inf"), 0.0
+    excess = ((got - want).abs() - (EPS[dt] * want.abs().clamp(min=1.0) + 1e-3)).max().item()
+    return f"patch_embed16 {dt} T={T} R={R} p={ps} N={N} bias={b is not None} pos={pos is not None}", max(excess, 0.0), 0.0
+
+
+def fuzz_preprocess():
+    """vitg_preprocess_u8 against the host twin of the real SiglipImageProcessor (Pillow bicubic + transformers' rescale / normalise): bit-exact"""
+    import numpy as np
+    from videoitg_amd.image_processor import SiglipImageProcessor
+    T, H, W = ri(1, 4), pick(ri(1, 40), ri(1, 400), ri(100, 1100)), pick(ri(1, 40), ri(1, 400), ri(100, 1300))
+    S = pick(ri(1, 64), 56, 224, 384, 448, ri(30, 500))
+    fr = torch.randint(0, 256, (T, H, W, 3), generator=gen, dtype=torch.uint8)
+    if ri(0, 1):                                                            # smooth content beside noise: long runs of equal bytes
+        fr = (fr.float().cumsum(2) / torch.arange(1, W + 1)[None, None, :, None]).round().clamp(0, 255).to(torch.uint8)
+    want = torch.from_numpy(np.stack(SiglipImageProcessor(size=S).preprocess(fr.numpy(), return_tensors="np")["pixel_values"]))
+    try:
+        got = ops.preprocess_u8(fr.to(DEV), S, torch.float32).cpu()
+    except Exception as e:
+        return f"preprocess_u8 T={T} {H}x{W} -> {S}: {type(e).__name__}: {str(e)[:120]}", float("inf"), 0.0
+    return f"preprocess_u8 T={T} {H}x{W} -> {S}", 0.0 if torch.equal(got, want) else float("inf"), 0.0
+
+
+def fuzz_splitk():
+    """the K-split forms (fp32 and 16-bit output) against the plain GEMM of the same call: equal up to fp32 summation order, and deterministic"""
+    dt = pick(torch.float16, torch.bfloat16)
+    M, N, K = ri(1, 3000), 4 * ri(16, 900), 64 * ri(2, 150)
+    splits = ri(2, min(6, K // 64))
+    a, w = rnd((M, K), 1.0, dt).to(DEV), rnd((N, K), K ** -0.5, dt).to(DEV)
+    b = rnd((N,), 0.1).to(DEV) if ri(0, 1) else None
+    ws = torch.empty((splits * M * N,), device=DEV)
+    x = rnd((M, N)).to(DEV)
+    plain = x.clone()
+    ops.gemm(a, w, plain, mode=ops.GEMM_F32, bias=b, res=plain)
+    o1, o2 = x.clone(), x.clone()
+    try:
+        ops.gemm_splitk(a, w, o1, ws, splits, bias=b, res=o1)
+        ops.gemm_splitk(a, w, o2, ws, splits, bias=b, res=o2)
+    except Exception as e:
+        if "SHAPE" in str(e).upper() or "shape" in str(e):
+            return f"gemm_splitk refused M={M} N={N} K={K} splits={splits}", 0.0, 0.0
+        raise
+    det = torch.equal(o1, o2)
+    err = (o1 - plain).abs().max().item()
+    return f"gemm_splitk {dt} M={M} N={N} K={K} splits={splits} bias={b is not None}", err if det else float("inf"), 2e-4 * math.sqrt(K)
+
+
+FAMILIES = [("gemm", fuzz_gemm), ("attention", fuzz_attention), ("norm", fuzz_norm), ("rank", fuzz_rank), ("pool_rope", fuzz_pool_rope), ("split", fuzz_split),
+            ("patch_embed", fuzz_patch_embed), ("preprocess", fuzz_preprocess), ("splitk", fuzz_splitk)]
 
 
 def main():
     bad_total = 0
     for name, fn in FAMILIES:
+        if only and name not in only:
+            continue
         t0, n, bad, worst = time.time(), 0, [], 0.0
         while time.time() - t0 < budget:
             try:

@@ -255,6 +255,9 @@ extern "C" int vitg_preprocess_u8(const void* frames, int T, int H, int W, long 
     if (T == 0) return 0;
     if (T < 0 || H <= 0 || W <= 0 || S <= 0 || !frames || !out) return VITG_ERR_ARG;
     if (row_stride < W * 3 || frame_stride < (long)row_stride * H) return VITG_ERR_SHAPE;
+    // Pillow resamples images more than 100 times taller than wide whose height is REDUCED with the VERTICAL pass first (each pass rounds to 8 bits: a different result); this
+    // entry implements the horizontal-first order only and refuses the geometry - the caller transposes around the call (videoitg_amd/ops.py does)
+    if ((long)H > 100L * W && S < H && W != S && W > 1) return VITG_ERR_SHAPE;      // (W == 1: constant along x, either order gives the same pixels)
     if (out_dtype != DT_BF16 && out_dtype != DT_F16 && out_dtype != DT_F32) return VITG_ERR_DTYPE;
     if (T > 65535) return VITG_ERR_SHAPE;
     const long need = tmp_bytes_for(T, H, W, S);

@@ -523,7 +523,11 @@ def preprocess_u8(frames: torch.Tensor, size: int, out_dtype: torch.dtype = torc
     if frames.dim() != 4 or frames.shape[-1] != 3:
         raise _lib.VitgError(f"expected uint8 [T,H,W,3], got {tuple(frames.shape)}")
     T, H, W, _ = frames.shape
-    if T > 0 and (frames.stride(3) != 1 or frames.stride(2) != 3):
+    if T > 0 and H > 100 * W and size < H and 1 < W != size:
+        # Pillow runs the vertical pass first when an image more than 100 times taller than wide is reduced in height; the kernel is horizontal-first: the
+        # same arithmetic on the transposed frames, transposed back (include/videoitg_hip.h: the C entry refuses this geometry)
+        return preprocess_u8(frames.transpose(1, 2).contiguous(), size, out_dtype).transpose(2, 3).contiguous()
+    if T > 0 and (frames.stride(3) != 1 or frames.stride(2) != 3 or (H == 1 and frames.stride(1) < 3 * W) or (T == 1 and frames.stride(0) < frames.stride(1) * H)):
         frames = frames.contiguous()
     out = torch.empty((T, 3, size, size), dtype=out_dtype, device=frames.device)
     if T == 0:
@@ -531,7 +535,9 @@ def preprocess_u8(frames: torch.Tensor, size: int, out_dtype: torch.dtype = torc
     need = C.c_long(0)
     _lib.call("vitg_preprocess_tmp_bytes", T, H, W, size, C.byref(need))
     tmp = torch.empty(need.value, dtype=torch.uint8, device=frames.device) if need.value else None
-    _lib.call("vitg_preprocess_u8", _ptr(frames), T, H, W, frames.stride(0), frames.stride(1), _ptr(out), size, dt_code(out_dtype),
+    row_stride = frames.stride(1) if H > 1 else max(frames.stride(1), 3 * W)          # (the stride of a size-1 dimension is arbitrary in torch)
+    frame_stride = frames.stride(0) if T > 1 else max(frames.stride(0), row_stride * H)
+    _lib.call("vitg_preprocess_u8", _ptr(frames), T, H, W, frame_stride, row_stride, _ptr(out), size, dt_code(out_dtype),
               _ptr(tmp), need.value, _stream())
     return out
 
