@@ -48,3 +48,39 @@ def images(s: dict):
 
 
 N_STRUCTURES = 16
+
+
+# ---- random ARCHITECTURES (round 6): widths, head counts, depths, GQA groups, FFN widths nobody chose -------------------------------------------------
+N_ARCHS = 12
+
+
+def draw_arch(seed: int) -> dict:
+    """one prompt, one clip - the structure is not the point here - on a drawn architecture: tower of 1-4 heads of 72 (the SigLIP head size), FFN width any
+    multiple of 4, 2-4 layers (hidden_states[-2] = all but the last), image side 56 / 62 / 70 / 84; decoder of 1-2 KV heads x GQA group 1 / 2 / 3 / 7 of
+    head size 128, FFN width any multiple of 8, 1-3 layers, rope_theta 1e4 or 1e6; a token budget that pools or not"""
+    g = torch.Generator().manual_seed(5000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g).item())       # noqa: E731
+    vh = ri(1, 4)
+    kv = ri(1, 2)
+    heads = kv * (1, 2, 3, 7)[ri(0, 3)]
+    arch = dict(vocab_size=320, hidden_size=128 * heads, intermediate_size=8 * ri(20, 150), num_hidden_layers=ri(1, 3), num_attention_heads=heads,
+                num_key_value_heads=kv, rope_theta=(1e4, 1e6)[ri(0, 1)], mm_hidden_size=72 * vh, vision_token_num=(16, 72, 100000)[ri(0, 2)],
+                vision=dict(image_size=(56, 62, 70, 84)[ri(0, 3)], patch_size=14, hidden_size=72 * vh, intermediate_size=4 * ri(20, 200),
+                            num_hidden_layers=ri(2, 4), num_attention_heads=vh))
+    T = ri(1, 9)
+    toks = [ri(1, 319) for _ in range(ri(0, 5))] + [-200] + [ri(1, 319) for _ in range(ri(0, 8))]
+    ids = torch.tensor([toks], dtype=torch.long)
+    return dict(seed=seed, arch=arch, T=[T], ids=ids, mask=torch.ones_like(ids).bool(), side=arch["vision"]["image_size"],
+                what=f"arch {seed}: tower {vh} x 72, ffn {arch['vision']['intermediate_size']}, {arch['vision']['num_hidden_layers']} layers, side "
+                     f"{arch['vision']['image_size']} | decoder {heads} q / {kv} kv x 128, ffn {arch['intermediate_size']}, {arch['num_hidden_layers']} layers | "
+                     f"T={T} budget={arch['vision_token_num']} prompt={len(toks)}")
+
+
+def arch_config(s: dict):
+    from videoitg_amd.config import ITGConfig
+    return ITGConfig.from_dict(s["arch"])
+
+
+def arch_images(s: dict):
+    from videoitg_amd import synth
+    return [synth.synth_pixel_values(t, s["side"], seed=500 + 7 * s["seed"] + i) for i, t in enumerate(s["T"])]

@@ -667,3 +667,30 @@ def test_randomly_drawn_batch_structures_equal_the_reference(golden_dir, seed):
         worst16 = max(worst16, (torch.sigmoid(gl.float().cpu()) - torch.sigmoid(wl)).abs().max().item())
     print(f"{what}: fp16 default max |dscore| vs the reference = {worst16:.2e}")
     assert worst16 <= GOLDEN_TOL[torch.float16]["chunk520"], what
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomly_drawn_architectures_equal_the_reference(golden_dir, seed):
+    """Architectures nobody chose (round 6, tests/structures.py: draw_arch): tower widths 72 .. 288 with FFN widths that are multiples of 4 only, 2-4 layers,
+    image sides 56 / 62 / 70 / 84; decoders of 2 .. 14 query heads over 1-2 KV heads (GQA groups 1 / 2 / 3 / 7), FFN widths that are multiples of 8 only, 1-3
+    layers, two rope bases - every padding rule of the engine (pad64 of widths, 32-row SwiGLU interleave, K multiples of 64) meets sizes it was not tuned on.
+    Expected values from THE REFERENCE (random_archs.npz).  Operand-split tier <= 2e-4 in logit = the structural gate; fp16 default at the toy-class 2e-3."""
+    import structures as ST
+    from videoitg_amd import synth
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    z = np.load(os.path.join(golden_dir, "random_archs.npz"))
+    s = ST.draw_arch(seed)
+    assert json.loads(str(z[f"a{seed}_arch"])) == json.loads(json.dumps(s["arch"])) and np.array_equal(z[f"a{seed}_ids"], s["ids"].numpy())
+    cfg, images, what = ST.arch_config(s), ST.arch_images(s), s["what"]
+    want = torch.from_numpy(z[f"a{seed}_logits0"])
+    sd, vsd = synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed)
+    eng2 = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0", vit_q_prescaled=False), operand_split=True)
+    got2 = eng2.forward(s["ids"], s["mask"], [im.half().cuda() for im in images])[0].float().cpu()
+    assert got2.shape == want.shape, what
+    e2 = (got2 - want).abs().max().item()
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    got = eng.forward(s["ids"], s["mask"], [im.cuda() for im in images])[0].float().cpu()
+    e16 = (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item()
+    print(f"{what}: split tier max |dlogit| = {e2:.2e}, fp16 default max |dscore| = {e16:.2e}")
+    assert e2 <= 2e-4, what
+    assert e16 <= GOLDEN_TOL[torch.float16]["chunk520"], what

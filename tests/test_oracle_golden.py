@@ -148,3 +148,19 @@ def test_oracle_matches_reference_on_random_batch_structures(golden_dir, seed):
         ref = torch.from_numpy(z[f"s{seed}_logits{b}"])
         assert logits[b].shape == ref.shape
         assert (logits[b] - ref).abs().max() < TOL, s["what"]
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_oracle_matches_reference_on_random_architectures(golden_dir, seed):
+    """Round 6: twelve drawn ARCHITECTURES (tests/structures.py: draw_arch - tower of 1-4 heads, FFN widths that are multiples of 4 only, 2-4 layers, four
+    image sides; decoder with GQA groups 1 / 2 / 3 / 7, FFN widths that are multiples of 8 only, 1-3 layers, two rope bases) through THE REFERENCE
+    (random_archs.npz): nothing in the oracle is tied to the two architectures the other fixtures use."""
+    import structures as ST
+    z = np.load(os.path.join(golden_dir, "random_archs.npz"))
+    s = ST.draw_arch(seed)
+    assert json.loads(str(z[f"a{seed}_arch"])) == json.loads(json.dumps(s["arch"])) and np.array_equal(z[f"a{seed}_ids"], s["ids"].numpy())
+    cfg = ST.arch_config(s)
+    sd, vsd = synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed)
+    logits = O.forward(cfg, sd, vsd, s["ids"], s["mask"], ST.arch_images(s))
+    ref = torch.from_numpy(z[f"a{seed}_logits0"])
+    assert logits[0].shape == ref.shape and (logits[0] - ref).abs().max() < TOL, s["what"]
