@@ -322,6 +322,40 @@ def fuzz_preprocess():
     return f"preprocess_u8 T={T} {H}x{W} -> {S}", 0.0 if torch.equal(got, want) else float("inf"), 0.0
 
 
+def fuzz_fp8():
+    """the per-token e4m3 quantiser against its arithmetic in torch (bit-exact bytes and scales: scale = amax * fp32(1/448), q = RNE(x * (1 / scale))), then
+    vitg_gemm_fp8 on those bytes against the fp32 product of the dequantised operands"""
+    dt = pick(torch.float16, torch.bfloat16)
+    M, N, K = pick(ri(1, 40), ri(1, 2500)), 8 * ri(2, 350), 128 * ri(1, 24)                  # (vitg_gemm_fp8: N % 8, K % 128)
+    x = rnd((M, K), pick(0.05, 1.0, 30.0), pick(torch.float32, dt))
+    x[:, ri(0, K - 1)] *= pick(1.0, 50.0)
+    if ri(0, 5) == 0:
+        x[ri(0, M - 1)] = 0                                                 # an all-zero token: scale 1, bytes 0
+    a8, sa = ops.quant_rows_fp8(x.to(DEV))
+    xf = x.float()
+    amax = xf.abs().amax(-1, keepdim=True)
+    sc = torch.where(amax > 0, amax * torch.tensor(1.0 / 448.0, dtype=torch.float32), torch.ones_like(amax))
+    q = (xf * (1.0 / sc)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    ok = torch.equal(a8[:, :K].cpu().view(torch.float8_e4m3fn).view(torch.uint8), q.view(torch.uint8)) and torch.equal(sa.cpu(), sc.view(-1))
+    if not ok:
+        return f"quant_rows_fp8 {x.dtype} M={M} K={K}: bytes / scales differ", float("inf"), 0.0
+    w = rnd((N, K), K ** -0.5)
+    w8, sw = ops.quant_rows_fp8(w.to(DEV))
+    wq = w8[:, :K].cpu().view(torch.float8_e4m3fn).float() * sw.cpu()[:, None]
+    ref = ((q.float() * sc).to(DEV) @ wq.to(DEV).t()).cpu()
+    b = rnd((N,), 0.1) if ri(0, 1) else None
+    if b is not None:
+        ref = ref + b
+    if ri(0, 1):
+        out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+        ops.gemm_fp8(a8, sa, w8, sw, out, mode=ops.GEMM_STORE16, out_dtype=dt, bias=None if b is None else b.to(DEV))
+        return f"gemm_fp8 store16 {dt} M={M} N={N} K={K}", (out.float().cpu() - ref).abs().max().item(), EPS[dt] * ref.abs().max().item() + 2e-3
+    r = rnd((M, N))
+    out = r.to(DEV)
+    ops.gemm_fp8(a8, sa, w8, sw, out, mode=ops.GEMM_F32, out_dtype=dt, bias=None if b is None else b.to(DEV), res=out)
+    return f"gemm_fp8 f32 M={M} N={N} K={K}", (out.cpu() - ref - r).abs().max().item(), 2e-6 * K * max(1.0, ref.abs().max().item()) + 1e-4
+
+
 def fuzz_splitk():
     """the K-split forms (fp32 and 16-bit output) against the plain GEMM of the same call: equal up to fp32 summation order, and deterministic"""
     dt = pick(torch.float16, torch.bfloat16)
@@ -347,7 +381,7 @@ def fuzz_splitk():
 
 
 FAMILIES = [("gemm", fuzz_gemm), ("attention", fuzz_attention), ("norm", fuzz_norm), ("rank", fuzz_rank), ("pool_rope", fuzz_pool_rope), ("split", fuzz_split),
-            ("patch_embed", fuzz_patch_embed), ("preprocess", fuzz_preprocess), ("splitk", fuzz_splitk)]
+            ("patch_embed", fuzz_patch_embed), ("preprocess", fuzz_preprocess), ("splitk", fuzz_splitk), ("fp8", fuzz_fp8)]
 
 
 def main():
