@@ -356,6 +356,58 @@ def fuzz_fp8():
     return f"gemm_fp8 f32 M={M} N={N} K={K}", (out.cpu() - ref - r).abs().max().item(), 2e-6 * K * max(1.0, ref.abs().max().item()) + 1e-4
 
 
+def fuzz_misc():
+    """the small kernels at the path's edges: embedding gather (exact), row gather (exact), per-frame mean + score head, patchify (exact copy into the im2col
+    layout), the grounding loss"""
+    kind = pick("embed", "gather", "pool_score", "patchify", "bce")
+    if kind == "embed":
+        dt = pick(torch.float16, torch.bfloat16)
+        V, D, n = ri(1, 2000), 4 * ri(1, 1000), ri(1, 300)
+        table = rnd((V, D), 1.0, dt)
+        ids = torch.randint(0, V, (n,), generator=gen)
+        out = torch.full((n, D + pick(0, 4)), float("nan"), device=DEV)
+        ops.embed_gather(ids.to(DEV), table.to(DEV), out)
+        return f"embed_gather {dt} V={V} D={D} n={n}", 0.0 if torch.equal(out[:, :D].cpu(), table[ids].float()) else float("inf"), 0.0
+    if kind == "gather":
+        dt = pick(torch.float32, torch.float16)
+        B, R_, W = ri(1, 5), ri(1, 400), 8 * ri(1, 250)                     # (rows move as 16-byte chunks: width and strides multiples of 16 bytes)
+        src = rnd((B * R_, W + pick(0, 8, 16)), 1.0, dt)
+        idx = torch.randint(0, R_, (ri(1, R_),), generator=gen, dtype=torch.int32)
+        out = torch.zeros((B * idx.numel(), W), dtype=dt, device=DEV)
+        ops.gather_rows(src.to(DEV), idx.to(DEV), R_, B, out, W)
+        want = torch.cat([src[b * R_ + idx.long(), :W] for b in range(B)], 0)
+        return f"gather_rows {dt} B={B} rows={R_} W={W} n={idx.numel()}", 0.0 if torch.equal(out.cpu(), want) else float("inf"), 0.0
+    if kind == "pool_score":
+        T, tok, D = ri(1, 600), ri(1, 300), 4 * ri(1, 900)
+        if T * tok * D > 4e7:
+            T = max(1, int(4e7 // (tok * D)))
+        h = rnd((T * tok, D))
+        w, b = rnd((D,), 0.1), rnd((1,), 1.0)
+        lg = torch.empty(T, device=DEV)
+        ops.pool_score(strided(h, pick(0, 4)), T, tok, D, w.to(DEV), b.to(DEV), lg)
+        want = (h.double().view(T, tok, D).mean(1) @ w.double() + b.double()).float()
+        return f"pool_score T={T} tokens={tok} D={D}", (lg.cpu() - want).abs().max().item(), 2e-6 * math.sqrt(D) * max(1.0, want.abs().max().item()) + 1e-5
+    if kind == "patchify":
+        dt, odt = pick(torch.float32, torch.float16, torch.bfloat16), pick(torch.float16, torch.bfloat16)
+        ps, G, T = pick(14, 14, 16, 8), ri(1, 12), ri(1, 5)
+        R = G * ps + ri(0, ps - 1)
+        kpad = ops.pad64(3 * ps * ps) + pick(0, 64)
+        pix = rnd((T, 3, R, R), 1.0, dt)
+        out = ops.patchify(pix.to(DEV), ps, kpad, odt)
+        want = pix[:, :, :G * ps, :G * ps].reshape(T, 3, G, ps, G, ps).permute(0, 2, 4, 1, 3, 5).reshape(T * G * G, 3 * ps * ps).to(odt)
+        ok = torch.equal(out[:, :3 * ps * ps].cpu(), want) and bool((out[:, 3 * ps * ps:] == 0).all())
+        return f"patchify {dt}->{odt} T={T} R={R} p={ps} kpad={kpad}", 0.0 if ok else float("inf"), 0.0
+    n = ri(1, 3000)
+    lg = rnd((n,), pick(0.5, 3.0, 20.0))
+    y = (torch.rand((n,), generator=gen) < pick(0.0, 0.02, 0.3, 1.0)).float()
+    loss, pw = ops.bce_loss(lg.to(DEV), y.to(DEV))
+    pos = y.sum()
+    wpos = min(5.0, math.sqrt((n - pos.item()) / max(1.0, pos.item())))
+    want = F.binary_cross_entropy_with_logits(lg.double(), y.double(), pos_weight=torch.tensor(wpos, dtype=torch.float64)).item()
+    err = abs(loss.item() - want) / max(abs(want), 1e-6) + abs(float(pw) - wpos)
+    return f"bce_loss n={n} pos={int(pos.item())}", err, 2e-5
+
+
 def fuzz_splitk():
     """the K-split forms (fp32 and 16-bit output) against the plain GEMM of the same call: equal up to fp32 summation order, and deterministic"""
     dt = pick(torch.float16, torch.bfloat16)
@@ -381,7 +433,7 @@ def fuzz_splitk():
 
 
 FAMILIES = [("gemm", fuzz_gemm), ("attention", fuzz_attention), ("norm", fuzz_norm), ("rank", fuzz_rank), ("pool_rope", fuzz_pool_rope), ("split", fuzz_split),
-            ("patch_embed", fuzz_patch_embed), ("preprocess", fuzz_preprocess), ("splitk", fuzz_splitk), ("fp8", fuzz_fp8)]
+            ("patch_embed", fuzz_patch_embed), ("preprocess", fuzz_preprocess), ("splitk", fuzz_splitk), ("fp8", fuzz_fp8), ("misc", fuzz_misc)]
 
 
 def main():
