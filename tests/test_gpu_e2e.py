@@ -694,3 +694,43 @@ def test_randomly_drawn_architectures_equal_the_reference(golden_dir, seed):
     print(f"{what}: split tier max |dlogit| = {e2:.2e}, fp16 default max |dscore| = {e16:.2e}")
     assert e2 <= 2e-4, what
     assert e16 <= GOLDEN_TOL[torch.float16]["chunk520"], what
+
+
+@pytest.mark.parametrize("content", ["black", "white", "zeros", "checker", "one_hot_frame", "fp16_extremes"])
+def test_degenerate_pixel_content_equals_the_oracle(content):
+    """frames a decoder really delivers at the edges: all-black / all-white clips (every patch identical: the tower's LayerNorm sees rows that differ by
+    the position table only), mid-grey zeros, a +-1 checkerboard at pixel pitch (the highest spatial frequency a patch can hold), one bright frame among
+    black ones, and values at the edge of what the processor can emit (+-1 exactly, 16-bit exact).  Oracle on the same tensors; split tier as the
+    structural gate, fp16 default at the toy-class bound."""
+    from videoitg_amd import synth
+    from videoitg_amd.config import tiny_config
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    from oracle import videoitg_oracle as O
+    cfg = tiny_config(vision_token_num=72)
+    R, T = cfg.vision.image_size, 8
+    pix = torch.zeros((T, 3, R, R))
+    if content == "black":
+        pix -= 1.0
+    elif content == "white":
+        pix += 1.0
+    elif content == "checker":
+        yy, xx = torch.meshgrid(torch.arange(R), torch.arange(R), indexing="ij")
+        pix += ((yy + xx) % 2 * 2 - 1).float()
+    elif content == "one_hot_frame":
+        pix -= 1.0
+        pix[5] = 1.0
+    elif content == "fp16_extremes":
+        g = torch.Generator().manual_seed(3)
+        pix = (torch.randint(0, 2, (T, 3, R, R), generator=g).float() * 2 - 1) * torch.tensor([1.0, 2.0 ** -8, 0.99609375])[torch.randint(0, 3, (T, 3, R, R), generator=g)]
+    sd, vsd = synth.synth_llm_state_dict(cfg, 1), synth.synth_vision_state_dict(cfg, 1)
+    ids = torch.tensor([[7, -200, 5, 6, 9]])
+    want = O.forward(cfg, sd, vsd, ids, None, [pix])[0]
+    assert torch.isfinite(want).all()
+    eng2 = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0", vit_q_prescaled=False), operand_split=True)
+    got2 = eng2.forward(ids, None, [pix.half().cuda()])[0].float().cpu()
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    got = eng.forward(ids, None, [pix.cuda()])[0].float().cpu()
+    e2, e16 = (got2 - want).abs().max().item(), (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item()
+    print(f"{content}: split tier max |dlogit| = {e2:.2e}, fp16 default max |dscore| = {e16:.2e}")
+    assert torch.isfinite(got).all() and torch.isfinite(got2).all()
+    assert e2 <= 2e-4 and e16 <= GOLDEN_TOL[torch.float16]["chunk520"], content
