@@ -146,3 +146,16 @@ def test_row_gatherer_split_api_in_place(tmp_path, world):
         for r in range(world):
             want = torch.arange(plan.n_local[r] * 6, dtype=torch.float32).view(-1, 6) + 1000 * (plan.offset[r] + it)
             assert torch.equal(allr[plan.offset[r]:plan.offset[r] + plan.n_local[r]], want)
+
+
+def test_fewer_frames_than_ranks_is_refused_before_any_collective():
+    """a rank without frames has no rows to exchange: ContextParallel.forward raises on every rank - no engine, no process group touched"""
+    from videoitg_amd.parallel import ContextParallel
+    cfg = tiny_config(vision_token_num=72)
+    eng = type("E", (), {"cfg": cfg})()
+    pix = torch.zeros((3, 3, cfg.vision.image_size, cfg.vision.image_size))
+    for rank in (0, 2, 3):
+        with pytest.raises(ValueError, match="at least one frame per rank"):
+            ContextParallel(rank, 4).forward(eng, torch.tensor([[-200, 5, 6]]), pix)
+    with pytest.raises(ValueError, match="at least one frame per rank"):
+        ContextParallel(1, 8).forward(eng, torch.tensor([[-200, 5]]), pix[:0], total_frames=5)

@@ -177,6 +177,10 @@ class ContextParallel:
             raise ValueError("exactly one <image> token per sample")
         pre, post = ids[:pos[0]], ids[pos[0] + 1:]
         T = pix.shape[0] if total_frames is None else total_frames
+        if T < self.world:
+            # a rank without frames would have no rows to exchange (and, in the middle of the group, no text either): not a mode the path has - the
+            # reference's only parallelism is one process per video.  Fail on every rank, before any collective.
+            raise ValueError(f"{T} frames over {self.world} ranks: the context-parallel forward needs at least one frame per rank (use <= {T} ranks)")
         G = pix.shape[-1] // cfg.vision.patch_size
         hw = cfg.pooled_grid(T, G)                           # GLOBAL frame count (mlp_proj.py:48)
         plan = make_plan(self.world, T, hw * hw, pre.numel(), post.numel())
