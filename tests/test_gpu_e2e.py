@@ -214,8 +214,9 @@ def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
 # (frame counts below 16 keep the single-rank reference on the same 128-tile GEMM kernels as the ranks: at 304 rows it would switch to
 # the 256-tile kernels, which differ from them in fp32 summation order - a kernel-set difference, not a sharding one)
 # (4 and 8 ranks on one GPU run in tests/test_gpu_cp_fullsize.py at full size; the 8-rank toy cost 85 s of process start-up, a 4-rank one 34 s: VERDICT r5 item 6)
-@pytest.mark.parametrize("world,frames", [(2, 9), (3, 8)])
-def test_context_parallel_multi_rank_on_one_gpu(world, frames):
+@pytest.mark.parametrize("world,frames,prompt", [(2, 9, None), (3, 8, None), (2, 5, [-200]), (2, 4, [9, 8, 7, -200])],
+                         ids=["2-9", "3-8", "2-5-image_only", "2-4-no_text_after"])
+def test_context_parallel_multi_rank_on_one_gpu(world, frames, prompt):
     """WORLD > 1 with the real kernels: `world` processes share cuda:0 and exchange over gloo (RCCL refuses two ranks on one
     device).  Frame shards are ragged (9 frames / 2 ranks, prompt tokens on the first and last rank), so global positions, the
     padded K|V all-gather + gather-rows compaction and the logits gather are all exercised.  Same arithmetic per token as the
@@ -226,7 +227,8 @@ def test_context_parallel_multi_rank_on_one_gpu(world, frames):
     if tools not in sys.path:
         sys.path.insert(0, tools)               # spawn hands sys.path to the children, which import the module by name
     import cp_two_ranks_one_gpu as mod
-    got, want = mod.run(world, frames, port=29540 + world)
+    # (prompt None = text on both sides of <image>; round 6: a prompt that is the <image> token alone - no rank owns text rows - and one with nothing after it)
+    got, want = mod.run(world, frames, port=29540 + world + (0 if prompt is None else 10 * len(prompt)), prompt=prompt)
     assert got.shape == want.shape == (frames,)
     assert (got - want).abs().max().item() <= 1e-5
 

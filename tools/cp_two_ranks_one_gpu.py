@@ -24,7 +24,7 @@ def build(fp8=False, split=False):
     return cfg, eng
 
 
-def worker(rank, world, frames, port, q, fp8=False, split=False):
+def worker(rank, world, frames, port, q, fp8=False, split=False, prompt=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -34,7 +34,7 @@ def worker(rank, world, frames, port, q, fp8=False, split=False):
         from videoitg_amd.parallel import ContextParallel
         cfg, eng = build(fp8, split)
         pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
-        ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
+        ids = torch.tensor([prompt or PROMPT])
         cp = ContextParallel(rank, world)
         fr = cp.local_frames(frames)
         local = pix[fr.start:fr.stop].clone()                 # every rank hands over ONLY its own frames
@@ -51,10 +51,13 @@ def worker(rank, world, frames, port, q, fp8=False, split=False):
         dist.destroy_process_group()
 
 
-def run(world=2, frames=9, port=29533, fp8=False, split=False):
+PROMPT = [11, 12, -200, 5, 6, 7]          # text on both sides of <image>: rank 0 owns the rows before it, the last rank the rows after it
+
+
+def run(world=2, frames=9, port=29533, fp8=False, split=False, prompt=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, world, frames, port, q, fp8, split)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, frames, port, q, fp8, split, prompt)) for r in range(world)]
     for p in procs:
         p.start()
     got = torch.tensor(q.get(timeout=600), dtype=torch.float32)
@@ -64,7 +67,7 @@ def run(world=2, frames=9, port=29533, fp8=False, split=False):
     from videoitg_amd import synth
     cfg, eng = build(fp8, split)
     pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
-    ids = torch.tensor([[11, 12, -200, 5, 6, 7]])
+    ids = torch.tensor([prompt or PROMPT])
     want = eng.forward(ids, None, [pix])[0].view(-1).float().cpu()
     return got, want
 
