@@ -360,6 +360,10 @@ def test_mp4_container_edge_cases(tmp_path, no_decoders):
     open(p4, "wb").write(raw.replace(b"vide", b"soun"))
     with pytest.raises(ValueError, match="no video track"):
         video_io.VideoReader(p4)
+    p6 = str(tmp_path / "no_stsc.mov")
+    open(p6, "wb").write(raw.replace(b"stsc", b"skip"))                   # a sample table without its sample-to-chunk box
+    with pytest.raises(ValueError, match="malformed sample table"):
+        video_io.VideoReader(p6)
     p5 = str(tmp_path / "no_moov.mp4")
     open(p5, "wb").write(ftyp + mdat)
     with pytest.raises(ValueError, match="no 'moov' box"):

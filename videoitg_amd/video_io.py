@@ -141,9 +141,12 @@ class _BmffIndex:
         moov = self._find(0, len(buf), b"moov")
         if moov is None:
             raise ValueError("no 'moov' box: not an ISO base media / QuickTime file (or a fragmented / truncated one)")
-        for cc, s, e in self._boxes(*moov):
-            if cc == b"trak" and self._track(s, e):
-                return
+        try:
+            for cc, s, e in self._boxes(*moov):
+                if cc == b"trak" and self._track(s, e):
+                    return
+        except (KeyError, IndexError, struct.error) as err:          # a table the track must have is missing, or a box is shorter than its fields
+            raise ValueError(f"malformed sample table in the video track ({type(err).__name__}: {err})") from err
         raise ValueError("no video track ('vide' handler) in the file")
 
     def _boxes(self, start: int, end: int):
