@@ -384,3 +384,23 @@ def test_get_batch_decodes_on_threads_in_index_order(tmp_path, no_decoders):
         assert np.array_equal(one, many) and np.array_equal(many[2], many[3])
         assert [int(np.abs(many[k].astype(int) - clip[i].astype(int)).mean() < 3.0) for k, i in enumerate(idx)] == [1] * len(idx)
     assert mm_utils.open_video_reader(path, num_threads=4)._threads == 4
+
+
+def test_lossless_containers_round_trip_on_random_geometries(tmp_path, no_decoders):
+    """odd widths (DIB rows pad to 4 bytes, QuickTime 'raw ' rows do not), 1-pixel frames, single-frame clips, chunking that does not divide the frame
+    count: uncompressed AVI, raw / PNG QuickTime tracks return every byte they were given"""
+    from videoitg_amd import video_io
+    rng = np.random.default_rng(11)
+    for k in range(24):
+        T, H, W = int(rng.integers(1, 7)), int(rng.integers(1, 41)), int(rng.integers(1, 41))
+        clip = rng.integers(0, 256, (T, H, W, 3), dtype=np.uint8)
+        kind = ("dib", "raw ", "png ")[k % 3]
+        path = str(tmp_path / f"c{k}.{'avi' if kind == 'dib' else 'mov'}")
+        if kind == "dib":
+            video_io.write_avi(path, clip, fps=float(rng.integers(1, 61)), codec="DIB ")
+        else:
+            video_io.write_mov(path, clip, fps=float(rng.integers(1, 61)), codec=kind, per_chunk=int(rng.integers(1, 5)), co64=bool(k & 1))
+        vr = video_io.VideoReader(path, num_threads=int(rng.integers(1, 4)))
+        assert len(vr) == T and (vr.height, vr.width) == (H, W), (kind, T, H, W)
+        assert np.array_equal(vr.get_batch(list(range(T))).asnumpy(), clip), (kind, T, H, W)
+        assert np.array_equal(vr[T - 1].asnumpy(), clip[-1])
