@@ -736,3 +736,35 @@ def test_degenerate_pixel_content_equals_the_oracle(content):
     print(f"{content}: split tier max |dlogit| = {e2:.2e}, fp16 default max |dscore| = {e16:.2e}")
     assert torch.isfinite(got).all() and torch.isfinite(got2).all()
     assert e2 <= 2e-4 and e16 <= GOLDEN_TOL[torch.float16]["chunk520"], content
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_full_width_random_shapes_equal_the_oracle(seed):
+    """the REAL layer widths (SigLIP 1152 / 4304 / 16 x 72, Qwen2 3584 / 18944, 28 q / 4 kv heads) at depth 1 + 1 on drawn frame counts, image sides (native,
+    ragged, tiny: the position table is resampled to every grid), budgets and prompt lengths: ragged M against the production tile shapes at the production
+    N and K.  Oracle on the host; split tier <= 2e-4 in logit as the structural gate, fp16 default <= north_star's 1e-3."""
+    from oracle import videoitg_oracle as O
+    from videoitg_amd import synth
+    from videoitg_amd.config import ITGConfig, VisionConfig
+    from videoitg_amd.engine import PackedWeights, SelectorEngine
+    g = torch.Generator().manual_seed(300 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g).item())       # noqa: E731
+    T, R = ri(1, 10), (56, 70, 126, 224, 230, 384)[ri(0, 5)]
+    cfg = ITGConfig(vocab_size=2048, num_hidden_layers=1, vision_token_num=(64, 400, 1600, 16384)[ri(0, 3)], vision=VisionConfig(image_size=384, num_hidden_layers=2))
+    sd, vsd = synth.synth_llm_state_dict(cfg, seed), synth.synth_vision_state_dict(cfg, seed)
+    pix = synth.synth_pixel_values(T, R, seed=900 + seed)
+    n_pre, n_post = ri(0, 6), ri(0, 24)
+    ids = torch.cat([synth.synth_prompt_ids(n_pre, cfg.vocab_size), torch.tensor([-200]), synth.synth_prompt_ids(n_post, cfg.vocab_size)]).unsqueeze(0)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    want = O.forward(cfg, sd, vsd, ids, None, [pix])[0].view(-1)
+    what = f"seed {seed}: T={T} R={R} grid {R // 14} -> {cfg.pooled_grid(T, R // 14)}, prompt {n_pre}+{n_post}, budget {cfg.vision_token_num}"
+    eng2 = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0", vit_q_prescaled=False), operand_split=True)
+    got2 = eng2.forward(ids, None, [pix.half().cuda()])[0].view(-1).float().cpu()
+    eng2.release_workspace()
+    del eng2
+    eng = SelectorEngine(PackedWeights.from_state_dicts(cfg, sd, vsd, torch.float16, "cuda:0"))
+    got = eng.forward(ids, None, [pix.cuda()])[0].view(-1).float().cpu()
+    e2, e16 = (got2 - want).abs().max().item(), (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item()
+    print(f"{what}: split tier max |dlogit| = {e2:.2e}, fp16 default max |dscore| = {e16:.2e}")
+    assert e2 <= 2e-4, what
+    assert e16 <= SCORE_TOL, what
