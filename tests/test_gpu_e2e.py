@@ -417,8 +417,10 @@ def test_infer_entry_point_runs_offline():
         assert sorted(os.listdir(vis)) == [f"frame_{i:03d}_idx{f}.jpg" for i, f in enumerate(sel)]
 
 
-def test_infer_entry_point_on_a_real_video_file():
-    """python infer.py --video clip.avi on a REAL file (infer.py:44-51, 81-94): a 20 s MJPEG-in-AVI clip written here, decoded by
+@pytest.mark.parametrize("container", ["avi", "mp4"])
+def test_infer_entry_point_on_a_real_video_file(container):
+    """(round 6: also an .mp4 whose track is Motion-JPEG as MP4 muxers label it - 'mp4v' + esds object type 0x6C - through the built-in demux)
+    python infer.py --video clip.avi on a REAL file (infer.py:44-51, 81-94): a 20 s MJPEG-in-AVI clip written here, decoded by
     the built-in reader (decord is not in the image), sampled at 2 fps by get_frame_indices, scored on the GPU; the Top-K are original frame
     indices out of the sampler's list and the saved JPEGs are those frames of the file."""
     import ast
@@ -436,8 +438,11 @@ def test_infer_entry_point_on_a_real_video_file():
         clip[i] = (i * 7) % 200 + 20
         clip[i, 10:30, (i % 60):(i % 60) + 20] = (240, 30, 60)
     with tempfile.TemporaryDirectory() as tmp:
-        path, vis = os.path.join(tmp, "clip.avi"), os.path.join(tmp, "vis")
-        video_io.write_avi(path, clip, fps=fps, codec="MJPG")
+        path, vis = os.path.join(tmp, f"clip.{container}"), os.path.join(tmp, "vis")
+        if container == "avi":
+            video_io.write_avi(path, clip, fps=fps, codec="MJPG")
+        else:
+            video_io.write_mov(path, clip, fps=fps, codec="mp4v-jpeg", per_chunk=25)
         out = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--model", "synthetic:tiny", "--video", path, "--topk", "6",
                               "--num-frames", "32", "--save-dir", vis], capture_output=True, text=True, timeout=600, cwd=root)
         assert out.returncode == 0, out.stderr[-2000:]
