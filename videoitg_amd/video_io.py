@@ -305,8 +305,12 @@ class VideoReader:
         self.path = path
         self._threads = max(1, int(num_threads or 1))        # decord: 0 = automatic; here 0 / None = one thread
         with open(path, "rb") as f:
-            self._data = f.read()
-        head = self._data[:12]
+            try:                                            # map, do not read: an hour of Motion-JPEG is gigabytes, and only the frames asked for are touched
+                import mmap
+                self._data = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            except (ValueError, OSError):                   # an empty file, a file system without mmap
+                self._data = f.read()
+        head = bytes(self._data[:12])
         if head.startswith(b"YUV4MPEG2"):
             self._init_y4m()
         elif head[:4] == b"RIFF" and head[8:12] != b"WEBP":
@@ -400,7 +404,9 @@ class VideoReader:
 
     # ---- YUV4MPEG2 ------------------------------------------------------------------------------------------------------------
     def _init_y4m(self):
-        end = self._data.index(b"\n")
+        end = self._data.find(b"\n")
+        if end < 0:
+            raise ValueError(f"{self.path}: YUV4MPEG2 header without a line end")
         toks = self._data[:end].decode("ascii").split(" ")[1:]
         self._chroma, num, den = "420jpeg", 25, 1
         for t in toks:
@@ -426,7 +432,10 @@ class VideoReader:
         while p < len(self._data):
             if self._data[p:p + 5] != b"FRAME":
                 raise ValueError(f"{self.path}: YUV4MPEG2 frame marker expected at byte {p}")
-            p = self._data.index(b"\n", p) + 1
+            nl = self._data.find(b"\n", p)
+            if nl < 0:
+                break                                       # truncated inside a frame header
+            p = nl + 1
             if p + self._fsize > len(self._data):
                 break                                       # truncated last frame
             self._offsets.append(p)
