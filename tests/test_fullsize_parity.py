@@ -108,9 +108,14 @@ def compare(rec, got):
     return ds, dl, sorted(order[:k]) == rec["topk"], order
 
 
+# (the secondary tier runs every fixture but the two 512-frame planted twins: its Top-K assertion on a planted gap stays on c1p / c0p / depth16p, and the
+# pair cost the suite 12 s of the 480 it is held to - VERDICT r5 item 6)
+FIXTURE_DTYPES = [pytest.param(n, d, id=f"{n}-{'fp16' if d == torch.float16 else 'bf16'}") for n in CASES for d in (torch.float16, torch.bfloat16)
+                  if not (d == torch.bfloat16 and n in ("c2p_512x448", "b0p_512x384"))]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name,dtype", FIXTURE_DTYPES)
 def test_full_depth_matches_oracle(golden_dir, name, dtype):
     rec = load_case(golden_dir, name)
     got = gpu_logits(rec, dtype)

@@ -214,8 +214,10 @@ def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
 # (frame counts below 16 keep the single-rank reference on the same 128-tile GEMM kernels as the ranks: at 304 rows it would switch to
 # the 256-tile kernels, which differ from them in fp32 summation order - a kernel-set difference, not a sharding one)
 # (4 and 8 ranks on one GPU run in tests/test_gpu_cp_fullsize.py at full size; the 8-rank toy cost 85 s of process start-up, a 4-rank one 34 s: VERDICT r5 item 6)
-@pytest.mark.parametrize("world,frames,prompt", [(2, 9, None), (3, 8, None), (2, 5, [-200]), (2, 4, [9, 8, 7, -200])],
-                         ids=["2-9", "3-8", "2-5-image_only", "2-4-no_text_after"])
+# (a 3-rank toy run - a middle rank without text rows - cost 16 s of process start-up; middle ranks run at full size in tests/test_gpu_cp_fullsize.py
+# (8 and 4 ranks) and in the gloo CPU tests, so round 6 traded it for the two prompt shapes below)
+@pytest.mark.parametrize("world,frames,prompt", [(2, 9, None), (2, 5, [-200]), (2, 4, [9, 8, 7, -200])],
+                         ids=["2-9", "2-5-image_only", "2-4-no_text_after"])
 def test_context_parallel_multi_rank_on_one_gpu(world, frames, prompt):
     """WORLD > 1 with the real kernels: `world` processes share cuda:0 and exchange over gloo (RCCL refuses two ranks on one
     device).  Frame shards are ragged (9 frames / 2 ranks, prompt tokens on the first and last rank), so global positions, the
@@ -251,7 +253,7 @@ def test_context_parallel_fp8_weight_path_on_one_gpu():
     assert d <= 5e-2, d
 
 
-@pytest.mark.parametrize("vit_layers,llm_layers", [(3, 2), (6, 5)])
+@pytest.mark.parametrize("vit_layers,llm_layers", [(6, 5)])      # ((3, 2) went when test_full_width_random_shapes_equal_the_oracle arrived: six drawn shapes at depth 1 + 1)
 def test_full_width_reduced_depth_parity(vit_layers, llm_layers):
     """Real layer widths (SigLIP 1152/4304/16x72, Qwen2 3584/18944, 28 q / 4 kv heads x128, pos-emb interpolation to a
     non-native grid, 16->10 token pool) at reduced depth / frame count so the fp32 oracle finishes on the host: every
