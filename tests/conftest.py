@@ -36,3 +36,24 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+CP_TOY_CASES = {          # name -> case of tools/cp_two_ranks_one_gpu.py: run_many (two ranks on cuda:0 over gloo, tiny model)
+    "2-9": dict(frames=9),                                   # ragged 5 + 4 frames, text on both sides of <image>
+    "2-5-image_only": dict(frames=5, prompt=[-200]),         # no rank owns text rows
+    "2-4-no_text_after": dict(frames=4, prompt=[9, 8, 7, -200]),
+    "fp8": dict(frames=9, fp8=True),
+    "split": dict(frames=9, split=True),
+}
+
+
+@pytest.fixture(scope="session")
+def cp_toy():
+    """the toy context-parallel runs of the suite through ONE pair of rank processes (each spawn re-imports torch and rebuilds its models: five separate
+    spawns cost 20 - 70 s depending on the box's page cache; VERDICT r5 item 6 holds the suite to 480 s) -> {name: (logits of the 2-rank job, single-rank logits)}"""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)               # spawn hands sys.path to the children, which import the module by name
+    import cp_two_ranks_one_gpu as mod
+    names = list(CP_TOY_CASES)
+    return dict(zip(names, mod.run_many(2, [CP_TOY_CASES[n] for n in names], port=29571)))

@@ -215,38 +215,25 @@ def test_context_parallel_path_world1_equals_plain_forward(golden_dir):
 # the 256-tile kernels, which differ from them in fp32 summation order - a kernel-set difference, not a sharding one)
 # (4 and 8 ranks on one GPU run in tests/test_gpu_cp_fullsize.py at full size; the 8-rank toy cost 85 s of process start-up, a 4-rank one 34 s: VERDICT r5 item 6)
 # (a 3-rank toy run - a middle rank without text rows - cost 16 s of process start-up; middle ranks run at full size in tests/test_gpu_cp_fullsize.py
-# (8 and 4 ranks) and in the gloo CPU tests, so round 6 traded it for the two prompt shapes below)
-@pytest.mark.parametrize("world,frames,prompt", [(2, 9, None), (2, 5, [-200]), (2, 4, [9, 8, 7, -200])],
-                         ids=["2-9", "2-5-image_only", "2-4-no_text_after"])
-def test_context_parallel_multi_rank_on_one_gpu(world, frames, prompt):
-    """WORLD > 1 with the real kernels: `world` processes share cuda:0 and exchange over gloo (RCCL refuses two ranks on one
+# (8 and 4 ranks) and in the gloo CPU tests, so round 6 traded it for the two prompt shapes below; all toy runs share ONE pair of rank processes: conftest cp_toy)
+@pytest.mark.parametrize("case", ["2-9", "2-5-image_only", "2-4-no_text_after"])
+def test_context_parallel_multi_rank_on_one_gpu(cp_toy, case):
+    """WORLD > 1 with the real kernels: two processes share cuda:0 and exchange over gloo (RCCL refuses two ranks on one
     device).  Frame shards are ragged (9 frames / 2 ranks, prompt tokens on the first and last rank), so global positions, the
-    padded K|V all-gather + gather-rows compaction and the logits gather are all exercised.  Same arithmetic per token as the
-    single-rank forward -> identical logits."""
-    import os
-    import sys
-    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
-    if tools not in sys.path:
-        sys.path.insert(0, tools)               # spawn hands sys.path to the children, which import the module by name
-    import cp_two_ranks_one_gpu as mod
-    # (prompt None = text on both sides of <image>; round 6: a prompt that is the <image> token alone - no rank owns text rows - and one with nothing after it)
-    got, want = mod.run(world, frames, port=29540 + world + (0 if prompt is None else 10 * len(prompt)), prompt=prompt)
-    assert got.shape == want.shape == (frames,)
+    padded K|V all-gather + gather-rows compaction and the logits gather are all exercised; round 6: a prompt that is the <image> token alone - no rank
+    owns text - and one with nothing after it.  Same arithmetic per token as the single-rank forward -> identical logits."""
+    from conftest import CP_TOY_CASES
+    got, want = cp_toy[case]
+    assert got.shape == want.shape == (CP_TOY_CASES[case]["frames"],)
     assert (got - want).abs().max().item() <= 1e-5
 
 
-def test_context_parallel_fp8_weight_path_on_one_gpu():
+def test_context_parallel_fp8_weight_path_on_one_gpu(cp_toy):
     """BASELINE.json configs[4] names the fp8 weight path at 1 AND 8 GPUs: the context-parallel forward on fp8 weights (per-token
     activation scales are row-local, so sharding the rows changes nothing but the kernels' block partition).  Two ranks on one GPU
-    over gloo against the single-rank fp8 forward; the bound is the fp8 tier's own (an fp32 rounding difference in front of a
-    quantiser can move an e4m3 code)."""
-    import os
-    import sys
-    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
-    if tools not in sys.path:
-        sys.path.insert(0, tools)
-    import cp_two_ranks_one_gpu as mod
-    got, want = mod.run(2, 9, port=29551, fp8=True)          # (ragged: 5 + 4 frames; 2 ranks since round 6 - the full-size fp8 run covers 8)
+    over gloo against the single-rank fp8 forward (ragged: 5 + 4 frames; the full-size fp8 run covers 8 ranks); the bound is the fp8 tier's own (an fp32
+    rounding difference in front of a quantiser can move an e4m3 code)."""
+    got, want = cp_toy["fp8"]
     assert got.shape == want.shape == (9,) and torch.isfinite(got).all()
     d = (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item()
     print(f"context-parallel fp8, 2 ranks: max|dscore| vs single-rank fp8 = {d:.2e}")

@@ -414,16 +414,12 @@ def test_bilinear_pool_split_on_compact_rows_and_the_compact_last_layer():
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-5
 
 
-def test_operand_split_tier_context_parallel_on_one_gpu():
+def test_operand_split_tier_context_parallel_on_one_gpu(cp_toy):
     """BASELINE configs[2] in the operand-split tier: two ranks share cuda:0 over gloo, frame-sharded tower (compact last layer, GLOBAL pooled grid),
     K|V exchanged as (hi, lo) PAIRS through the blocking all-gather, 3-term attention of the local queries against all keys - against the one-rank forward of
-    the same tier (same arithmetic per token: fp32 rounding apart) and, through it, the oracle"""
-    import sys
-    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
-    if tools not in sys.path:
-        sys.path.insert(0, tools)
-    import cp_two_ranks_one_gpu as mod
-    got, want = mod.run(2, 9, port=29553, split=True)            # ragged: 5 + 4 frames, prompt tokens on both ends
+    the same tier (same arithmetic per token: fp32 rounding apart) and, through it, the oracle (ragged: 5 + 4 frames, prompt tokens on both ends; the run
+    shares its rank processes with the other toy context-parallel cases: conftest cp_toy)"""
+    got, want = cp_toy["split"]
     assert got.shape == want.shape == (9,) and torch.isfinite(got).all()
     d = (got - want).abs().max().item()
     print(f"operand-split tier, context-parallel x2: max|dlogit| vs one rank = {d:.2e}")

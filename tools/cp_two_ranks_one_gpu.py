@@ -72,6 +72,66 @@ def run(world=2, frames=9, port=29533, fp8=False, split=False, prompt=None):
     return got, want
 
 
+
+# ---- several cases through ONE set of rank processes (each spawn re-imports torch and rebuilds a model: 4-15 s per case on a cold box) ---------------
+def worker_many(rank, world, cases, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from videoitg_amd import synth
+        from videoitg_amd.parallel import ContextParallel
+        engines, outs = {}, []
+        for c in cases:
+            key = (bool(c.get("fp8")), bool(c.get("split")))
+            if key not in engines:
+                engines[key] = build(*key)
+            cfg, eng = engines[key]
+            frames = c["frames"]
+            pix = synth.synth_pixel_values(frames, cfg.vision.image_size, seed=1234).cuda()
+            ids = torch.tensor([c.get("prompt") or PROMPT])
+            cp = ContextParallel(rank, world)
+            fr = cp.local_frames(frames)
+            local = pix[fr.start:fr.stop].clone()
+            first = cp.forward(eng, ids, local, total_frames=frames)
+            out = cp.forward(eng, ids, local, total_frames=frames)          # second call: cached gatherer
+            assert torch.equal(first, out) and len(cp._gatherers) == 1
+            assert torch.equal(cp.forward(eng, ids, pix), out)              # the whole video resident: same result
+            torch.cuda.synchronize()
+            outs.append(out.float().cpu().tolist())
+        if rank == 0:
+            q.put(outs)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def run_many(world, cases, port=29570):
+    """cases: [{"frames": T, "prompt": [...] | None, "fp8": bool, "split": bool}, ...] -> [(got, want), ...]: every case through the same `world` processes,
+    `want` = the single-rank forward of the same engine in this process"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker_many, args=(r, world, cases, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = q.get(timeout=900)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, p.exitcode
+    from videoitg_amd import synth
+    engines, res = {}, []
+    for c, got in zip(cases, outs):
+        key = (bool(c.get("fp8")), bool(c.get("split")))
+        if key not in engines:
+            engines[key] = build(*key)
+        cfg, eng = engines[key]
+        pix = synth.synth_pixel_values(c["frames"], cfg.vision.image_size, seed=1234).cuda()
+        ids = torch.tensor([c.get("prompt") or PROMPT])
+        want = eng.forward(ids, None, [pix])[0].view(-1).float().cpu()
+        res.append((torch.tensor(got, dtype=torch.float32), want))
+    return res
+
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 9
